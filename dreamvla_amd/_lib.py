@@ -1,0 +1,105 @@
+"""ctypes binding of libdvla_hip.so (C ABI declared in include/dvla.h).
+
+The product path has NO CPU / eager fallback: if the shared library is missing or a kernel is asked to run
+on a non-CUDA tensor the call raises.  (`oracle/` holds the CPU restatement used only as a checker.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvla_hip.so")
+
+DT_BF16, DT_F32 = 0, 1
+ACT = {"none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "gelu_new": 2, "relu": 3, "silu": 4,
+       "quick_gelu": 5, "tanh": 6, "sigmoid": 7}
+
+DVLA_ERRORS = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported shape/alignment"}
+
+
+class DvlaError(RuntimeError):
+    pass
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64), ("a_trans", C.c_int32),
+        ("B", C.c_void_p), ("ldb", C.c_int64), ("b_trans", C.c_int32),
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_dtype", C.c_int32),
+        ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+        ("bias", C.c_void_p), ("bias_dtype", C.c_int32),
+        ("act", C.c_int32),
+        ("preact", C.c_void_p), ("ld_preact", C.c_int64),
+        ("dact_aux", C.c_void_p), ("ld_dact", C.c_int64), ("dact", C.c_int32),
+        ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+        ("residual", C.c_void_p), ("ld_res", C.c_int64),
+        ("accumulate", C.c_int32),
+        ("split_k", C.c_int32), ("workspace", C.c_void_p),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+        ("q_stride_b", C.c_int64), ("q_stride_t", C.c_int64), ("q_stride_h", C.c_int64),
+        ("k_stride_b", C.c_int64), ("k_stride_t", C.c_int64), ("k_stride_h", C.c_int64),
+        ("v_stride_b", C.c_int64), ("v_stride_t", C.c_int64), ("v_stride_h", C.c_int64),
+        ("o_stride_b", C.c_int64), ("o_stride_t", C.c_int64), ("o_stride_h", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
+        ("scale", C.c_float),
+        ("mask", C.c_void_p), ("ld_mask", C.c_int64),
+        ("tile_map", C.c_void_p),
+        ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+        ("lse", C.c_void_p),
+        ("dout", C.c_void_p), ("do_stride_b", C.c_int64), ("do_stride_t", C.c_int64), ("do_stride_h", C.c_int64),
+        ("delta", C.c_void_p),
+        ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+        ("dq_stride_b", C.c_int64), ("dq_stride_t", C.c_int64), ("dq_stride_h", C.c_int64),
+        ("dk_stride_b", C.c_int64), ("dk_stride_t", C.c_int64), ("dk_stride_h", C.c_int64),
+        ("dv_stride_b", C.c_int64), ("dv_stride_t", C.c_int64), ("dv_stride_h", C.c_int64),
+    ]
+
+
+# every symbol include/dvla.h declares: (name, restype, argtypes)
+_P, _I64, _I32, _F, _U32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint32
+SYMBOLS = {
+    "dvla_abi_version": (C.c_int, []),
+    "dvla_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), _P]),
+    "dvla_layernorm_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I64, _I64, _F, _P]),
+    "dvla_layernorm_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "dvla_layernorm_bwd_partial_rows": (_I64, []),
+    "dvla_attn_fwd": (C.c_int, [C.POINTER(AttnParams), _P]),
+    "dvla_attn_bwd": (C.c_int, [C.POINTER(AttnParams), _P]),
+    "dvla_colsum": (C.c_int, [_P, _I64, _I64, _I64, _P, _P, _P]),
+    "dvla_colsum_partial_rows": (_I64, []),
+    "dvla_dropout": (C.c_int, [_P, _P, _I64, _I64, _F, _U32, _U32, _P]),
+    "dvla_act_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _F, _U32, _U32, _P]),
+    "dvla_act_fwd": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "dvla_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
+    "dvla_cast_bf16_to_f32": (C.c_int, [_P, _P, _I64, _P]),
+    "dvla_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises DvlaError with build instructions when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DvlaError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (hipcc --offload-arch=gfx950) from the repo root. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DvlaError(f"{what} failed: {DVLA_ERRORS.get(rc, 'error')} (code {rc})")

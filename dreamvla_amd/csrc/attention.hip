@@ -1,0 +1,558 @@
+// attention.hip -- fused multi-head attention (head_dim 64) forward + backward for gfx950.
+//
+// "Transposed flash attention": every score tile is computed as S^T = K.Q^T with
+// v_mfma_f32_32x32x16_bf16(a = K fragment, b = Q fragment), so a lane owns ONE query column
+// (q = lane & 31) and 16 of the 32 keys of the tile in its accumulator registers
+// (key = (r&3) + 8*(r>>2) + 4*(lane>>5)).  Consequences:
+//   * the softmax row max / row sum are in-lane reductions plus ONE __shfl_xor(.,32);
+//   * the running max m, sum l and the O rescale factor are per-lane scalars;
+//   * P (bf16) is already in MFMA B-operand layout for O^T = V^T.P^T: no cross-lane movement, no LDS
+//     round trip for P.  The k-slot <-> key permutation this implies is applied to the V^T fragment,
+//     which is read from a "pair-interleaved" LDS image [key/2][d] (dword = {key even, key odd}).
+// K/V tiles (32 keys) are staged global -> registers -> LDS once per 128-query block (4 waves share
+// them), double-buffered with the next tile's global loads in flight during the MFMAs; one barrier per
+// tile.  Fully masked 32x32 tiles (tile_map == 0) are skipped: that is 64-81 % of the trunk's tiles
+// under generate_attention_mask (models/dreamvla_model.py:25-66).
+//
+// Backward = delta kernel (rowsum dO.O) + dQ kernel (same structure as forward) + dK/dV kernel (a wave
+// owns 32 keys, loops over query tiles; S = Q.K^T orientation so a lane owns one key and dK^T/dV^T
+// accumulate in registers).  No atomics; S is recomputed in each (7 MFMA passes instead of 5).
+#include "common.h"
+#include "../../include/dvla.h"
+
+namespace {
+
+constexpr int AT_THREADS = 256;
+constexpr int RM72 = 72;                 // row-major LDS row stride in bf16 (144 B, 16-B aligned, conflict-free)
+constexpr int RM_BYTES = 32 * RM72 * 2;  // 4608
+constexpr int PI_BYTES = 16 * 64 * 4;    // 4096
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnKArgs {
+  const bf16_t *q, *k, *v; bf16_t* o;
+  int64_t qsb, qst, qsh, ksb, kst, ksh, vsb, vst, vsh, osb, ost, osh;
+  int B, H, Lq, Lk;
+  float scale;
+  const float* mask; int64_t ldm;
+  const uint8_t* tile_map; int nqt, nkt;
+  int has_drop; uint32_t drop_thr; float inv_keep; uint32_t seed_lo, seed_hi;
+  float* lse;
+  const bf16_t* dout; int64_t dsb, dst, dsh;
+  float* delta;
+  bf16_t *dq, *dk, *dv;
+  int64_t dqsb, dqst, dqsh, dksb, dkst, dksh, dvsb, dvst, dvsh;
+};
+
+// accumulator register r of lane group g  <->  row index inside the 32-row MFMA tile
+__device__ __forceinline__ int acc_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+__device__ __forceinline__ uint4 load_row16(const bf16_t* base, int64_t row, int64_t nrows, int64_t stride, int col) {
+  if (row < nrows) return *reinterpret_cast<const uint4*>(base + row * stride + col);
+  return make_uint4(0u, 0u, 0u, 0u);
+}
+
+// thread `u` (0..127) of a 128-thread staging group owns rows (2*pr, 2*pr+1), columns oct*8..oct*8+7
+__device__ __forceinline__ void stage_rows_load(uint4 (&reg)[2], const bf16_t* base, int64_t stride, int64_t row0,
+                                                int64_t nrows, int u) {
+  const int pr = u >> 3, oct = u & 7;
+  reg[0] = load_row16(base, row0 + 2 * pr, nrows, stride, oct * 8);
+  reg[1] = load_row16(base, row0 + 2 * pr + 1, nrows, stride, oct * 8);
+}
+__device__ __forceinline__ void stage_store_rm(const uint4 (&reg)[2], char* lds, int u) {
+  const int pr = u >> 3, oct = u & 7;
+  *reinterpret_cast<uint4*>(lds + ((2 * pr) * RM72 + oct * 8) * 2) = reg[0];
+  *reinterpret_cast<uint4*>(lds + ((2 * pr + 1) * RM72 + oct * 8) * 2) = reg[1];
+}
+__device__ __forceinline__ void stage_store_pi(const uint4 (&reg)[2], char* lds, int u) {
+  const int pr = u >> 3, oct = u & 7;
+  const uint32_t a[4] = {reg[0].x, reg[0].y, reg[0].z, reg[0].w};  // even row, cols oct*8 + {0,1},{2,3},...
+  const uint32_t b[4] = {reg[1].x, reg[1].y, reg[1].z, reg[1].w};  // odd row
+  uint32_t o[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = (a[i] & 0xffffu) | (b[i] << 16);
+    o[2 * i + 1] = (a[i] >> 16) | (b[i] & 0xffff0000u);
+  }
+  uint32_t* dst = reinterpret_cast<uint32_t*>(lds) + pr * 64 + oct * 8;
+  *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+}
+// row-major fragment: row (lane&31) of the tile, d-slots 16*s + 8*g .. +7
+__device__ __forceinline__ bf16x8 frag_rm(const char* lds, int row, int s, int g) {
+  return *reinterpret_cast<const bf16x8*>(lds + (row * RM72 + s * 16 + g * 8) * 2);
+}
+// transposed fragment from the pair-interleaved image: "row" index = column c (a d value), k-slots =
+// tile rows acc_row(8*mm + jj, g), jj = 0..7   (pairs 8mm+2g, 8mm+2g+1, 8mm+4+2g, 8mm+4+2g+1)
+__device__ __forceinline__ bf16x8 frag_pi(const char* lds, int c, int mm, int g) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(lds) + (8 * mm + 2 * g) * 64 + c;
+  union { uint32_t w[4]; bf16x8 v; } u;
+  u.w[0] = src[0]; u.w[1] = src[64]; u.w[2] = src[4 * 64]; u.w[3] = src[5 * 64];
+  return u.v;
+}
+__device__ __forceinline__ bf16x8 pack_frag(const float* p) {
+  union { uint32_t w[4]; bf16x8 v; } u;
+  u.w[0] = pack2bf(p[0], p[1]); u.w[1] = pack2bf(p[2], p[3]);
+  u.w[2] = pack2bf(p[4], p[5]); u.w[3] = pack2bf(p[6], p[7]);
+  return u.v;
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+// store the transposed accumulators (lane = token row, regs = d) of one token as 16 x 8-byte pieces
+__device__ __forceinline__ void store_token(bf16_t* dst, const f32x16 (&acc)[2], float mul, int g) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int d = 32 * db + 8 * rq + 4 * g;
+      *reinterpret_cast<uint2*>(dst + d) = make_uint2(pack2bf(acc[db][4 * rq] * mul, acc[db][4 * rq + 1] * mul),
+                                                      pack2bf(acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul));
+    }
+}
+
+// block-level "is tile (qt..qt+3, kt) needed" and next needed tile
+__device__ __forceinline__ int tile_flag(const AttnKArgs& p, int qt, int kt) {
+  if (qt >= p.nqt) return 0;
+  if (p.tile_map) return p.tile_map[qt * p.nkt + kt];
+  return p.mask ? 2 : 1;
+}
+
+// ====================================================================================================
+// forward
+// ====================================================================================================
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (RM_BYTES + PI_BYTES)];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qt0 = blockIdx.x * 4;
+  const int qt = qt0 + wave;
+  const int64_t q = (int64_t)qt * 32 + l31;
+  const float scale_log2 = p.scale * LOG2E;
+
+  const bf16_t* qb = p.q + b * p.qsb + h * p.qsh;
+  const bf16_t* kb = p.k + b * p.ksb + h * p.ksh;
+  const bf16_t* vb = p.v + b * p.vsb + h * p.vsh;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 u = load_row16(qb, q, p.Lq, p.qst, 16 * s + 8 * g);
+    qf[s] = *reinterpret_cast<const bf16x8*>(&u);
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 oacc[2] = {zero16(), zero16()};
+  uint32_t rowkey = 0;
+  if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(((int64_t)b * p.H + h) * p.Lq + q));
+
+  // block-uniform list walk over needed key tiles
+  auto blk_need = [&](int kt) -> bool {
+    return (tile_flag(p, qt0, kt) | tile_flag(p, qt0 + 1, kt) | tile_flag(p, qt0 + 2, kt) | tile_flag(p, qt0 + 3, kt)) != 0;
+  };
+  auto next_needed = [&](int kt) -> int {
+    while (kt < p.nkt && !blk_need(kt)) ++kt;
+    return kt < p.nkt ? kt : -1;
+  };
+  const bool is_v_loader = t < 128;
+  const int u = is_v_loader ? t : t - 128;
+  uint4 reg[2];
+  auto g_load = [&](int kt) {
+    if (is_v_loader) stage_rows_load(reg, vb, p.vst, (int64_t)kt * 32, p.Lk, u);
+    else stage_rows_load(reg, kb, p.kst, (int64_t)kt * 32, p.Lk, u);
+  };
+  auto l_store = [&](int buf) {
+    char* base = smem + buf * (RM_BYTES + PI_BYTES);
+    if (is_v_loader) stage_store_pi(reg, base + RM_BYTES, u);
+    else stage_store_rm(reg, base, u);
+  };
+
+  int kt = next_needed(0);
+  if (kt >= 0) { g_load(kt); l_store(0); }
+  __syncthreads();
+  int cur = 0;
+  while (kt >= 0) {
+    const int ktn = next_needed(kt + 1);
+    if (ktn >= 0) g_load(ktn);
+    const int flag = tile_flag(p, qt, kt);
+    if (flag != 0) {
+      const char* ks = smem + cur * (RM_BYTES + PI_BYTES);
+      const char* vs = ks + RM_BYTES;
+      f32x16 sacc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
+      float sv[16];
+      float mt = -INFINITY;
+      const int64_t k0 = (int64_t)kt * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t key = k0 + acc_row(r, g);
+        float x = sacc[r] * scale_log2;
+        if (flag == 2 && q < p.Lq && key < p.Lk) x += p.mask[q * p.ldm + key] * LOG2E;
+        if (key >= p.Lk) x = -INFINITY;
+        sv[r] = x;
+        mt = fmaxf(mt, x);
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = exp2f(m_run - m_safe);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sv[r] = exp2f(sv[r] - m_safe); rs += sv[r]; }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+      if (p.has_drop) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)(k0 + acc_row(r, g)));
+          sv[r] = (hsh >= p.drop_thr) ? sv[r] * p.inv_keep : 0.f;
+        }
+      }
+      const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_pi(vs, 32 * db + l31, 0, g), pf0, oacc[db], 0, 0, 0);
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_pi(vs, 32 * db + l31, 1, g), pf1, oacc[db], 0, 0, 0);
+      }
+    }
+    if (ktn >= 0) l_store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+    kt = ktn;
+  }
+  if (q < p.Lq) {
+    const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
+    store_token(p.o + b * p.osb + q * p.ost + h * p.osh, oacc, inv_l, g);
+    if (p.lse && g == 0)
+      p.lse[((int64_t)b * p.H + h) * p.Lq + q] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
+  }
+}
+
+// ====================================================================================================
+// backward: delta[b,h,q] = sum_d dO * O   (8 lanes per row of 64)
+// ====================================================================================================
+__global__ void attn_delta_kernel(AttnKArgs p) {
+  const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gt >> 3;
+  const int part = (int)(gt & 7);
+  const int64_t nrows = (int64_t)p.B * p.H * p.Lq;
+  float s = 0.f;
+  if (row < nrows) {
+    const int64_t q = row % p.Lq, bh = row / p.Lq, h = bh % p.H, b = bh / p.H;
+    const uint4 a = *reinterpret_cast<const uint4*>(p.dout + b * p.dsb + q * p.dst + h * p.dsh + part * 8);
+    const uint4 c = *reinterpret_cast<const uint4*>(p.o + b * p.osb + q * p.ost + h * p.osh + part * 8);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s += bf2f((bf16_t)(aw[i] & 0xffff)) * bf2f((bf16_t)(cw[i] & 0xffff));
+      s += bf2f((bf16_t)(aw[i] >> 16)) * bf2f((bf16_t)(cw[i] >> 16));
+    }
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (row < nrows && part == 0) p.delta[row] = s;
+}
+
+// ====================================================================================================
+// backward: dQ  (one wave = 32 queries, loop over key tiles; same orientation as forward)
+//   LDS per buffer: K row-major | K pair-interleaved | V row-major
+// ====================================================================================================
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
+  constexpr int BUF = 2 * RM_BYTES + PI_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qt0 = blockIdx.x * 4;
+  const int qt = qt0 + wave;
+  const int64_t q = (int64_t)qt * 32 + l31;
+  const float scale_log2 = p.scale * LOG2E;
+  const bf16_t* qb = p.q + b * p.qsb + h * p.qsh;
+  const bf16_t* kb = p.k + b * p.ksb + h * p.ksh;
+  const bf16_t* vb = p.v + b * p.vsb + h * p.vsh;
+  const bf16_t* dob = p.dout + b * p.dsb + h * p.dsh;
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 a = load_row16(qb, q, p.Lq, p.qst, 16 * s + 8 * g);
+    const uint4 c = load_row16(dob, q, p.Lq, p.dst, 16 * s + 8 * g);
+    qf[s] = *reinterpret_cast<const bf16x8*>(&a);
+    dof[s] = *reinterpret_cast<const bf16x8*>(&c);
+  }
+  const int64_t rowid = ((int64_t)b * p.H + h) * p.Lq + q;
+  const float lse2 = (q < p.Lq) ? p.lse[rowid] * LOG2E : INFINITY;
+  const float dlt = (q < p.Lq) ? p.delta[rowid] : 0.f;
+  uint32_t rowkey = 0;
+  if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
+  f32x16 dqacc[2] = {zero16(), zero16()};
+
+  auto blk_need = [&](int kt) -> bool {
+    return (tile_flag(p, qt0, kt) | tile_flag(p, qt0 + 1, kt) | tile_flag(p, qt0 + 2, kt) | tile_flag(p, qt0 + 3, kt)) != 0;
+  };
+  auto next_needed = [&](int kt) -> int {
+    while (kt < p.nkt && !blk_need(kt)) ++kt;
+    return kt < p.nkt ? kt : -1;
+  };
+  const bool is_k_loader = t < 128;
+  const int u = is_k_loader ? t : t - 128;
+  uint4 reg[2];
+  auto g_load = [&](int kt) {
+    if (is_k_loader) stage_rows_load(reg, kb, p.kst, (int64_t)kt * 32, p.Lk, u);
+    else stage_rows_load(reg, vb, p.vst, (int64_t)kt * 32, p.Lk, u);
+  };
+  auto l_store = [&](int buf) {
+    char* base = smem + buf * BUF;
+    if (is_k_loader) { stage_store_rm(reg, base, u); stage_store_pi(reg, base + RM_BYTES, u); }
+    else stage_store_rm(reg, base + RM_BYTES + PI_BYTES, u);
+  };
+
+  int kt = next_needed(0);
+  if (kt >= 0) { g_load(kt); l_store(0); }
+  __syncthreads();
+  int cur = 0;
+  while (kt >= 0) {
+    const int ktn = next_needed(kt + 1);
+    if (ktn >= 0) g_load(ktn);
+    const int flag = tile_flag(p, qt, kt);
+    if (flag != 0) {
+      const char* k_rm = smem + cur * BUF;
+      const char* k_pi = k_rm + RM_BYTES;
+      const char* v_rm = k_pi + PI_BYTES;
+      f32x16 sacc = zero16(), dpacc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(k_rm, l31, s, g), qf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(v_rm, l31, s, g), dof[s], dpacc, 0, 0, 0);
+      }
+      float ds[16];
+      const int64_t k0 = (int64_t)kt * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t key = k0 + acc_row(r, g);
+        float x = sacc[r] * scale_log2;
+        if (flag == 2 && q < p.Lq && key < p.Lk) x += p.mask[q * p.ldm + key] * LOG2E;
+        float pr = (key < p.Lk) ? exp2f(x - lse2) : 0.f;
+        float dp = dpacc[r];
+        if (p.has_drop) {
+          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)key);
+          dp = (hsh >= p.drop_thr) ? dp * p.inv_keep : 0.f;
+        }
+        ds[r] = pr * (dp - dlt) * p.scale;
+      }
+      const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_pi(k_pi, 32 * db + l31, 0, g), f0, dqacc[db], 0, 0, 0);
+        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_pi(k_pi, 32 * db + l31, 1, g), f1, dqacc[db], 0, 0, 0);
+      }
+    }
+    if (ktn >= 0) l_store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+    kt = ktn;
+  }
+  if (q < p.Lq) store_token(p.dq + b * p.dqsb + q * p.dqst + h * p.dqsh, dqacc, 1.0f, g);
+}
+
+// ====================================================================================================
+// backward: dK, dV  (one wave = 32 keys, loop over query tiles)
+//   S = Q.K^T orientation: mfma(a = Q fragment (row = query), b = K fragment) -> lane owns one key,
+//   registers = 16 queries.  dV^T[d][key] += dO^T[d][q] . Pdrop[q][key],  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+//   LDS per buffer: Q row-major | Q pair-interleaved | dO row-major | dO pair-interleaved
+// ====================================================================================================
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
+  constexpr int BUF = 2 * RM_BYTES + 2 * PI_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kt0 = blockIdx.x * 4;
+  const int ktw = kt0 + wave;
+  const int64_t key = (int64_t)ktw * 32 + l31;
+  const float scale_log2 = p.scale * LOG2E;
+  const bf16_t* qb = p.q + b * p.qsb + h * p.qsh;
+  const bf16_t* kb = p.k + b * p.ksb + h * p.ksh;
+  const bf16_t* vb = p.v + b * p.vsb + h * p.vsh;
+  const bf16_t* dob = p.dout + b * p.dsb + h * p.dsh;
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 a = load_row16(kb, key, p.Lk, p.kst, 16 * s + 8 * g);
+    const uint4 c = load_row16(vb, key, p.Lk, p.vst, 16 * s + 8 * g);
+    kf[s] = *reinterpret_cast<const bf16x8*>(&a);
+    vf[s] = *reinterpret_cast<const bf16x8*>(&c);
+  }
+  f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
+  const int64_t bh_row0 = ((int64_t)b * p.H + h) * p.Lq;
+
+  auto col_flag = [&](int qt, int kt) -> int {
+    if (kt >= p.nkt) return 0;
+    if (p.tile_map) return p.tile_map[qt * p.nkt + kt];
+    return p.mask ? 2 : 1;
+  };
+  auto blk_need = [&](int qt) -> bool {
+    return (col_flag(qt, kt0) | col_flag(qt, kt0 + 1) | col_flag(qt, kt0 + 2) | col_flag(qt, kt0 + 3)) != 0;
+  };
+  auto next_needed = [&](int qt) -> int {
+    while (qt < p.nqt && !blk_need(qt)) ++qt;
+    return qt < p.nqt ? qt : -1;
+  };
+  const bool is_q_loader = t < 128;
+  const int u = is_q_loader ? t : t - 128;
+  uint4 reg[2];
+  auto g_load = [&](int qt) {
+    if (is_q_loader) stage_rows_load(reg, qb, p.qst, (int64_t)qt * 32, p.Lq, u);
+    else stage_rows_load(reg, dob, p.dst, (int64_t)qt * 32, p.Lq, u);
+  };
+  auto l_store = [&](int buf) {
+    char* base = smem + buf * BUF + (is_q_loader ? 0 : (RM_BYTES + PI_BYTES));
+    stage_store_rm(reg, base, u);
+    stage_store_pi(reg, base + RM_BYTES, u);
+  };
+
+  int qt = next_needed(0);
+  if (qt >= 0) { g_load(qt); l_store(0); }
+  __syncthreads();
+  int cur = 0;
+  while (qt >= 0) {
+    const int qtn = next_needed(qt + 1);
+    if (qtn >= 0) g_load(qtn);
+    const int flag = col_flag(qt, ktw);
+    if (flag != 0) {
+      const char* q_rm = smem + cur * BUF;
+      const char* q_pi = q_rm + RM_BYTES;
+      const char* do_rm = q_pi + PI_BYTES;
+      const char* do_pi = do_rm + RM_BYTES;
+      f32x16 sacc = zero16(), dpacc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(q_rm, l31, s, g), kf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(do_rm, l31, s, g), vf[s], dpacc, 0, 0, 0);
+      }
+      float pd[16], ds[16];
+      const int64_t q0 = (int64_t)qt * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t q = q0 + acc_row(r, g);
+        const bool valid = (q < p.Lq) && (key < p.Lk);
+        float pr = 0.f, dlt = 0.f;
+        if (valid) {
+          float x = sacc[r] * scale_log2;
+          if (flag == 2) x += p.mask[q * p.ldm + key] * LOG2E;
+          pr = exp2f(x - p.lse[bh_row0 + q] * LOG2E);
+          dlt = p.delta[bh_row0 + q];
+        }
+        float dp = dpacc[r];
+        float pdrop = pr;
+        if (p.has_drop) {
+          const uint32_t rk = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + q));
+          const bool keep = drop_hash_rk(rk, (uint32_t)key) >= p.drop_thr;
+          dp = keep ? dp * p.inv_keep : 0.f;
+          pdrop = keep ? pr * p.inv_keep : 0.f;
+        }
+        pd[r] = pdrop;
+        ds[r] = pr * (dp - dlt) * p.scale;
+      }
+      const bf16x8 pf0 = pack_frag(pd), pf1 = pack_frag(pd + 8);
+      const bf16x8 sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_pi(do_pi, 32 * db + l31, 0, g), pf0, dvacc[db], 0, 0, 0);
+        dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_pi(do_pi, 32 * db + l31, 1, g), pf1, dvacc[db], 0, 0, 0);
+        dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_pi(q_pi, 32 * db + l31, 0, g), sf0, dkacc[db], 0, 0, 0);
+        dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_pi(q_pi, 32 * db + l31, 1, g), sf1, dkacc[db], 0, 0, 0);
+      }
+    }
+    if (qtn >= 0) l_store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+    qt = qtn;
+  }
+  if (key < p.Lk) {
+    store_token(p.dk + b * p.dksb + key * p.dkst + h * p.dksh, dkacc, 1.0f, g);
+    store_token(p.dv + b * p.dvsb + key * p.dvst + h * p.dvsh, dvacc, 1.0f, g);
+  }
+}
+
+inline bool ok16(const void* ptr, int64_t s0, int64_t s1, int64_t s2) {
+  return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && (s0 % 8 == 0) && (s1 % 8 == 0) && (s2 % 8 == 0);
+}
+
+int fill_args(const dvla_attn_params* q, AttnKArgs& a) {
+  if (!q || !q->q || !q->k || !q->v || !q->o) return DVLA_ERR_ARG;
+  if (q->B <= 0 || q->H <= 0 || q->Lq <= 0 || q->Lk <= 0) return DVLA_ERR_ARG;
+  if (q->dropout_p < 0.f || q->dropout_p >= 1.f) return DVLA_ERR_ARG;
+  if (!ok16(q->q, q->q_stride_b, q->q_stride_t, q->q_stride_h) || !ok16(q->k, q->k_stride_b, q->k_stride_t, q->k_stride_h) ||
+      !ok16(q->v, q->v_stride_b, q->v_stride_t, q->v_stride_h) ||
+      !(reinterpret_cast<uintptr_t>(q->o) % 8 == 0 && q->o_stride_b % 4 == 0 && q->o_stride_t % 4 == 0 && q->o_stride_h % 4 == 0))
+    return DVLA_ERR_UNSUPPORTED;
+  a.q = (const bf16_t*)q->q; a.k = (const bf16_t*)q->k; a.v = (const bf16_t*)q->v; a.o = (bf16_t*)q->o;
+  a.qsb = q->q_stride_b; a.qst = q->q_stride_t; a.qsh = q->q_stride_h;
+  a.ksb = q->k_stride_b; a.kst = q->k_stride_t; a.ksh = q->k_stride_h;
+  a.vsb = q->v_stride_b; a.vst = q->v_stride_t; a.vsh = q->v_stride_h;
+  a.osb = q->o_stride_b; a.ost = q->o_stride_t; a.osh = q->o_stride_h;
+  a.B = q->B; a.H = q->H; a.Lq = q->Lq; a.Lk = q->Lk;
+  a.scale = q->scale;
+  a.mask = q->mask; a.ldm = q->ld_mask;
+  a.tile_map = q->mask ? q->tile_map : nullptr;
+  a.nqt = (q->Lq + 31) / 32; a.nkt = (q->Lk + 31) / 32;
+  a.has_drop = q->dropout_p > 0.f;
+  a.inv_keep = a.has_drop ? 1.0f / (1.0f - q->dropout_p) : 1.0f;
+  {
+    double thr = (double)q->dropout_p * 4294967296.0;
+    a.drop_thr = thr >= 4294967295.0 ? 4294967295u : (uint32_t)thr;
+  }
+  a.seed_lo = q->seed_lo; a.seed_hi = q->seed_hi;
+  a.lse = q->lse;
+  a.dout = (const bf16_t*)q->dout; a.dsb = q->do_stride_b; a.dst = q->do_stride_t; a.dsh = q->do_stride_h;
+  a.delta = q->delta;
+  a.dq = (bf16_t*)q->dq; a.dk = (bf16_t*)q->dk; a.dv = (bf16_t*)q->dv;
+  a.dqsb = q->dq_stride_b; a.dqst = q->dq_stride_t; a.dqsh = q->dq_stride_h;
+  a.dksb = q->dk_stride_b; a.dkst = q->dk_stride_t; a.dksh = q->dk_stride_h;
+  a.dvsb = q->dv_stride_b; a.dvst = q->dv_stride_t; a.dvsh = q->dv_stride_h;
+  return DVLA_OK;
+}
+
+}  // namespace
+
+extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  AttnKArgs a;
+  int rc = fill_args(q, a);
+  if (rc != DVLA_OK) return rc;
+  dim3 grid((unsigned)((a.nqt + 3) / 4), (unsigned)a.H, (unsigned)a.B), block(AT_THREADS);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, a);
+  return dvla_check_launch();
+}
+
+extern "C" int dvla_attn_bwd(const dvla_attn_params* q, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  AttnKArgs a;
+  int rc = fill_args(q, a);
+  if (rc != DVLA_OK) return rc;
+  if (!q->dout || !q->lse || !q->delta || !q->dq || !q->dk || !q->dv) return DVLA_ERR_ARG;
+  if (!ok16(q->dout, q->do_stride_b, q->do_stride_t, q->do_stride_h)) return DVLA_ERR_UNSUPPORTED;
+  auto ok8 = [](const void* ptr, int64_t s0, int64_t s1, int64_t s2) {
+    return (reinterpret_cast<uintptr_t>(ptr) % 8 == 0) && (s0 % 4 == 0) && (s1 % 4 == 0) && (s2 % 4 == 0);
+  };
+  if (!ok8(q->dq, q->dq_stride_b, q->dq_stride_t, q->dq_stride_h) || !ok8(q->dk, q->dk_stride_b, q->dk_stride_t, q->dk_stride_h) ||
+      !ok8(q->dv, q->dv_stride_b, q->dv_stride_t, q->dv_stride_h) || !ok16(q->o, q->o_stride_b, q->o_stride_t, q->o_stride_h))
+    return DVLA_ERR_UNSUPPORTED;
+  const int64_t nrows = (int64_t)a.B * a.H * a.Lq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows * 8 + 255) / 256)), dim3(256), 0, stream, a);
+  rc = dvla_check_launch();
+  if (rc != DVLA_OK) return rc;
+  dim3 block(AT_THREADS);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)((a.nqt + 3) / 4), (unsigned)a.H, (unsigned)a.B), block, 0, stream, a);
+  rc = dvla_check_launch();
+  if (rc != DVLA_OK) return rc;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((a.nkt + 3) / 4), (unsigned)a.H, (unsigned)a.B), block, 0, stream, a);
+  return dvla_check_launch();
+}

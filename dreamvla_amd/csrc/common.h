@@ -1,0 +1,131 @@
+// Shared device helpers for the DreamVLA CDNA4 (gfx950) kernels.
+// Everything here is wave64 / MFMA specific; there is no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DVLA_OK 0
+#define DVLA_ERR_ARG (-1)
+#define DVLA_ERR_LAUNCH (-2)
+#define DVLA_ERR_UNSUPPORTED (-3)
+
+enum DvlaAct { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_RELU = 3, ACT_SILU = 4, ACT_QUICK_GELU = 5,
+               ACT_TANH = 6, ACT_SIGMOID = 7 };
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even float -> bf16 (same rounding as torch's float->bfloat16 cast)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    case ACT_GELU_TANH: {
+      float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      return 0.5f * x * (1.0f + tanhf(u));
+    }
+    case ACT_RELU: return x > 0.f ? x : 0.f;
+    case ACT_SILU: return x / (1.0f + __expf(-x));
+    case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+    case ACT_TANH: return tanhf(x);
+    case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+    default: return x;
+  }
+}
+
+// d act(x) / dx evaluated at the pre-activation x
+__device__ __forceinline__ float act_bwd(float x, int act) {
+  switch (act) {
+    case ACT_GELU_ERF: {
+      float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case ACT_GELU_TANH: {
+      float x2 = x * x;
+      float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+      float t = tanhf(u);
+      float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
+      return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+    }
+    case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case ACT_SILU: {
+      float s = 1.0f / (1.0f + __expf(-x));
+      return s * (1.0f + x * (1.0f - s));
+    }
+    case ACT_QUICK_GELU: {
+      float s = 1.0f / (1.0f + __expf(-1.702f * x));
+      return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+    case ACT_TANH: { float t = tanhf(x); return 1.0f - t * t; }
+    case ACT_SIGMOID: { float s = 1.0f / (1.0f + __expf(-x)); return s * (1.0f - s); }
+    default: return 1.0f;
+  }
+}
+
+// ---- counter-based dropout RNG (stateless; forward and backward recompute the same mask) ----------
+// keep(element) <=> drop_hash(seed, idx_hi, idx_lo) >= thr,  thr = floor(p * 2^32)
+// elementwise tensors: idx_hi = row, idx_lo = col.  attention probs: idx_hi = (b*H+h)*Lq + q, idx_lo = key.
+// oracle/torch_ref.py::drop_keep_mask restates this bit for bit.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_rowkey(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx_hi) {
+  return hash32(idx_hi ^ seed_hi) + seed_lo;
+}
+__device__ __forceinline__ uint32_t drop_hash_rk(uint32_t rowkey, uint32_t idx_lo) {
+  return hash32(rowkey + idx_lo * 0x9E3779B9u);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// load 8 consecutive bf16 along the contiguous ("inner") dim of a 2-D operand, zero filled outside
+// [outer_lim) x [inner_lim).  vec_ok = (ld % 8 == 0 && base 16-B aligned && inner offset % 8 == 0).
+__device__ __forceinline__ uint4 load8_guard(const bf16_t* __restrict__ base, int64_t ld, int64_t outer,
+                                              int64_t inner, int64_t outer_lim, int64_t inner_lim, bool vec_ok) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (outer < outer_lim && inner < inner_lim) {
+    const bf16_t* p = base + outer * ld + inner;
+    if (vec_ok && inner + 8 <= inner_lim) {
+      v = *reinterpret_cast<const uint4*>(p);
+    } else {
+      uint32_t w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t lo = (inner + 2 * i < inner_lim) ? (uint32_t)p[2 * i] : 0u;
+        uint32_t hi = (inner + 2 * i + 1 < inner_lim) ? (uint32_t)p[2 * i + 1] : 0u;
+        w[i] = lo | (hi << 16);
+      }
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  return v;
+}
+
+static inline int dvla_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DVLA_OK : DVLA_ERR_LAUNCH;
+}

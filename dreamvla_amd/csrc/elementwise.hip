@@ -1,0 +1,183 @@
+// elementwise.hip -- small HBM-bound helpers (bias-gradient column sums, dropout, activation backward,
+// casts, broadcast add).  All bf16 traffic is 16-byte vectorised where alignment allows.
+#include "common.h"
+#include "../../include/dvla.h"
+
+namespace {
+
+constexpr int CS_BLOCKS = 512;  // persistent row-slabs for colsum
+
+// out_partial[slab][c] = sum over the slab's rows of x[r][c]; thread = one column pair-of-8? keep simple:
+// block = 256 threads covers 256*8 = 2048 columns per pass with 16-B loads when cols % 8 == 0.
+__global__ void colsum_partial_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows, int64_t cols,
+                                      float* __restrict__ partial, int vec_ok) {
+  const int64_t slab = blockIdx.y;
+  const int64_t nslab = gridDim.y;
+  const int64_t r_begin = rows * slab / nslab, r_end = rows * (slab + 1) / nslab;
+  const int64_t c0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (c0 >= cols) return;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (vec_ok && c0 + 8 <= cols) {
+    for (int64_t r = r_begin; r < r_end; ++r) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + r * ld + c0);
+      s[0] += bf2f((bf16_t)(u.x & 0xffff)); s[1] += bf2f((bf16_t)(u.x >> 16));
+      s[2] += bf2f((bf16_t)(u.y & 0xffff)); s[3] += bf2f((bf16_t)(u.y >> 16));
+      s[4] += bf2f((bf16_t)(u.z & 0xffff)); s[5] += bf2f((bf16_t)(u.z >> 16));
+      s[6] += bf2f((bf16_t)(u.w & 0xffff)); s[7] += bf2f((bf16_t)(u.w >> 16));
+    }
+  } else {
+    for (int64_t r = r_begin; r < r_end; ++r)
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e < cols) s[e] += bf2f(x[r * ld + c0 + e]);
+  }
+  for (int e = 0; e < 8; ++e)
+    if (c0 + e < cols) partial[slab * cols + c0 + e] = s[e];
+}
+
+__global__ void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab, int64_t cols) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += partial[(int64_t)k * cols + c];
+  out[c] = s;
+}
+
+__global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int64_t cols,
+                               uint32_t thr, float scale, uint32_t seed_lo, uint32_t seed_hi) {
+  const int64_t total = rows * cols;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < total; i += (int64_t)gridDim.x * blockDim.x * 2) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t idx = i + e;
+      if (idx < total) {
+        const int64_t r = idx / cols, c = idx % cols;
+        const uint32_t h = drop_hash_rk(drop_rowkey(seed_lo, seed_hi, (uint32_t)r), (uint32_t)c);
+        y[idx] = (h >= thr) ? f2bf(bf2f(x[idx]) * scale) : (bf16_t)0;
+      }
+    }
+  }
+}
+
+__global__ void act_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ pre, bf16_t* __restrict__ dz,
+                               int64_t rows, int64_t cols, int act, int has_drop, uint32_t thr, float scale,
+                               uint32_t seed_lo, uint32_t seed_hi) {
+  const int64_t total = rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    float g = bf2f(dy[idx]);
+    if (has_drop) {
+      const int64_t r = idx / cols, c = idx % cols;
+      const uint32_t h = drop_hash_rk(drop_rowkey(seed_lo, seed_hi, (uint32_t)r), (uint32_t)c);
+      g = (h >= thr) ? g * scale : 0.f;
+    }
+    if (pre) g *= act_bwd(bf2f(pre[idx]), act);
+    dz[idx] = f2bf(g);
+  }
+}
+
+__global__ void act_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = f2bf(act_fwd(bf2f(x[i]), act));
+}
+
+__global__ void cast_f2b_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = f2bf(s[i]);
+}
+__global__ void cast_b2f_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = bf2f(s[i]);
+}
+__global__ void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o, int64_t n,
+                           int64_t period) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = f2bf(bf2f(a[i]) + bf2f(b[period > 0 ? (i % period) : i]));
+}
+
+inline unsigned grid_for(int64_t n, int per_thread = 1) {
+  int64_t b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+inline uint32_t thr_of(float p) {
+  double thr = (double)p * 4294967296.0;
+  return thr >= 4294967295.0 ? 4294967295u : (uint32_t)thr;
+}
+
+}  // namespace
+
+extern "C" int dvla_abi_version(void) { return 1; }
+extern "C" int64_t dvla_colsum_partial_rows(void) { return CS_BLOCKS; }
+
+extern "C" int dvla_colsum(const void* x, int64_t ld, int64_t rows, int64_t cols, float* out, float* partial, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!x || !out || !partial || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
+  int64_t nslab = rows < CS_BLOCKS ? (rows > 0 ? rows : 1) : CS_BLOCKS;
+  // keep the grid reasonable for very wide matrices
+  const int64_t colblocks = (cols + 2047) / 2048;
+  while (nslab > 1 && nslab * colblocks > 2048) nslab /= 2;
+  const int vec_ok = (ld % 8 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)colblocks, (unsigned)nslab), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(x), ld, rows, cols, partial, vec_ok);
+  int rc = dvla_check_launch();
+  if (rc != DVLA_OK) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, partial, out,
+                     (int)nslab, cols);
+  return dvla_check_launch();
+}
+
+extern "C" int dvla_dropout(const void* x, void* y, int64_t rows, int64_t cols, float p, uint32_t seed_lo, uint32_t seed_hi,
+                            void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!x || !y || rows < 0 || cols <= 0 || p < 0.f || p >= 1.f) return DVLA_ERR_ARG;
+  if (rows == 0) return DVLA_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * cols, 2)), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), rows, cols, thr_of(p),
+                     1.0f / (1.0f - p), seed_lo, seed_hi);
+  return dvla_check_launch();
+}
+
+extern "C" int dvla_act_bwd(const void* dy, const void* preact, void* dz, int64_t rows, int64_t cols, int32_t act,
+                            float dropout_p, uint32_t seed_lo, uint32_t seed_hi, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!dy || !dz || rows < 0 || cols <= 0 || dropout_p < 0.f || dropout_p >= 1.f) return DVLA_ERR_ARG;
+  if (rows == 0) return DVLA_OK;
+  const int has_drop = dropout_p > 0.f;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(dy), reinterpret_cast<const bf16_t*>(preact),
+                     reinterpret_cast<bf16_t*>(dz), rows, cols, act, has_drop, thr_of(dropout_p),
+                     has_drop ? 1.0f / (1.0f - dropout_p) : 1.0f, seed_lo, seed_hi);
+  return dvla_check_launch();
+}
+
+extern "C" int dvla_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!x || !y || n < 0) return DVLA_ERR_ARG;
+  if (n == 0) return DVLA_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<const bf16_t*>(x),
+                     reinterpret_cast<bf16_t*>(y), n, act);
+  return dvla_check_launch();
+}
+
+extern "C" int dvla_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!src || !dst || n < 0) return DVLA_ERR_ARG;
+  if (n == 0) return DVLA_OK;
+  hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n)), dim3(256), 0, stream, src, reinterpret_cast<bf16_t*>(dst), n);
+  return dvla_check_launch();
+}
+extern "C" int dvla_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!src || !dst || n < 0) return DVLA_ERR_ARG;
+  if (n == 0) return DVLA_OK;
+  hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<const bf16_t*>(src), dst, n);
+  return dvla_check_launch();
+}
+extern "C" int dvla_add(const void* a, const void* b, void* out, int64_t n, int64_t b_period, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!a || !b || !out || n < 0) return DVLA_ERR_ARG;
+  if (n == 0) return DVLA_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<const bf16_t*>(a),
+                     reinterpret_cast<const bf16_t*>(b), reinterpret_cast<bf16_t*>(out), n, b_period);
+  return dvla_check_launch();
+}

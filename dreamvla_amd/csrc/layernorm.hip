@@ -1,0 +1,253 @@
+// layernorm.hip -- LayerNorm forward / backward for gfx950, HBM-bound.
+//
+// One wave (64 lanes) owns one row; a 256-thread block = 4 rows per pass, grid-strided.  A lane holds
+// its slice of the row in registers as 16-byte vectors (8 bf16): vector index = lane + 64*i, so a wave
+// reads/writes 1 KiB contiguous per instruction.  Statistics are two-pass in registers (mean, then
+// sum (x-mean)^2) in fp32 and reduced with wave shuffles; nothing goes through LDS in forward.
+// Algorithmic bytes: forward 2*rows*cols*2 B (+8 B/row of stats); backward 3*rows*cols*2 B.
+//
+// Backward: a lane's column set is the same for every row, so per-lane dgamma/dbeta partial sums stay
+// in registers across the block's rows, are combined across the 4 waves through LDS at the end, and
+// written to partial[block][2][cols]; a second tiny kernel reduces over blocks (deterministic).
+#include "common.h"
+#include "../../include/dvla.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_MAX_VPL = 4;          // vectors per lane -> cols <= 64*8*4 = 2048
+constexpr int LN_BWD_BLOCKS = 1024;    // persistent grid for backward (partial rows)
+
+__device__ __forceinline__ float param_at(const void* p, int f32, int64_t i) {
+  return f32 ? reinterpret_cast<const float*>(p)[i] : bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
+}
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = bf2f((bf16_t)(u.x & 0xffff)); f[1] = bf2f((bf16_t)(u.x >> 16));
+  f[2] = bf2f((bf16_t)(u.y & 0xffff)); f[3] = bf2f((bf16_t)(u.y >> 16));
+  f[4] = bf2f((bf16_t)(u.z & 0xffff)); f[5] = bf2f((bf16_t)(u.z >> 16));
+  f[6] = bf2f((bf16_t)(u.w & 0xffff)); f[7] = bf2f((bf16_t)(u.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+// cols % 8 == 0 required (vector path); VPL = ceil(cols / 512)
+template <int VPL>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16_t* __restrict__ x, const void* __restrict__ gamma,
+                                                            const void* __restrict__ beta, int pf32,
+                                                            bf16_t* __restrict__ y, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, int64_t rows, int cols,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = cols >> 3;
+  const float inv_n = 1.0f / (float)cols;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const uint4* xr = reinterpret_cast<const uint4*>(x + row * cols);
+    float v[VPL][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        unpack8(xr[vi], v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) * inv_n;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      if (lane + 64 * i < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+      }
+    }
+    const float var = wave_sum(ss) * inv_n;
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+    uint4* yr = reinterpret_cast<uint4*>(y + row * cols);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float h = (v[i][e] - mean) * rstd;
+          if (gamma) h *= param_at(gamma, pf32, vi * 8 + e);
+          if (beta) h += param_at(beta, pf32, vi * 8 + e);
+          o[e] = h;
+        }
+        yr[vi] = pack8(o);
+      }
+    }
+  }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const void* __restrict__ gamma, int pf32,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            bf16_t* __restrict__ dx, float* __restrict__ partial,
+                                                            int64_t rows, int cols) {
+  __shared__ float red[4][64 * 8];  // one vector-slot at a time: [wave][lane*8+e]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = cols >> 3;
+  const float inv_n = 1.0f / (float)cols;
+  float gam[VPL][8], dg[VPL][8], db[VPL][8];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gam[i][e] = (gamma && vi < nvec) ? param_at(gamma, pf32, vi * 8 + e) : 1.0f;
+      dg[i][e] = 0.f; db[i][e] = 0.f;
+    }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const uint4* xr = reinterpret_cast<const uint4*>(x + row * cols);
+    const uint4* gr = reinterpret_cast<const uint4*>(dy + row * cols);
+    const float mu = mean[row], rs = rstd[row];
+    float xh[VPL][8], gy[VPL][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        float xv[8], dv[8];
+        unpack8(xr[vi], xv);
+        unpack8(gr[vi], dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          gy[i][e] = dv[e] * gam[i][e];
+          s1 += gy[i][e];
+          s2 += gy[i][e] * xh[i][e];
+          dg[i][e] += dv[e] * xh[i][e];
+          db[i][e] += dv[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xh[i][e] = 0.f; gy[i][e] = 0.f; }
+      }
+    }
+    s1 = wave_sum(s1) * inv_n;
+    s2 = wave_sum(s2) * inv_n;
+    uint4* dr = reinterpret_cast<uint4*>(dx + row * cols);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
+        dr[vi] = pack8(o);
+      }
+    }
+  }
+  if (partial) {
+    // combine the 4 waves' register partials and write partial[block][0|1][cols]
+    float* pg = partial + (int64_t)blockIdx.x * 2 * cols;
+    float* pb = pg + cols;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = which ? db[i][e] : dg[i][e];
+        __syncthreads();
+        // 256 threads sum 512 slots x 4 waves
+        for (int sidx = threadIdx.x; sidx < 512; sidx += LN_THREADS) {
+          const float tot = red[0][sidx] + red[1][sidx] + red[2][sidx] + red[3][sidx];
+          const int col = (64 * i) * 8 + sidx;  // slot sidx = lane*8+e  -> column (lane + 64 i)*8 + e
+          if (col < cols) (which ? pb : pg)[col] = tot;
+        }
+      }
+    }
+  }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int nblocks, int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float sg = 0.f, sb = 0.f;
+  for (int b = 0; b < nblocks; ++b) {
+    sg += partial[(int64_t)b * 2 * cols + c];
+    sb += partial[(int64_t)b * 2 * cols + cols + c];
+  }
+  if (dgamma) dgamma[c] = sg;
+  if (dbeta) dbeta[c] = sb;
+}
+
+int fwd_blocks(int64_t rows) {
+  int64_t b = (rows + 3) / 4;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int64_t dvla_layernorm_bwd_partial_rows(void) { return LN_BWD_BLOCKS; }
+
+extern "C" int dvla_layernorm_fwd(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
+                                  float* mean, float* rstd, int64_t rows, int64_t cols, float eps, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!x || !y || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
+  if (rows == 0) return DVLA_OK;
+  if (cols % 8 != 0 || cols > 64 * 8 * LN_MAX_VPL) return DVLA_ERR_UNSUPPORTED;
+  const int vpl = (int)((cols / 8 + 63) / 64);
+  const int pf32 = (param_dtype == DVLA_DT_F32);
+  dim3 grid(fwd_blocks(rows)), block(LN_THREADS);
+  const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
+  bf16_t* yp = reinterpret_cast<bf16_t*>(y);
+  switch (vpl) {
+    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps); break;
+    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps); break;
+    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps); break;
+    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps); break;
+  }
+  return dvla_check_launch();
+}
+
+extern "C" int dvla_layernorm_bwd(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
+                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                  float* partial, int64_t rows, int64_t cols, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!dy || !x || !mean || !rstd || !dx || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
+  if ((dgamma || dbeta) && !partial) return DVLA_ERR_ARG;
+  if (rows == 0) return DVLA_OK;
+  if (cols % 8 != 0 || cols > 64 * 8 * LN_MAX_VPL) return DVLA_ERR_UNSUPPORTED;
+  const int vpl = (int)((cols / 8 + 63) / 64);
+  const int pf32 = (param_dtype == DVLA_DT_F32);
+  int64_t nb = (rows + 3) / 4;
+  if (nb > LN_BWD_BLOCKS) nb = LN_BWD_BLOCKS;
+  dim3 grid((unsigned)nb), block(LN_THREADS);
+  float* part = (dgamma || dbeta) ? partial : nullptr;
+  const bf16_t* dyp = reinterpret_cast<const bf16_t*>(dy);
+  const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
+  bf16_t* dxp = reinterpret_cast<bf16_t*>(dx);
+  switch (vpl) {
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols); break;
+    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols); break;
+  }
+  int rc = dvla_check_launch();
+  if (rc != DVLA_OK) return rc;
+  if (part) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, part, dgamma,
+                       dbeta, (int)nb, (int)cols);
+    rc = dvla_check_launch();
+  }
+  return rc;
+}

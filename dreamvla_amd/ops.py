@@ -1,0 +1,614 @@
+"""Host-side operators: torch.autograd.Function wrappers around the C-ABI HIP kernels.
+
+Every op here runs ONLY on the HIP extension (bf16 CUDA tensors); there is no eager fallback -- a CPU
+tensor, a wrong dtype or a missing library raises.  torch is used for device memory (torch.empty),
+streams and autograd bookkeeping.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT, AttnParams, DT_BF16, DT_F32, GemmParams, check
+
+BF16 = torch.bfloat16
+
+
+# ---------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t, name, dtype=BF16):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise _lib.DvlaError(f"{name}: tensor is on {t.device}; the DreamVLA HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype} (round-1 kernels compute in bf16: cast the module "
+                        f"with .bfloat16(), i.e. the reference's --precision bf16)")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dt(t):
+    return DT_F32 if t.dtype == torch.float32 else DT_BF16
+
+
+def _param_dt(t, name):
+    if t.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"{name}: expected bf16 or fp32 parameter, got {t.dtype}")
+    if not t.is_cuda:
+        raise _lib.DvlaError(f"{name}: parameter is on {t.device}; no CPU fallback")
+    return DT_F32 if t.dtype == torch.float32 else DT_BF16
+
+
+def _rows2d(x, cols):
+    """View x as (rows, cols) with unit inner stride (copies only if the layout forces it)."""
+    x2 = x.reshape(-1, cols)
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < cols):
+        x2 = x2.contiguous()
+    return x2
+
+
+class _Seeds:
+    """Counter-based dropout seeds: (lo, hi) = (per-call counter, hash of torch.initial_seed() and rank)."""
+    counter = 0
+    salt = 0
+
+    @classmethod
+    def next(cls):
+        cls.counter = (cls.counter + 1) & 0xFFFFFFFF
+        base = (torch.initial_seed() ^ (cls.salt * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+        hi = ((base >> 32) ^ (base & 0xFFFFFFFF) * 0x85EBCA6B) & 0xFFFFFFFF
+        return cls.counter, hi
+
+
+def set_seed_salt(salt):
+    _Seeds.salt = int(salt)
+
+
+def next_seed():
+    return _Seeds.next()
+
+
+# ---------------------------------------------------------------------------------------------------
+# raw kernel launchers (no autograd)
+# ---------------------------------------------------------------------------------------------------
+def auto_split_k(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 160 or K < 4096:
+        return 1
+    s = min(16, max(1, 384 // tiles), K // 1024)
+    return max(1, s)
+
+
+def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=False, dact_aux=None, dact=0,
+         dropout_p=0.0, seed=(0, 0), residual=None, out_dtype=BF16, out=None, accumulate=False, split_k=1):
+    """C[M,N] = epilogue(A . B^T); see include/dvla.h.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
+    Returns C (and the pre-activation tensor if want_preact)."""
+    lib = _lib.load()
+    _req(a, "gemm.a"); _req(b, "gemm.b")
+    if a.dim() != 2 or b.dim() != 2:
+        raise ValueError("gemm operands must be 2-D")
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    if a_trans:
+        K, M = a.shape
+    else:
+        M, K = a.shape
+    if b_trans:
+        Kb, N = b.shape
+    else:
+        N, Kb = b.shape
+    if K != Kb:
+        raise ValueError(f"gemm: contraction mismatch {K} vs {Kb}")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    else:
+        if out.shape != (M, N) or out.stride(1) != 1:
+            raise ValueError("gemm: bad `out`")
+    p = GemmParams()
+    p.A, p.lda, p.a_trans = a.data_ptr(), a.stride(0), int(a_trans)
+    p.B, p.ldb, p.b_trans = b.data_ptr(), b.stride(0), int(b_trans)
+    p.C, p.ldc, p.c_dtype = out.data_ptr(), out.stride(0), _dt(out)
+    p.M, p.N, p.K = M, N, K
+    if bias is not None:
+        p.bias, p.bias_dtype = bias.data_ptr(), _param_dt(bias, "gemm.bias")
+    p.act = int(act)
+    preact = None
+    if want_preact:
+        preact = torch.empty((M, N), dtype=BF16, device=a.device)
+        p.preact, p.ld_preact = preact.data_ptr(), preact.stride(0)
+    if dact_aux is not None:
+        _req(dact_aux, "gemm.dact_aux")
+        if dact_aux.stride(1) != 1:
+            dact_aux = dact_aux.contiguous()
+        p.dact_aux, p.ld_dact, p.dact = dact_aux.data_ptr(), dact_aux.stride(0), int(dact)
+    p.dropout_p = float(dropout_p)
+    p.seed_lo, p.seed_hi = int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF
+    if residual is not None:
+        _req(residual, "gemm.residual")
+        if residual.stride(1) != 1:
+            residual = residual.contiguous()
+        p.residual, p.ld_res = residual.data_ptr(), residual.stride(0)
+    p.accumulate = int(accumulate)
+    ws = None
+    if split_k > 1:
+        ws = torch.empty((split_k, M, N), dtype=torch.float32, device=a.device)
+        p.split_k, p.workspace = int(split_k), ws.data_ptr()
+    else:
+        p.split_k = 1
+    check(lib.dvla_gemm_bf16(C.byref(p), _stream()), "dvla_gemm_bf16")
+    return (out, preact) if want_preact else out
+
+
+def layernorm_fwd(x2, gamma, beta, eps, want_stats):
+    lib = _lib.load()
+    rows, cols = x2.shape
+    y = torch.empty_like(x2)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
+    if gamma is not None and beta is not None and beta.dtype != gamma.dtype:
+        raise TypeError("layernorm weight/bias dtype mismatch")
+    check(lib.dvla_layernorm_fwd(x2.data_ptr(), _ptr(gamma), _ptr(beta), pdt, y.data_ptr(), _ptr(mean), _ptr(rstd),
+                                 rows, cols, float(eps), _stream()), "dvla_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads):
+    lib = _lib.load()
+    rows, cols = x2.shape
+    dx = torch.empty_like(x2)
+    dg = db = part = None
+    if need_param_grads:
+        dg = torch.empty(cols, dtype=torch.float32, device=x2.device)
+        db = torch.empty(cols, dtype=torch.float32, device=x2.device)
+        part = torch.empty(2 * lib.dvla_layernorm_bwd_partial_rows() * cols, dtype=torch.float32, device=x2.device)
+    pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
+    check(lib.dvla_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), _ptr(gamma), pdt, mean.data_ptr(), rstd.data_ptr(),
+                                 dx.data_ptr(), _ptr(dg), _ptr(db), _ptr(part), rows, cols, _stream()),
+          "dvla_layernorm_bwd")
+    return dx, dg, db
+
+
+def colsum(x2):
+    lib = _lib.load()
+    rows, cols = x2.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x2.device)
+    part = torch.empty(lib.dvla_colsum_partial_rows() * cols, dtype=torch.float32, device=x2.device)
+    check(lib.dvla_colsum(x2.data_ptr(), x2.stride(0), rows, cols, out.data_ptr(), part.data_ptr(), _stream()),
+          "dvla_colsum")
+    return out
+
+
+def cast_to(x, dtype):
+    """fp32 <-> bf16 cast on the HIP path."""
+    lib = _lib.load()
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    if x.dtype == torch.float32 and dtype == BF16:
+        check(lib.dvla_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "dvla_cast")
+    elif x.dtype == BF16 and dtype == torch.float32:
+        check(lib.dvla_cast_bf16_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "dvla_cast")
+    else:
+        raise TypeError(f"cast {x.dtype} -> {dtype} unsupported")
+    return out
+
+
+def act_bwd_raw(dy2, preact2, act, dropout_p=0.0, seed=(0, 0)):
+    lib = _lib.load()
+    if dy2.stride(1) != 1 or dy2.stride(0) != dy2.shape[1]:
+        dy2 = dy2.contiguous()
+    if preact2 is not None and not preact2.is_contiguous():
+        preact2 = preact2.contiguous()
+    dz = torch.empty(dy2.shape, dtype=BF16, device=dy2.device)
+    check(lib.dvla_act_bwd(dy2.data_ptr(), _ptr(preact2), dz.data_ptr(), dy2.shape[0], dy2.shape[1], int(act),
+                           float(dropout_p), int(seed[0]), int(seed[1]), _stream()), "dvla_act_bwd")
+    return dz
+
+
+def dropout_raw(x2, p, seed):
+    lib = _lib.load()
+    x2 = x2.contiguous()
+    y = torch.empty_like(x2)
+    check(lib.dvla_dropout(x2.data_ptr(), y.data_ptr(), x2.shape[0], x2.shape[1], float(p), int(seed[0]), int(seed[1]),
+                           _stream()), "dvla_dropout")
+    return y
+
+
+def act_fwd_raw(x, act):
+    lib = _lib.load()
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib.dvla_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), int(act), _stream()), "dvla_act_fwd")
+    return y
+
+
+def add_raw(a, b, period=0):
+    lib = _lib.load()
+    a = a.contiguous(); b = b.contiguous()
+    out = torch.empty_like(a)
+    check(lib.dvla_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), int(period), _stream()), "dvla_add")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention launchers
+# ---------------------------------------------------------------------------------------------------
+def build_tile_map(mask):
+    """uint8 (ceil(Lq/32), ceil(Lk/32)) classification of an additive 0/-inf mask: 0 = all -inf (skip),
+    1 = all visible, 2 = mixed.  Host-side, once per mask (models/dreamvla_model.py:25-66 masks are static
+    outside the pretrain phase)."""
+    m = mask.detach().float().cpu()
+    Lq, Lk = m.shape
+    nq, nk = (Lq + 31) // 32, (Lk + 31) // 32
+    vis = torch.zeros(nq * 32, nk * 32, dtype=torch.bool)
+    valid = torch.zeros(nq * 32, nk * 32, dtype=torch.bool)
+    vis[:Lq, :Lk] = m == 0
+    valid[:Lq, :Lk] = True
+    other = torch.zeros(nq * 32, nk * 32, dtype=torch.bool)
+    other[:Lq, :Lk] = (m != 0) & ~torch.isinf(m)
+    v = vis.view(nq, 32, nk, 32).permute(0, 2, 1, 3).reshape(nq, nk, -1)
+    va = valid.view(nq, 32, nk, 32).permute(0, 2, 1, 3).reshape(nq, nk, -1)
+    ot = other.view(nq, 32, nk, 32).permute(0, 2, 1, 3).reshape(nq, nk, -1)
+    n_valid = va.sum(-1)
+    n_vis = (v & va).sum(-1)
+    tm = torch.full((nq, nk), 2, dtype=torch.uint8)
+    tm[(n_vis == n_valid) & ~ot.any(-1)] = 1
+    tm[(n_vis == 0) & ~ot.any(-1)] = 0
+    return tm.to(mask.device)
+
+
+def _attn_params(q, k, v, o, H, Lq, Lk, scale, mask, tile_map, dropout_p, seed, lse):
+    p = AttnParams()
+    B = q.shape[0]
+    p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        if t.stride(3) != 1 or t.shape[3] != 64:
+            raise ValueError("attention expects (B, L, H, 64) views with unit inner stride")
+        setattr(p, name + "_stride_b", t.stride(0))
+        setattr(p, name + "_stride_t", t.stride(1))
+        setattr(p, name + "_stride_h", t.stride(2))
+    p.B, p.H, p.Lq, p.Lk = B, H, Lq, Lk
+    p.scale = float(scale)
+    if mask is not None:
+        if mask.dtype != torch.float32 or mask.shape != (Lq, Lk) or mask.stride(1) != 1 or not mask.is_cuda:
+            raise ValueError("attention mask must be a CUDA fp32 (Lq, Lk) tensor")
+        p.mask, p.ld_mask = mask.data_ptr(), mask.stride(0)
+        if tile_map is not None:
+            if tile_map.dtype != torch.uint8 or not tile_map.is_contiguous() or \
+                    tile_map.shape != ((Lq + 31) // 32, (Lk + 31) // 32):
+                raise ValueError("bad tile_map")
+            p.tile_map = tile_map.data_ptr()
+    p.dropout_p = float(dropout_p)
+    p.seed_lo, p.seed_hi = int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF
+    p.lse = _ptr(lse)
+    return p
+
+
+def attn_fwd_raw(q, k, v, *, scale, mask=None, tile_map=None, dropout_p=0.0, seed=(0, 0), want_lse=True):
+    """q: (B, Lq, H, 64), k/v: (B, Lk, H, 64) strided bf16 views.  Returns o (B, Lq, H, 64) contiguous, lse."""
+    lib = _lib.load()
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _req(t, "attention." + n)
+    B, Lq, H, _ = q.shape
+    Lk = k.shape[1]
+    o = torch.empty((B, Lq, H, 64), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device) if want_lse else None
+    p = _attn_params(q, k, v, o, H, Lq, Lk, scale, mask, tile_map, dropout_p, seed, lse)
+    check(lib.dvla_attn_fwd(C.byref(p), _stream()), "dvla_attn_fwd")
+    return o, lse
+
+
+def attn_bwd_raw(q, k, v, o, lse, dout, dq, dk, dv, *, scale, mask=None, tile_map=None, dropout_p=0.0, seed=(0, 0)):
+    lib = _lib.load()
+    B, Lq, H, _ = q.shape
+    Lk = k.shape[1]
+    if dout.stride(3) != 1:
+        dout = dout.contiguous()
+    p = _attn_params(q, k, v, o, H, Lq, Lk, scale, mask, tile_map, dropout_p, seed, lse)
+    delta = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    p.dout = dout.data_ptr()
+    p.do_stride_b, p.do_stride_t, p.do_stride_h = dout.stride(0), dout.stride(1), dout.stride(2)
+    p.delta = delta.data_ptr()
+    p.dq, p.dk, p.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    for name, t in (("dq", dq), ("dk", dk), ("dv", dv)):
+        setattr(p, name + "_stride_b", t.stride(0))
+        setattr(p, name + "_stride_t", t.stride(1))
+        setattr(p, name + "_stride_h", t.stride(2))
+    check(lib.dvla_attn_bwd(C.byref(p), _stream()), "dvla_attn_bwd")
+
+
+# ---------------------------------------------------------------------------------------------------
+# autograd Functions
+# ---------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = residual + dropout(act(x . W^T + b)).  conv1d=True: W is HF Conv1D (in, out) (models/gpt2.py:53)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, act, conv1d, dropout_p):
+        _req(x, "linear.input"); _req(w, "linear.weight")
+        K = w.shape[0] if conv1d else w.shape[1]
+        N = w.shape[1] if conv1d else w.shape[0]
+        x2 = _rows2d(x, K)
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)
+                                                 or (residual is not None and residual.requires_grad))
+        seed = next_seed() if dropout_p > 0 else (0, 0)
+        res2 = _rows2d(residual, N) if residual is not None else None
+        want_pre = need_grad and act != 0
+        r = gemm(x2, w, b_trans=conv1d, bias=b, act=act, want_preact=want_pre, dropout_p=dropout_p, seed=seed,
+                 residual=res2)
+        y2, pre = r if want_pre else (r, None)
+        ctx.act, ctx.conv1d, ctx.dropout_p, ctx.seed = act, conv1d, dropout_p, seed
+        ctx.has_bias, ctx.has_res = b is not None, residual is not None
+        ctx.x_shape = x.shape
+        ctx.bias_dtype = b.dtype if b is not None else None
+        if need_grad:
+            ctx.save_for_backward(x2, w, pre)
+        return y2.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, pre = ctx.saved_tensors
+        conv1d = ctx.conv1d
+        N = w.shape[1] if conv1d else w.shape[0]
+        K = w.shape[0] if conv1d else w.shape[1]
+        dy2 = _rows2d(_req(dy, "linear.grad_output"), N)
+        if ctx.act != 0 or ctx.dropout_p > 0:
+            dz = act_bwd_raw(dy2, pre, ctx.act, ctx.dropout_p, ctx.seed)
+        else:
+            dz = dy2
+        M = dz.shape[0]
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            # dx[m,k] = sum_n dz[m,n] W(n,k)
+            dx = gemm(dz, w, b_trans=not conv1d).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            if conv1d:   # dW[k,n] = sum_m x[m,k] dz[m,n]
+                dw = gemm(x2, dz, a_trans=True, b_trans=True, split_k=auto_split_k(K, N, M))
+            else:        # dW[n,k] = sum_m dz[m,n] x[m,k]
+                dw = gemm(dz, x2, a_trans=True, b_trans=True, split_k=auto_split_k(N, K, M))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = cast_to(colsum(dz), ctx.bias_dtype)
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None, None, None
+
+
+def linear(x, w, b=None, *, act="none", conv1d=False, residual=None, dropout_p=0.0):
+    return _Linear.apply(x, w, b, residual, ACT[act] if isinstance(act, str) else int(act), bool(conv1d),
+                         float(dropout_p))
+
+
+class _Mlp(torch.autograd.Function):
+    """y = residual + dropout(act(x W1^T + b1) W2^T + b2): fc1 epilogue stores the pre-activation, the
+    backward dH GEMM applies act'(u) in its epilogue (no separate elementwise pass)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, act, conv1d, dropout_p):
+        _req(x, "mlp.input"); _req(w1, "mlp.fc1.weight"); _req(w2, "mlp.fc2.weight")
+        K = w1.shape[0] if conv1d else w1.shape[1]
+        N = w2.shape[1] if conv1d else w2.shape[0]
+        x2 = _rows2d(x, K)
+        need_grad = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (x, w1, b1, w2, b2, residual))
+        seed = next_seed() if dropout_p > 0 else (0, 0)
+        res2 = _rows2d(residual, N) if residual is not None else None
+        if need_grad:
+            h, u = gemm(x2, w1, b_trans=conv1d, bias=b1, act=act, want_preact=True)
+        else:
+            h, u = gemm(x2, w1, b_trans=conv1d, bias=b1, act=act), None
+        y2 = gemm(h, w2, b_trans=conv1d, bias=b2, dropout_p=dropout_p, seed=seed, residual=res2)
+        ctx.act, ctx.conv1d, ctx.dropout_p, ctx.seed = act, conv1d, dropout_p, seed
+        ctx.x_shape = x.shape
+        ctx.has_b1, ctx.has_b2, ctx.has_res = b1 is not None, b2 is not None, residual is not None
+        ctx.b1_dtype = b1.dtype if b1 is not None else None
+        ctx.b2_dtype = b2.dtype if b2 is not None else None
+        if need_grad:
+            ctx.save_for_backward(x2, w1, w2, u, h)
+        return y2.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, u, h = ctx.saved_tensors
+        conv1d = ctx.conv1d
+        N = w2.shape[1] if conv1d else w2.shape[0]
+        Hd = w1.shape[1] if conv1d else w1.shape[0]
+        K = w1.shape[0] if conv1d else w1.shape[1]
+        dy2 = _rows2d(_req(dy, "mlp.grad_output"), N)
+        dz = act_bwd_raw(dy2, None, 0, ctx.dropout_p, ctx.seed) if ctx.dropout_p > 0 else dy2
+        M = dz.shape[0]
+        # du = (dz . W2) * act'(u)
+        du = gemm(dz, w2, b_trans=not conv1d, dact_aux=u, dact=ctx.act)
+        dx = dw1 = db1 = dw2 = db2 = dres = None
+        if ctx.needs_input_grad[3]:
+            dw2 = (gemm(h, dz, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, N, M)) if conv1d else
+                   gemm(dz, h, a_trans=True, b_trans=True, split_k=auto_split_k(N, Hd, M)))
+        if ctx.has_b2 and ctx.needs_input_grad[4]:
+            db2 = cast_to(colsum(dz), ctx.b2_dtype)
+        if ctx.needs_input_grad[0]:
+            dx = gemm(du, w1, b_trans=not conv1d).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dw1 = (gemm(x2, du, a_trans=True, b_trans=True, split_k=auto_split_k(K, Hd, M)) if conv1d else
+                   gemm(du, x2, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, K, M)))
+        if ctx.has_b1 and ctx.needs_input_grad[2]:
+            db1 = cast_to(colsum(du), ctx.b1_dtype)
+        if ctx.has_res and ctx.needs_input_grad[5]:
+            dres = dy
+        return dx, dw1, db1, dw2, db2, dres, None, None, None
+
+
+def mlp(x, w1, b1, w2, b2, *, act, conv1d=False, residual=None, dropout_p=0.0):
+    return _Mlp.apply(x, w1, b1, w2, b2, residual, ACT[act] if isinstance(act, str) else int(act), bool(conv1d),
+                      float(dropout_p))
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _req(x, "layernorm.input")
+        cols = x.shape[-1]
+        x2 = x.reshape(-1, cols)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or (gamma is not None and gamma.requires_grad))
+        y, mean, rstd = layernorm_fwd(x2, gamma, beta, eps, need_grad)
+        ctx.has_affine = gamma is not None
+        ctx.has_beta = beta is not None
+        ctx.x_shape = x.shape
+        if need_grad:
+            ctx.save_for_backward(x2, gamma, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        dy2 = _req(dy, "layernorm.grad_output").reshape(x2.shape)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        need_p = ctx.has_affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p)
+        dgam = dbet = None
+        if need_p:
+            dgam = cast_to(dg, gamma.dtype)
+            if ctx.has_beta:
+                dbet = cast_to(db, gamma.dtype)
+        return dx.view(ctx.x_shape), dgam, dbet, None
+
+
+def layer_norm(x, weight, bias, eps):
+    return _LayerNorm.apply(x, weight, bias, float(eps))
+
+
+class _SelfAttention(torch.autograd.Function):
+    """Packed self-attention: qkv (B, L, 3*H*64) laid out [q | k | v] x (H, 64) -- exactly timm's
+    qkv.reshape(B,N,3,h,d) and GPT-2's c_attn(...).split(H) order.  Returns (B, L, H*64)."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, scale, mask, tile_map, dropout_p):
+        _req(qkv, "attention.qkv")
+        B, L, W = qkv.shape
+        if W != 3 * H * 64:
+            raise ValueError("attention: head_dim must be 64")
+        if not qkv.is_contiguous():
+            qkv = qkv.contiguous()
+        v5 = qkv.view(B, L, 3, H, 64)
+        q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
+        need_grad = torch.is_grad_enabled() and qkv.requires_grad
+        seed = next_seed() if dropout_p > 0 else (0, 0)
+        o, lse = attn_fwd_raw(q, k, v, scale=scale, mask=mask, tile_map=tile_map, dropout_p=dropout_p, seed=seed,
+                              want_lse=need_grad)
+        ctx.H, ctx.scale, ctx.dropout_p, ctx.seed = H, scale, dropout_p, seed
+        if need_grad:
+            ctx.save_for_backward(qkv, o, lse, mask, tile_map)
+        return o.view(B, L, H * 64)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, o, lse, mask, tile_map = ctx.saved_tensors
+        B, L, _ = qkv.shape
+        H = ctx.H
+        v5 = qkv.view(B, L, 3, H, 64)
+        dqkv = torch.empty_like(qkv)
+        d5 = dqkv.view(B, L, 3, H, 64)
+        do = _req(dout, "attention.grad_output").contiguous().view(B, L, H, 64)
+        attn_bwd_raw(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], o, lse, do, d5[:, :, 0], d5[:, :, 1], d5[:, :, 2],
+                     scale=ctx.scale, mask=mask, tile_map=tile_map, dropout_p=ctx.dropout_p, seed=ctx.seed)
+        return dqkv, None, None, None, None, None
+
+
+def self_attention(qkv, num_heads, *, scale=None, mask=None, tile_map=None, dropout_p=0.0):
+    scale = (1.0 / math.sqrt(64.0)) if scale is None else scale
+    return _SelfAttention.apply(qkv, int(num_heads), float(scale), mask, tile_map, float(dropout_p))
+
+
+class _CrossAttention(torch.autograd.Function):
+    """q (B, Lq, H*64); kv (B, Lk, 2*H*64) laid out [k | v] x (H, 64) (perceiver to_kv(...).chunk(2),
+    models/perceiver_resampler.py:50-52).  Returns (B, Lq, H*64)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, H, scale):
+        _req(q, "attention.q"); _req(kv, "attention.kv")
+        B, Lq, _ = q.shape
+        Lk = kv.shape[1]
+        q = q.contiguous(); kv = kv.contiguous()
+        q4 = q.view(B, Lq, H, 64)
+        kv5 = kv.view(B, Lk, 2, H, 64)
+        need_grad = torch.is_grad_enabled() and (q.requires_grad or kv.requires_grad)
+        o, lse = attn_fwd_raw(q4, kv5[:, :, 0], kv5[:, :, 1], scale=scale, want_lse=need_grad)
+        ctx.H, ctx.scale = H, scale
+        if need_grad:
+            ctx.save_for_backward(q, kv, o, lse)
+        return o.view(B, Lq, H * 64)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, o, lse = ctx.saved_tensors
+        H = ctx.H
+        B, Lq, _ = q.shape
+        Lk = kv.shape[1]
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        kv5, dkv5 = kv.view(B, Lk, 2, H, 64), dkv.view(B, Lk, 2, H, 64)
+        do = _req(dout, "attention.grad_output").contiguous().view(B, Lq, H, 64)
+        attn_bwd_raw(q.view(B, Lq, H, 64), kv5[:, :, 0], kv5[:, :, 1], o, lse, do, dq.view(B, Lq, H, 64),
+                     dkv5[:, :, 0], dkv5[:, :, 1], scale=ctx.scale)
+        return dq, dkv, None, None
+
+
+def cross_attention(q, kv, num_heads, *, scale=None):
+    scale = (1.0 / math.sqrt(64.0)) if scale is None else scale
+    return _CrossAttention.apply(q, kv, int(num_heads), float(scale))
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        _req(x, "dropout.input")
+        seed = next_seed()
+        ctx.p, ctx.seed, ctx.shape = p, seed, x.shape
+        return dropout_raw(x.reshape(-1, x.shape[-1]), p, seed).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dropout_raw(dy.reshape(-1, ctx.shape[-1]), ctx.p, ctx.seed).view(ctx.shape), None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, float(p))
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        _req(x, "act.input")
+        ctx.act = act
+        if torch.is_grad_enabled() and x.requires_grad:
+            ctx.save_for_backward(x)
+        return act_fwd_raw(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        cols = x.shape[-1]
+        return act_bwd_raw(dy.reshape(-1, cols), x.reshape(-1, cols).contiguous(), ctx.act).view(x.shape), None
+
+
+def activation(x, act):
+    return _Act.apply(x, ACT[act] if isinstance(act, str) else int(act))

@@ -1,0 +1,146 @@
+/* dvla.h -- C ABI of libdvla_hip.so: the hand-written CDNA4 (gfx950) kernels under DreamVLA's
+ * transformer hot path.
+ *
+ * The reference (Zhangwenyao1/DreamVLA) has no native code and no FFI: every "kernel" on this path is
+ * an ATen / F.scaled_dot_product_attention call issued from eager Python.  Each
+ * entry point below therefore cites the reference *call sites* whose ATen op(s) it replaces; the
+ * Python-side binding (ctypes) is dreamvla_amd/_lib.py and the drop-in nn.Module surface is
+ * models/dreamvla_model.py.
+ *
+ * Conventions: plain pointers + sizes, no torch types.  All tensors are device pointers.  bf16 is the
+ * raw 16-bit pattern.  Every function enqueues work on `stream` (a hipStream_t passed as void*),
+ * never allocates, never synchronises, is re-entrant per stream, and returns 0 on success or a negative
+ * DVLA_ERR_* code (no exceptions cross the ABI).  dtype codes: 0 = bf16, 1 = fp32.
+ */
+#ifndef DVLA_H_
+#define DVLA_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVLA_DT_BF16 0
+#define DVLA_DT_F32 1
+
+/* activation codes (applied in fp32 on the accumulator) */
+#define DVLA_ACT_NONE 0
+#define DVLA_ACT_GELU_ERF 1   /* timm Mlp nn.GELU():            models/vit_mae.py:73, dreamvla_model.py:349 */
+#define DVLA_ACT_GELU_TANH 2  /* HF ACT2FN["gelu_new"]:         models/gpt2.py:292-301; DiT approx_gelu models.py:133 */
+#define DVLA_ACT_RELU 3       /* action MLP head / depth pred:  dreamvla_model.py:458-471,842 */
+#define DVLA_ACT_SILU 4       /* DiT TimestepEmbedder:          action_model/models.py:34 */
+#define DVLA_ACT_QUICK_GELU 5 /* CLIP text tower QuickGELU (openai/CLIP model.py) */
+#define DVLA_ACT_TANH 6
+#define DVLA_ACT_SIGMOID 7
+
+int dvla_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue( A[M,K] * B[N,K]^T )     bf16 operands, fp32 MFMA accumulate
+ *   a_trans = 0: A(m,k) at A[m*lda + k]      a_trans = 1: A(m,k) at A[k*lda + m]
+ *   b_trans = 0: B(n,k) at B[n*ldb + k]  (nn.Linear weight (out,in))
+ *   b_trans = 1: B(n,k) at B[k*ldb + n]  (HF Conv1D weight (in,out), models/gpt2.py:53-54,291-292)
+ * epilogue, in order: v = acc; v += bias[n]; preact[m,n] = v; v = act(v); v *= act'(dact_aux[m,n]) (dact);
+ *   v = dropout(v) (p, seed; element (m,n)); v += residual[m,n]; C = v (or C += v when accumulate, fp32 C).
+ * Replaces: nn.Linear / Conv1D / timm PatchEmbed-as-GEMM + bias + GELU + dropout + residual add at
+ *   models/vit_mae.py:188-203 (via timm Block), models/gpt2.py:160,172-173,296-301,329-339,
+ *   models/perceiver_resampler.py:11-18,49-51,61, models/dreamvla_model.py:652-664,718-724,800-809,
+ *   models/action_model/models.py:34-41,128-141,158-160, and their autograd backward GEMMs.
+ * split_k > 1: K is cut in split_k slices written to `workspace` (split_k*M*N fp32) and reduced by a
+ *   second kernel; only valid with the plain epilogue (used for weight gradients).
+ */
+typedef struct dvla_gemm_params {
+  const void* A; int64_t lda; int32_t a_trans;
+  const void* B; int64_t ldb; int32_t b_trans;
+  void* C; int64_t ldc; int32_t c_dtype;
+  int64_t M, N, K;
+  const void* bias; int32_t bias_dtype;
+  int32_t act;
+  void* preact; int64_t ld_preact;
+  const void* dact_aux; int64_t ld_dact; int32_t dact;
+  float dropout_p; uint32_t seed_lo; uint32_t seed_hi;
+  const void* residual; int64_t ld_res;
+  int32_t accumulate;
+  int32_t split_k; void* workspace;
+} dvla_gemm_params;
+int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (rows x cols, bf16 in/out, fp32 statistics).
+ * gamma/beta may be NULL (DiT elementwise_affine=False, action_model/models.py:129-131,148).
+ * Replaces nn.LayerNorm at models/vit_mae.py:77,202-204 (eps 1e-6), models/gpt2.py:312-315,437
+ * (eps 1e-5), models/dreamvla_model.py:279,352,374,393,412,433, models/perceiver_resampler.py:14,28-29,101.
+ * fwd writes mean/rstd (fp32, one per row) when they are non-NULL (needed by bwd).
+ * bwd: dx always; dgamma/dbeta (fp32, cols) when non-NULL, using `partial` = fp32 workspace of
+ *      2 * dvla_layernorm_bwd_partial_rows() * cols floats.
+ */
+int dvla_layernorm_fwd(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
+                       float* mean, float* rstd, int64_t rows, int64_t cols, float eps, void* stream);
+int dvla_layernorm_bwd(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
+                       const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                       float* partial, int64_t rows, int64_t cols, void* stream);
+int64_t dvla_layernorm_bwd_partial_rows(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused multi-head attention, head_dim = 64 (every attention in DreamVLA: ViT 768/12, trunk 1024/16,
+ * dream-head decoders 1024/16, DiT 768/12, perceiver dim_head 64, CLIP text 512/8).
+ *   O[b,i,h,:] = sum_j softmax_j( scale * q[b,i,h,:].k[b,j,h,:] + mask[i,j] ) * drop(.) * v[b,j,h,:]
+ * q/k/v/o element (b, token, head, d) lives at ptr[b*stride_b + token*stride_t + head*stride_h + d], so
+ * the fused (B,N,3,h,d) timm qkv buffer, the GPT-2 c_attn (B,L,3H) buffer and the perceiver q / kv
+ * buffers are read in place (no head-split copies).  mask: optional fp32 additive (Lq x Lk, row stride
+ * ld_mask), values 0 / -inf as built by generate_attention_mask (models/dreamvla_model.py:25-66); the
+ * optional tile map (ceil(Lq/32) x ceil(Lk/32) bytes: 0 = fully masked -> skipped, 1 = fully visible,
+ * 2 = mixed) lets the kernel skip the 64-81 % of trunk tiles that are -inf.
+ * lse (B*H*Lq fp32, natural-log-sum-exp of the scaled+masked scores) is written when non-NULL.
+ * Replaces: F.scaled_dot_product_attention in timm Attention (vit_mae.py:202-203, dreamvla_model.py:806-904,
+ * action_model/models.py:137), GPT2Attention._attn / GPT2SdpaAttention (models/gpt2.py:61-84,267-274),
+ * PerceiverAttention einsum-softmax-einsum (models/perceiver_resampler.py:55-60).
+ */
+typedef struct dvla_attn_params {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t q_stride_b, q_stride_t, q_stride_h;
+  int64_t k_stride_b, k_stride_t, k_stride_h;
+  int64_t v_stride_b, v_stride_t, v_stride_h;
+  int64_t o_stride_b, o_stride_t, o_stride_h;
+  int32_t B, H, Lq, Lk;
+  float scale;
+  const float* mask; int64_t ld_mask;
+  const uint8_t* tile_map;
+  float dropout_p; uint32_t seed_lo; uint32_t seed_hi;
+  float* lse;
+  /* backward only */
+  const void* dout; int64_t do_stride_b, do_stride_t, do_stride_h;
+  float* delta; /* workspace B*H*Lq fp32: rowsum(dO * O) */
+  void* dq; void* dk; void* dv;
+  int64_t dq_stride_b, dq_stride_t, dq_stride_h;
+  int64_t dk_stride_b, dk_stride_t, dk_stride_h;
+  int64_t dv_stride_b, dv_stride_t, dv_stride_h;
+} dvla_attn_params;
+int dvla_attn_fwd(const dvla_attn_params* p, void* stream);
+int dvla_attn_bwd(const dvla_attn_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Small HBM-bound helpers (bf16 unless noted).
+ */
+/* out[n] = sum_m x[m,n]  (bias gradients).  out fp32; `partial` = fp32 workspace of
+ * dvla_colsum_partial_rows() * cols floats. */
+int dvla_colsum(const void* x, int64_t ld, int64_t rows, int64_t cols, float* out, float* partial, void* stream);
+int64_t dvla_colsum_partial_rows(void);
+/* y = dropout(x) * 1/(1-p) with the stateless hash RNG; rows x cols, row stride = cols.
+ * GPT2Model.drop (models/gpt2.py:459) and its backward (same call on the gradient). */
+int dvla_dropout(const void* x, void* y, int64_t rows, int64_t cols, float p, uint32_t seed_lo, uint32_t seed_hi,
+                 void* stream);
+/* dz = dy * act'(preact) (optionally after dropout mask of dy): backward of a fused activation. */
+int dvla_act_bwd(const void* dy, const void* preact, void* dz, int64_t rows, int64_t cols, int32_t act,
+                 float dropout_p, uint32_t seed_lo, uint32_t seed_hi, void* stream);
+/* y = act(x) */
+int dvla_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream);
+/* dst(bf16) = src(fp32) / dst(fp32) = src(bf16) */
+int dvla_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int dvla_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* out = a + b (bf16, n elements); b_period > 0 broadcasts b with period b_period elements */
+int dvla_add(const void* a, const void* b, void* out, int64_t n, int64_t b_period, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVLA_H_ */

@@ -1,0 +1,127 @@
+"""ORACLE -- test infrastructure, NOT product code.
+
+Plain-PyTorch fp32 CPU restatement of the DreamVLA hot path's operators, used only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker for the HIP path.  Each function
+cites the reference lines it follows.  Pinning: tests/test_oracle_vs_reference.py checks these functions
+and oracle/model_ref.py against the REAL reference modules imported from /root/reference (build
+container only) and against the golden fixtures under tests/golden/ (everywhere).
+
+Nothing under dreamvla_amd/ or models/ imports this module.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------------------------------
+# activations
+# ---------------------------------------------------------------------------------------------------
+
+
+def act(x, name):
+    if name in ("none", None):
+        return x
+    if name in ("gelu", "gelu_erf"):      # timm Mlp act_layer=nn.GELU (erf)  -- models/vit_mae.py:73 via timm Block
+        return F.gelu(x)
+    if name in ("gelu_tanh", "gelu_new"):  # HF ACT2FN["gelu_new"] -- models/gpt2.py:294; DiT approx_gelu models.py:133
+        return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+    if name == "relu":
+        return F.relu(x)
+    if name == "silu":
+        return F.silu(x)
+    if name == "quick_gelu":              # openai/CLIP model.py QuickGELU
+        return x * torch.sigmoid(1.702 * x)
+    if name == "tanh":
+        return torch.tanh(x)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    raise ValueError(name)
+
+
+# ---------------------------------------------------------------------------------------------------
+# stateless dropout RNG -- bit-for-bit restatement of dreamvla_amd/csrc/common.h (hash32 / drop_rowkey /
+# drop_hash_rk).  The reference uses ATen's Philox stream (models/gpt2.py:56-57,435), which cannot be
+# reproduced; parity with the reference is checked at p = 0 and the dropout path is checked against THIS
+# restatement of our own generator.
+# ---------------------------------------------------------------------------------------------------
+_M32 = 0xFFFFFFFF
+
+
+def _hash32(x):
+    x = x & _M32
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & _M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def drop_keep_mask(seed, idx_hi, idx_lo, p):
+    """keep <=> hash >= floor(p * 2^32).  idx_hi / idx_lo: int64 tensors (broadcastable)."""
+    seed_lo, seed_hi = int(seed[0]) & _M32, int(seed[1]) & _M32
+    rowkey = (_hash32((idx_hi & _M32) ^ seed_hi) + seed_lo) & _M32
+    h = _hash32((rowkey + ((idx_lo & _M32) * 0x9E3779B9 & _M32)) & _M32)
+    thr = min(int(p * 4294967296.0), 4294967295)
+    return h >= thr
+
+
+def dropout_elementwise(x2, p, seed):
+    """(rows, cols) tensor: idx_hi = row, idx_lo = col."""
+    rows, cols = x2.shape
+    keep = drop_keep_mask(seed, torch.arange(rows, dtype=torch.int64)[:, None], torch.arange(cols, dtype=torch.int64)[None, :], p)
+    return torch.where(keep, x2 / (1.0 - p), torch.zeros_like(x2))
+
+
+# ---------------------------------------------------------------------------------------------------
+# operators
+# ---------------------------------------------------------------------------------------------------
+def layer_norm(x, weight, bias, eps):
+    """nn.LayerNorm over the last dim (vit_mae.py:77 eps 1e-6; gpt2.py:312-315 eps 1e-5; DiT no affine)."""
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
+def linear(x, w, b=None, conv1d=False):
+    """nn.Linear (w: (out,in)) or HF Conv1D (w: (in,out); transformers pytorch_utils.Conv1D, gpt2.py:53)."""
+    y = x @ (w if conv1d else w.t())
+    return y if b is None else y + b
+
+
+def attention(q, k, v, scale=None, mask=None, drop=None):
+    """softmax(q k^T * scale + mask) v over (B, H, L, d) tensors.
+    timm Attention -> F.scaled_dot_product_attention (vit_mae.py:202-203 via Block);
+    GPT2Attention._attn (gpt2.py:61-84): scores / sqrt(d) + additive mask, softmax, dropout, @ v;
+    PerceiverAttention (perceiver_resampler.py:53-60).  drop = (p, seed) applies our hash mask to the probabilities
+    with idx_hi = (b*H + h)*Lq + i, idx_lo = j."""
+    B, H, Lq, d = q.shape
+    Lk = k.shape[2]
+    scale = d ** -0.5 if scale is None else scale
+    s = torch.matmul(q, k.transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s + mask
+    p = torch.softmax(s, dim=-1)
+    if drop is not None and drop[0] > 0:
+        pd, seed = drop
+        rows = torch.arange(B * H * Lq, dtype=torch.int64).view(B, H, Lq, 1)
+        cols = torch.arange(Lk, dtype=torch.int64).view(1, 1, 1, Lk)
+        keep = drop_keep_mask(seed, rows, cols, pd)
+        p = torch.where(keep, p / (1.0 - pd), torch.zeros_like(p))
+    return torch.matmul(p, v)
+
+
+def split_qkv(qkv, H):
+    """(B, L, 3*H*d) -> q, k, v as (B, H, L, d): timm `reshape(B,N,3,h,d).permute(2,0,3,1,4)`; GPT-2
+    `split(H, dim=2)` + `_split_heads` (gpt2.py:136-142,160-164)."""
+    B, L, W = qkv.shape
+    d = W // (3 * H)
+    t = qkv.view(B, L, 3, H, d).permute(2, 0, 3, 1, 4)
+    return t[0], t[1], t[2]
+
+
+def merge_heads(o):
+    B, H, L, d = o.shape
+    return o.permute(0, 2, 1, 3).reshape(B, L, H * d)
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)

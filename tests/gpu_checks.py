@@ -1,0 +1,342 @@
+"""Kernel-level parity checks: HIP path (through the C ABI) vs oracle/torch_ref.py on identical seeded inputs.
+
+Each check returns a dict of error metrics and a `ok` flag; tests/test_kernels_gpu.py asserts on them and
+tests/gpu_diag.py dumps all of them into gpurun_out/ in one go (no stop at first failure).
+
+Tolerances (written here, used everywhere):
+  * bf16 outputs are compared with the fp32 oracle result rounded to bf16:   rel-L2 <= 1e-3
+  * fp32 outputs (GEMM with fp32 C, LayerNorm statistics, LSE):              rel-L2 <= 1e-5 / abs 1e-4
+  * gradients (bf16, pass through bf16-rounded P / dS fragments):            rel-L2 <= 4e-3
+rel-L2 = ||a - b||_2 / max(||b||_2, tiny).
+"""
+import math
+
+import torch
+
+from oracle import torch_ref as R
+
+TOL_FWD = 1e-3
+TOL_F32 = 1e-5
+TOL_GRAD = 4e-3
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rel_l2(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    if not torch.isfinite(a).all():
+        return float("inf")
+    return float((a - b).norm() / max(float(b.norm()), 1e-12))
+
+
+def metrics(name, got, ref, tol, round_ref=True):
+    ref_c = R.bf16_round(ref) if round_ref else ref
+    g = got.detach().float().cpu()
+    r = rel_l2(g, ref_c)
+    d = (g - ref_c).abs()
+    finite = bool(torch.isfinite(g).all())
+    idx = int(d.flatten().argmax()) if d.numel() else 0
+    return {"name": name, "rel_l2": r, "max_abs": float(d.max()) if d.numel() else 0.0,
+            "ref_absmax": float(ref_c.abs().max()) if d.numel() else 0.0, "worst_index": idx,
+            "shape": list(g.shape), "finite": finite, "tol": tol, "ok": bool(finite and r <= tol)}
+
+
+def rnd(shape, gen, scale=1.0):
+    """bf16-representable fp32 CPU tensor."""
+    return R.bf16_round(torch.randn(shape, generator=gen) * scale)
+
+
+# ---------------------------------------------------------------------------------------------------
+def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", residual=False, out_f32=False,
+               split_k=1, dropout_p=0.0, dact=None, want_preact=False, seed=0):
+    from dreamvla_amd import ops
+    from dreamvla_amd._lib import ACT
+    g = torch.Generator().manual_seed(1234 + seed)
+    A = rnd((M, K), g)
+    B = rnd((N, K), g, 1.0 / math.sqrt(max(K, 1)))
+    bias_t = rnd((N,), g) if bias else None
+    res_t = rnd((M, N), g) if residual else None
+    aux_t = rnd((M, N), g) if dact else None
+    a_dev = (A.t().contiguous() if a_trans else A).to(DEV, BF)
+    b_dev = (B.t().contiguous() if b_trans else B).to(DEV, BF)
+    sd = (77, 4242)
+    r = ops.gemm(a_dev, b_dev, a_trans=a_trans, b_trans=b_trans,
+                 bias=None if bias_t is None else bias_t.to(DEV, BF), act=ACT[act], want_preact=want_preact,
+                 dact_aux=None if aux_t is None else aux_t.to(DEV, BF), dact=ACT[dact] if dact else 0,
+                 dropout_p=dropout_p, seed=sd, residual=None if res_t is None else res_t.to(DEV, BF),
+                 out_dtype=torch.float32 if out_f32 else BF, split_k=split_k)
+    got, pre = r if want_preact else (r, None)
+    ref = A @ B.t()
+    if bias:
+        ref = ref + bias_t
+    out = []
+    if want_preact:
+        out.append(metrics("preact", pre, ref, TOL_FWD))
+        ref = R.bf16_round(ref)
+    ref = R.act(ref, act)
+    if dact:
+        x = aux_t.clone().requires_grad_(True)
+        R.act(x, dact).sum().backward()
+        ref = ref * x.grad
+    if dropout_p > 0:
+        ref = R.dropout_elementwise(ref, dropout_p, sd)
+    if residual:
+        ref = ref + res_t
+    tag = f"gemm M{M} N{N} K{K} at{int(a_trans)} bt{int(b_trans)} bias{int(bias)} {act} res{int(residual)} f32{int(out_f32)} sk{split_k} p{dropout_p} dact{dact}"
+    out.insert(0, metrics(tag, got, ref, TOL_F32 if out_f32 else TOL_FWD, round_ref=not out_f32))
+    return out
+
+
+def check_layernorm(rows, cols, affine=True, eps=1e-5, param_f32=False, seed=0):
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(99 + seed)
+    x = rnd((rows, cols), g, 2.0) + 0.5
+    x = R.bf16_round(x)
+    w = rnd((cols,), g) + 1.0 if affine else None
+    b = rnd((cols,), g) if affine else None
+    if affine:
+        w, b = R.bf16_round(w), R.bf16_round(b)
+    dy = rnd((rows, cols), g)
+    pdt = torch.float32 if param_f32 else BF
+    xd = x.to(DEV, BF).requires_grad_(True)
+    wd = w.to(DEV, pdt).requires_grad_(True) if affine else None
+    bd = b.to(DEV, pdt).requires_grad_(True) if affine else None
+    y = ops.layer_norm(xd, wd, bd, eps)
+    y.backward(dy.to(DEV, BF))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True) if affine else None
+    br = b.clone().requires_grad_(True) if affine else None
+    yr = R.layer_norm(xr, wr, br, eps)
+    yr.backward(dy)
+    tag = f"layernorm {rows}x{cols} affine{int(affine)} eps{eps} pf32{int(param_f32)}"
+    out = [metrics(tag + " y", y, yr, TOL_FWD), metrics(tag + " dx", xd.grad, xr.grad, TOL_GRAD)]
+    if affine:
+        out.append(metrics(tag + " dgamma", wd.grad, wr.grad, TOL_GRAD, round_ref=not param_f32))
+        out.append(metrics(tag + " dbeta", bd.grad, br.grad, TOL_GRAD, round_ref=not param_f32))
+    return out
+
+
+def make_block_mask(L, blk, nA):
+    """small analogue of generate_attention_mask (dreamvla_model.py:25-66): block-causal over `blk`-token steps,
+    the last blk-nA tokens of every step are never keys."""
+    m = torch.zeros(L, L)
+    nsteps = (L + blk - 1) // blk
+    for i in range(nsteps):
+        s, e = i * blk, min((i + 1) * blk, L)
+        m[s:e, e:] = -float("inf")
+        m[:, s + nA:e] = -float("inf")
+    return m
+
+
+def check_self_attention(B, H, L, mask_kind="none", dropout_p=0.0, grad=True, seed=0, scale=None):
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(7 + seed)
+    qkv = rnd((B, L, 3 * H * 64), g)
+    do = rnd((B, L, H * 64), g)
+    mask = None
+    if mask_kind == "block":
+        mask = make_block_mask(L, 19, 12)
+    elif mask_kind == "causal":
+        mask = torch.full((L, L), -float("inf")).triu(1)
+    qd = qkv.to(DEV, BF).requires_grad_(grad)
+    md = mask.to(DEV) if mask is not None else None
+    tm = ops.build_tile_map(md) if md is not None else None
+    from dreamvla_amd.ops import _Seeds
+    _Seeds.counter = 1000 + seed
+    o = ops.self_attention(qd, H, mask=md, tile_map=tm, dropout_p=dropout_p, scale=scale)
+    sd = (_Seeds.counter, _Seeds.next()[1])
+    _Seeds.counter -= 1
+    qr = qkv.clone().requires_grad_(grad)
+    q, k, v = R.split_qkv(qr, H)
+    orf = R.merge_heads(R.attention(q, k, v, scale=scale, mask=mask, drop=(dropout_p, sd) if dropout_p > 0 else None))
+    tag = f"self_attn B{B} H{H} L{L} mask={mask_kind} p{dropout_p}"
+    out = [metrics(tag + " o", o, orf, TOL_FWD)]
+    if grad:
+        o.backward(do.to(DEV, BF))
+        orf.backward(do)
+        out.append(metrics(tag + " dqkv", qd.grad, qr.grad, TOL_GRAD))
+        W = H * 64
+        out.append(metrics(tag + " dq", qd.grad[..., :W], qr.grad[..., :W], TOL_GRAD))
+        out.append(metrics(tag + " dk", qd.grad[..., W:2 * W], qr.grad[..., W:2 * W], TOL_GRAD))
+        out.append(metrics(tag + " dv", qd.grad[..., 2 * W:], qr.grad[..., 2 * W:], TOL_GRAD))
+    return out
+
+
+def check_cross_attention(B, H, Lq, Lk, seed=0):
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(17 + seed)
+    q = rnd((B, Lq, H * 64), g)
+    kv = rnd((B, Lk, 2 * H * 64), g)
+    do = rnd((B, Lq, H * 64), g)
+    qd = q.to(DEV, BF).requires_grad_(True)
+    kvd = kv.to(DEV, BF).requires_grad_(True)
+    o = ops.cross_attention(qd, kvd, H)
+    o.backward(do.to(DEV, BF))
+    qr = q.clone().requires_grad_(True)
+    kvr = kv.clone().requires_grad_(True)
+    q4 = qr.view(B, Lq, H, 64).permute(0, 2, 1, 3)
+    kv5 = kvr.view(B, Lk, 2, H, 64).permute(2, 0, 3, 1, 4)
+    orf = R.merge_heads(R.attention(q4, kv5[0], kv5[1]))
+    orf.backward(do)
+    tag = f"cross_attn B{B} H{H} Lq{Lq} Lk{Lk}"
+    return [metrics(tag + " o", o, orf, TOL_FWD), metrics(tag + " dq", qd.grad, qr.grad, TOL_GRAD),
+            metrics(tag + " dkv", kvd.grad, kvr.grad, TOL_GRAD)]
+
+
+def check_linear_fn(M, K, N, act="none", conv1d=False, residual=False, bias=True, dropout_p=0.0, seed=0):
+    from dreamvla_amd import ops
+    from dreamvla_amd.ops import _Seeds
+    g = torch.Generator().manual_seed(31 + seed)
+    x = rnd((3, M // 3, K), g) if M % 3 == 0 else rnd((M, K), g)
+    w = rnd((K, N) if conv1d else (N, K), g, 1.0 / math.sqrt(K))
+    b = rnd((N,), g) if bias else None
+    res = rnd(x.shape[:-1] + (N,), g) if residual else None
+    dy = rnd(x.shape[:-1] + (N,), g)
+    xd = x.to(DEV, BF).requires_grad_(True)
+    wd = w.to(DEV, BF).requires_grad_(True)
+    bd = b.to(DEV, BF).requires_grad_(True) if bias else None
+    rd = res.to(DEV, BF).requires_grad_(True) if residual else None
+    _Seeds.counter = 500 + seed
+    y = ops.linear(xd, wd, bd, act=act, conv1d=conv1d, residual=rd, dropout_p=dropout_p)
+    sd = (_Seeds.counter, _Seeds.next()[1])
+    y.backward(dy.to(DEV, BF))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    rr = res.clone().requires_grad_(True) if residual else None
+    pre = R.linear(xr, wr, br, conv1d)
+    if act != "none":
+        pre = pre + (R.bf16_round(pre.detach()) - pre.detach())  # forward sees the stored (bf16) pre-activation
+    yr = R.act(pre, act)
+    if dropout_p > 0:
+        yr = R.dropout_elementwise(yr.reshape(-1, N), dropout_p, sd).view(yr.shape)
+    if residual:
+        yr = yr + rr
+    yr.backward(dy)
+    tag = f"linear M{M} K{K} N{N} {act} conv1d{int(conv1d)} res{int(residual)} p{dropout_p}"
+    out = [metrics(tag + " y", y, yr, TOL_FWD), metrics(tag + " dx", xd.grad, xr.grad, TOL_GRAD),
+           metrics(tag + " dw", wd.grad, wr.grad, TOL_GRAD)]
+    if bias:
+        out.append(metrics(tag + " db", bd.grad, br.grad, TOL_GRAD))
+    if residual:
+        out.append(metrics(tag + " dres", rd.grad, rr.grad, TOL_GRAD))
+    return out
+
+
+def check_mlp_fn(M, K, Hd, act="gelu_erf", conv1d=False, dropout_p=0.0, seed=0):
+    from dreamvla_amd import ops
+    from dreamvla_amd.ops import _Seeds
+    g = torch.Generator().manual_seed(41 + seed)
+    x = rnd((M, K), g)
+    w1 = rnd((K, Hd) if conv1d else (Hd, K), g, 1.0 / math.sqrt(K))
+    w2 = rnd((Hd, K) if conv1d else (K, Hd), g, 1.0 / math.sqrt(Hd))
+    b1, b2 = rnd((Hd,), g), rnd((K,), g)
+    dy = rnd((M, K), g)
+    dev = [t.to(DEV, BF).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    _Seeds.counter = 900 + seed
+    y = ops.mlp(dev[0], dev[1], dev[2], dev[3], dev[4], act=act, conv1d=conv1d, residual=dev[0], dropout_p=dropout_p)
+    sd = (_Seeds.counter, _Seeds.next()[1])
+    y.backward(dy.to(DEV, BF))
+    ref = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    u = R.linear(ref[0], ref[1], ref[2], conv1d)
+    u = u + (R.bf16_round(u.detach()) - u.detach())
+    h = R.act(u, act)
+    h = h + (R.bf16_round(h.detach()) - h.detach())  # h is stored in bf16 between the two GEMMs
+    z = R.linear(h, ref[3], ref[4], conv1d)
+    if dropout_p > 0:
+        z = R.dropout_elementwise(z, dropout_p, sd)
+    yr = ref[0] + z
+    yr.backward(dy)
+    tag = f"mlp M{M} K{K} H{Hd} {act} conv1d{int(conv1d)} p{dropout_p}"
+    names = ["dx", "dw1", "db1", "dw2", "db2"]
+    out = [metrics(tag + " y", y, yr, TOL_FWD)]
+    for n, d, r in zip(names, dev, ref):
+        out.append(metrics(tag + " " + n, d.grad, r.grad, TOL_GRAD))
+    return out
+
+
+def check_misc():
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(5)
+    out = []
+    x = rnd((777, 1000), g)
+    out.append(metrics("colsum 777x1000", ops.colsum(x.to(DEV, BF)), x.sum(0), TOL_F32 * 10, round_ref=False))
+    x = rnd((50, 24), g)
+    out.append(metrics("colsum 50x24", ops.colsum(x.to(DEV, BF)), x.sum(0), TOL_F32 * 10, round_ref=False))
+    x = rnd((123, 96), g)
+    sd = (5, 6)
+    out.append(metrics("dropout 123x96 p0.1", ops.dropout_raw(x.to(DEV, BF), 0.1, sd), R.dropout_elementwise(x, 0.1, sd), TOL_FWD))
+    keep = (ops.dropout_raw(torch.ones(4096, 1024, device=DEV, dtype=BF), 0.1, (9, 9)) != 0).float().mean().item()
+    out.append({"name": "dropout keep-rate p0.1", "rel_l2": abs(keep - 0.9), "tol": 2e-3, "ok": abs(keep - 0.9) < 2e-3,
+                "max_abs": keep, "finite": True})
+    for a in ("gelu_erf", "gelu_tanh", "relu", "silu", "quick_gelu", "tanh", "sigmoid"):
+        x = rnd((64, 256), g, 2.0)
+        xr = x.clone().requires_grad_(True)
+        yr = R.act(xr, a)
+        dy = rnd((64, 256), g)
+        yr.backward(dy)
+        xd = x.to(DEV, BF).requires_grad_(True)
+        y = ops.activation(xd, a)
+        y.backward(dy.to(DEV, BF))
+        out.append(metrics(f"act {a} fwd", y, yr, TOL_FWD))
+        out.append(metrics(f"act {a} bwd", xd.grad, xr.grad, TOL_GRAD))
+    x = rnd((1000, 64), g)
+    out.append(metrics("cast f32->bf16", ops.cast_to(x.to(DEV) * 1.001, BF), (x * 1.001), TOL_FWD))
+    b = rnd((64,), g)
+    out.append(metrics("add bcast", ops.add_raw(x.to(DEV, BF), b.to(DEV, BF), 64), x + b, TOL_FWD))
+    return out
+
+
+def all_checks(quick=False):
+    """yield (callable, kwargs) for the whole kernel matrix"""
+    L = []
+    # GEMM: all four layouts, ragged edges, tiny K, epilogues
+    for at in (False, True):
+        for bt in (False, True):
+            L.append((check_gemm, dict(M=256, N=256, K=64, a_trans=at, b_trans=bt)))
+            L.append((check_gemm, dict(M=197, N=200, K=72, a_trans=at, b_trans=bt, out_f32=True)))
+    L += [
+        (check_gemm, dict(M=300, N=136, K=40, bias=True, act="gelu_erf", residual=True)),
+        (check_gemm, dict(M=130, N=264, K=96, bias=True, act="gelu_tanh", want_preact=True)),
+        (check_gemm, dict(M=64, N=7, K=768, bias=True)),
+        (check_gemm, dict(M=100, N=1024, K=6, bias=True)),
+        (check_gemm, dict(M=100, N=64, K=7, b_trans=True, bias=True)),
+        (check_gemm, dict(M=257, N=129, K=33)),
+        (check_gemm, dict(M=128, N=128, K=2048, a_trans=True, b_trans=True, split_k=4)),
+        (check_gemm, dict(M=200, N=72, K=1000, a_trans=True, b_trans=True, split_k=3)),
+        (check_gemm, dict(M=256, N=128, K=64, dropout_p=0.1, residual=True)),
+        (check_gemm, dict(M=256, N=128, K=64, dact="gelu_tanh")),
+        (check_gemm, dict(M=1024, N=1024, K=1024, bias=True, act="relu")),
+    ]
+    L += [
+        (check_layernorm, dict(rows=37, cols=768, eps=1e-6)),
+        (check_layernorm, dict(rows=1000, cols=1024)),
+        (check_layernorm, dict(rows=5000, cols=1024, param_f32=True)),
+        (check_layernorm, dict(rows=64, cols=512)),
+        (check_layernorm, dict(rows=33, cols=768, affine=False, eps=1e-6)),
+        (check_layernorm, dict(rows=9, cols=2048)),
+    ]
+    L += [
+        (check_self_attention, dict(B=2, H=2, L=32)),
+        (check_self_attention, dict(B=2, H=3, L=197)),
+        (check_self_attention, dict(B=3, H=2, L=6)),
+        (check_self_attention, dict(B=1, H=2, L=265)),
+        (check_self_attention, dict(B=2, H=2, L=133, mask_kind="block")),
+        (check_self_attention, dict(B=1, H=4, L=399, mask_kind="block")),
+        (check_self_attention, dict(B=2, H=2, L=77, mask_kind="causal")),
+        (check_self_attention, dict(B=2, H=2, L=133, mask_kind="block", dropout_p=0.1)),
+        (check_self_attention, dict(B=1, H=1, L=64, dropout_p=0.25)),
+        (check_cross_attention, dict(B=3, H=8, Lq=16, Lk=212)),
+        (check_cross_attention, dict(B=2, H=2, Lq=40, Lk=33)),
+    ]
+    L += [
+        (check_linear_fn, dict(M=192, K=96, N=160)),
+        (check_linear_fn, dict(M=192, K=96, N=160, conv1d=True, residual=True, dropout_p=0.1)),
+        (check_linear_fn, dict(M=150, K=64, N=72, act="relu")),
+        (check_linear_fn, dict(M=90, K=7, N=64, bias=True)),
+        (check_linear_fn, dict(M=2500, K=128, N=128, bias=False)),
+        (check_mlp_fn, dict(M=200, K=128, Hd=512)),
+        (check_mlp_fn, dict(M=333, K=64, Hd=256, act="gelu_tanh", conv1d=True, dropout_p=0.1)),
+        (check_misc, dict()),
+    ]
+    return L

@@ -1,0 +1,240 @@
+"""CPU model of the lane/register bookkeeping used by the HIP kernels (no GPU needed).
+
+The kernels in dreamvla_amd/csrc rely on the v_mfma_f32_32x32x16_bf16 fragment layout documented in
+/opt/skills/guides/cdna_hip_programming.md section 3:
+
+  a operand : lane l holds A[i = l & 31][slot (g = l >> 5, j = 0..7)]
+  b operand : lane l holds B[slot (g, j)][jcol = l & 31]
+  c / d     : lane l, register r holds C[i = (r & 3) + 8 * (r >> 2) + 4 * g][jcol = l & 31]
+
+and on the fact that the hardware contracts slot (g, j) of `a` with slot (g, j) of `b`, so ANY assignment of
+k values to slots is valid as long as both operands use the same one.  This file re-implements, in numpy,
+the index helpers of gemm.hip / attention.hip (stage_store, frag_load, frag_pi, acc_row, pack order) on top
+of that model and checks that the data flow computes the intended matrix products.  It pins the *design*;
+the `-m gpu` parity tests pin the compiled kernels.
+"""
+import numpy as np
+import pytest
+
+LANES = np.arange(64)
+L31 = LANES & 31
+G = LANES >> 5
+
+
+def acc_row(r, g):
+    return (r & 3) + 8 * (r >> 2) + 4 * g
+
+
+def mfma_32x32x16(a, b, c):
+    """a, b: [64 lanes][8 slots]; c: [64][16].  Returns d with the documented c/d layout."""
+    A = np.zeros((32, 2, 8))
+    B = np.zeros((2, 8, 32))
+    for l in range(64):
+        A[l & 31, l >> 5, :] = a[l]
+        B[l >> 5, :, l & 31] = b[l]
+    C = np.einsum("igj,gjn->in", A, B)
+    d = c.copy()
+    for l in range(64):
+        for r in range(16):
+            d[l, r] += C[acc_row(r, l >> 5), l & 31]
+    return d
+
+
+# ---------------------------------------------------------------------------------------------------
+# GEMM tile model (gemm.hip): 128x128x32 tile, both operand layouts
+# ---------------------------------------------------------------------------------------------------
+BM, BK, RM_STRIDE = 128, 32, 40
+
+
+def gemm_stage_rm(tile):  # tile[row][k] (128 x 32)  ->  LDS element array (row-major, padded)
+    lds = np.zeros(BM * RM_STRIDE)
+    for t in range(256):
+        r, kc = t >> 2, (t & 3) * 8
+        for rr in (r, r + 64):
+            lds[rr * RM_STRIDE + kc: rr * RM_STRIDE + kc + 8] = tile[rr, kc:kc + 8]
+    return lds
+
+
+def gemm_stage_pi(tile):  # same logical tile, but memory is [k][row]; LDS dwords [k/2][128] -> model as (dword, half)
+    lds = np.zeros((16 * BM, 2))
+    for t in range(256):
+        kp, r0 = t >> 4, (t & 15) * 8
+        v0 = tile[r0:r0 + 8, 2 * kp]       # 16-B vector: 8 rows at k even
+        v1 = tile[r0:r0 + 8, 2 * kp + 1]   # 8 rows at k odd
+        for i in range(8):
+            lds[kp * BM + r0 + i, 0] = v0[i]
+            lds[kp * BM + r0 + i, 1] = v1[i]
+    return lds
+
+
+def gemm_frag_rm(lds, row_base, ks):
+    f = np.zeros((64, 8))
+    for l in range(64):
+        row, g = row_base + (l & 31), l >> 5
+        off = row * RM_STRIDE + ks * 16 + g * 8
+        f[l] = lds[off:off + 8]
+    return f
+
+
+def gemm_frag_pi(lds, row_base, ks):
+    f = np.zeros((64, 8))
+    for l in range(64):
+        row, g = row_base + (l & 31), l >> 5
+        for jj in range(4):
+            dw = (ks * 8 + g * 4 + jj) * BM + row
+            f[l, 2 * jj], f[l, 2 * jj + 1] = lds[dw, 0], lds[dw, 1]
+    return f
+
+
+@pytest.mark.parametrize("a_t,b_t", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_tile_dataflow(a_t, b_t):
+    rng = np.random.default_rng(0)
+    A = rng.integers(-4, 5, (BM, BK)).astype(np.float64)   # A[m][k]
+    B = rng.integers(-4, 5, (BM, BK)).astype(np.float64)   # B[n][k]
+    la = gemm_stage_pi(A) if a_t else gemm_stage_rm(A)
+    lb = gemm_stage_pi(B) if b_t else gemm_stage_rm(B)
+    fa = gemm_frag_pi if a_t else gemm_frag_rm
+    fb = gemm_frag_pi if b_t else gemm_frag_rm
+    C = np.zeros((BM, BM))
+    for wave in range(4):
+        wm, wn = wave & 1, wave >> 1
+        acc = [[np.zeros((64, 16)) for _ in range(2)] for _ in range(2)]
+        for ks in range(2):
+            for i in range(2):
+                for j in range(2):
+                    acc[i][j] = mfma_32x32x16(fb(lb, wn * 64 + i * 32, ks), fa(la, wm * 64 + j * 32, ks), acc[i][j])
+        for i in range(2):
+            for j in range(2):
+                for l in range(64):
+                    for r in range(16):
+                        m = wm * 64 + 32 * j + (l & 31)
+                        n = wn * 64 + 32 * i + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3)
+                        C[m, n] = acc[i][j][l, r]
+    np.testing.assert_array_equal(C, A @ B.T)
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention tile model (attention.hip)
+# ---------------------------------------------------------------------------------------------------
+RM72 = 72
+
+
+def at_stage_rm(tile):  # tile[32 rows][64]
+    lds = np.zeros(32 * RM72)
+    for u in range(128):
+        pr, oc = u >> 3, u & 7
+        for row in (2 * pr, 2 * pr + 1):
+            lds[row * RM72 + oc * 8: row * RM72 + oc * 8 + 8] = tile[row, oc * 8: oc * 8 + 8]
+    return lds
+
+
+def at_stage_pi(tile):
+    lds = np.zeros((16 * 64, 2))
+    for u in range(128):
+        pr, oc = u >> 3, u & 7
+        for i in range(8):
+            lds[pr * 64 + oc * 8 + i, 0] = tile[2 * pr, oc * 8 + i]
+            lds[pr * 64 + oc * 8 + i, 1] = tile[2 * pr + 1, oc * 8 + i]
+    return lds
+
+
+def at_frag_rm(lds, s):
+    f = np.zeros((64, 8))
+    for l in range(64):
+        off = (l & 31) * RM72 + s * 16 + (l >> 5) * 8
+        f[l] = lds[off:off + 8]
+    return f
+
+
+def at_frag_pi(lds, db, mm):
+    f = np.zeros((64, 8))
+    for l in range(64):
+        c, g = 32 * db + (l & 31), l >> 5
+        base = (8 * mm + 2 * g) * 64 + c
+        for w, off in enumerate((0, 64, 4 * 64, 5 * 64)):
+            f[l, 2 * w], f[l, 2 * w + 1] = lds[base + off, 0], lds[base + off, 1]
+    return f
+
+
+def direct_frag(mat, s):  # register fragments loaded straight from global: row = l&31, cols 16s+8g..+7
+    f = np.zeros((64, 8))
+    for l in range(64):
+        f[l] = mat[l & 31, 16 * s + 8 * (l >> 5): 16 * s + 8 * (l >> 5) + 8]
+    return f
+
+
+def test_attention_forward_tile_dataflow():
+    rng = np.random.default_rng(1)
+    Q = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    K = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    V = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    k_rm, v_pi = at_stage_rm(K), at_stage_pi(V)
+    sacc = np.zeros((64, 16))
+    for s in range(4):
+        sacc = mfma_32x32x16(at_frag_rm(k_rm, s), direct_frag(Q, s), sacc)
+    # lane l: query l&31, register r: key acc_row(r, g)
+    S = Q @ K.T
+    for l in range(64):
+        for r in range(16):
+            assert sacc[l, r] == S[l & 31, acc_row(r, l >> 5)]
+    P = sacc  # use raw scores as "probabilities" (integers -> exact)
+    oacc = [np.zeros((64, 16)), np.zeros((64, 16))]
+    for db in range(2):
+        oacc[db] = mfma_32x32x16(at_frag_pi(v_pi, db, 0), P[:, 0:8], oacc[db])
+        oacc[db] = mfma_32x32x16(at_frag_pi(v_pi, db, 1), P[:, 8:16], oacc[db])
+    O = S @ V
+    for l in range(64):
+        for db in range(2):
+            for r in range(16):
+                assert oacc[db][l, r] == O[l & 31, 32 * db + acc_row(r, l >> 5)]
+
+
+def test_attention_backward_tile_dataflow():
+    rng = np.random.default_rng(2)
+    Q = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    K = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    V = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    dO = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    # ---- dQ kernel orientation: lane = query
+    k_rm, k_pi, v_rm = at_stage_rm(K), at_stage_pi(K), at_stage_rm(V)
+    sacc, dpacc = np.zeros((64, 16)), np.zeros((64, 16))
+    for s in range(4):
+        sacc = mfma_32x32x16(at_frag_rm(k_rm, s), direct_frag(Q, s), sacc)
+        dpacc = mfma_32x32x16(at_frag_rm(v_rm, s), direct_frag(dO, s), dpacc)
+    S, dP = Q @ K.T, dO @ V.T
+    for l in range(64):
+        for r in range(16):
+            assert dpacc[l, r] == dP[l & 31, acc_row(r, l >> 5)]
+    dS = sacc * dpacc  # any elementwise combination keeps the layout
+    dq = [np.zeros((64, 16)), np.zeros((64, 16))]
+    for db in range(2):
+        dq[db] = mfma_32x32x16(at_frag_pi(k_pi, db, 0), dS[:, 0:8], dq[db])
+        dq[db] = mfma_32x32x16(at_frag_pi(k_pi, db, 1), dS[:, 8:16], dq[db])
+    dQ = (S * dP) @ K
+    for l in range(64):
+        for db in range(2):
+            for r in range(16):
+                assert dq[db][l, r] == dQ[l & 31, 32 * db + acc_row(r, l >> 5)]
+    # ---- dK/dV kernel orientation: lane = key, registers = queries
+    q_rm, q_pi, do_rm, do_pi = at_stage_rm(Q), at_stage_pi(Q), at_stage_rm(dO), at_stage_pi(dO)
+    sacc, dpacc = np.zeros((64, 16)), np.zeros((64, 16))
+    for s in range(4):
+        sacc = mfma_32x32x16(at_frag_rm(q_rm, s), direct_frag(K, s), sacc)
+        dpacc = mfma_32x32x16(at_frag_rm(do_rm, s), direct_frag(V, s), dpacc)
+    for l in range(64):
+        for r in range(16):
+            assert sacc[l, r] == S[acc_row(r, l >> 5), l & 31]
+            assert dpacc[l, r] == dP[acc_row(r, l >> 5), l & 31]
+    P, dSr = sacc, sacc * dpacc
+    dv = [np.zeros((64, 16)), np.zeros((64, 16))]
+    dk = [np.zeros((64, 16)), np.zeros((64, 16))]
+    for db in range(2):
+        for mm in range(2):
+            dv[db] = mfma_32x32x16(at_frag_pi(do_pi, db, mm), P[:, 8 * mm: 8 * mm + 8], dv[db])
+            dk[db] = mfma_32x32x16(at_frag_pi(q_pi, db, mm), dSr[:, 8 * mm: 8 * mm + 8], dk[db])
+    dV, dK = S.T @ dO, (S * dP).T @ Q
+    for l in range(64):
+        for db in range(2):
+            for r in range(16):
+                assert dv[db][l, r] == dV[l & 31, 32 * db + acc_row(r, l >> 5)]
+                assert dk[db][l, r] == dK[l & 31, 32 * db + acc_row(r, l >> 5)]
