@@ -31,7 +31,7 @@ class GemmParams(C.Structure):
         ("preact", C.c_void_p), ("ld_preact", C.c_int64),
         ("dact_aux", C.c_void_p), ("ld_dact", C.c_int64), ("dact", C.c_int32),
         ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
-        ("residual", C.c_void_p), ("ld_res", C.c_int64),
+        ("residual", C.c_void_p), ("ld_res", C.c_int64), ("res_rows", C.c_int64),
         ("accumulate", C.c_int32),
         ("split_k", C.c_int32), ("workspace", C.c_void_p),
     ]
@@ -46,7 +46,7 @@ class AttnParams(C.Structure):
         ("o_stride_b", C.c_int64), ("o_stride_t", C.c_int64), ("o_stride_h", C.c_int64),
         ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
         ("scale", C.c_float),
-        ("mask", C.c_void_p), ("ld_mask", C.c_int64),
+        ("key_index", C.c_void_p), ("mask_bits_q", C.c_void_p), ("mask_bits_k", C.c_void_p),
         ("tile_map", C.c_void_p),
         ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
         ("lse", C.c_void_p),

@@ -4,15 +4,18 @@
 // v_mfma_f32_32x32x16_bf16(a = K fragment, b = Q fragment), so a lane owns ONE query column
 // (q = lane & 31) and 16 of the 32 keys of the tile in its accumulator registers
 // (key = (r&3) + 8*(r>>2) + 4*(lane>>5)).  Consequences:
-//   * the softmax row max / row sum are in-lane reductions plus ONE __shfl_xor(.,32);
+//   * the softmax row max / row sum are in-lane reductions plus ONE cross-half exchange;
 //   * the running max m, sum l and the O rescale factor are per-lane scalars;
-//   * P (bf16) is already in MFMA B-operand layout for O^T = V^T.P^T: no cross-lane movement, no LDS
-//     round trip for P.  The k-slot <-> key permutation this implies is applied to the V^T fragment,
-//     which is read from a "pair-interleaved" LDS image [key/2][d] (dword = {key even, key odd}).
+//   * P (bf16, hardware v_cvt_pk_bf16_f32) is already in MFMA B-operand layout for O^T = V^T.P^T: no
+//     cross-lane movement, no LDS round trip for P.  The k-slot <-> key permutation this implies is
+//     applied to the V^T fragment, read from a "pair-interleaved" LDS image [key/2][d]
+//     (dword = {key even, key odd}).
 // K/V tiles (32 keys) are staged global -> registers -> LDS once per 128-query block (4 waves share
 // them), double-buffered with the next tile's global loads in flight during the MFMAs; one barrier per
-// tile.  Fully masked 32x32 tiles (tile_map == 0) are skipped: that is 64-81 % of the trunk's tiles
-// under generate_attention_mask (models/dreamvla_model.py:25-66).
+// tile.  Masks are 0/-inf only (models/dreamvla_model.py:25-66) and reach the kernel as bit tables plus
+// a per-32x32-tile map: fully masked tiles are skipped, fully visible tiles never touch the table, mixed
+// tiles read ONE 32-bit word per lane.  `key_index` lets the caller drop keys nobody can see (the
+// prediction-query columns of the trunk mask) without copying K/V.
 //
 // Backward = delta kernel (rowsum dO.O) + dQ kernel (same structure as forward) + dK/dV kernel (a wave
 // owns 32 keys, loops over query tiles; S = Q.K^T orientation so a lane owns one key and dK^T/dV^T
@@ -34,7 +37,8 @@ struct AttnKArgs {
   int64_t qsb, qst, qsh, ksb, kst, ksh, vsb, vst, vsh, osb, ost, osh;
   int B, H, Lq, Lk;
   float scale;
-  const float* mask; int64_t ldm;
+  const int32_t* key_index;
+  const uint32_t *bits_q, *bits_k;
   const uint8_t* tile_map; int nqt, nkt;
   int has_drop; uint32_t drop_thr; float inv_keep; uint32_t seed_lo, seed_hi;
   float* lse;
@@ -47,17 +51,21 @@ struct AttnKArgs {
 // accumulator register r of lane group g  <->  row index inside the 32-row MFMA tile
 __device__ __forceinline__ int acc_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-__device__ __forceinline__ uint4 load_row16(const bf16_t* base, int64_t row, int64_t nrows, int64_t stride, int col) {
-  if (row < nrows) return *reinterpret_cast<const uint4*>(base + row * stride + col);
-  return make_uint4(0u, 0u, 0u, 0u);
+__device__ __forceinline__ uint4 load16(const bf16_t* p, bool ok) {
+  return ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0u, 0u, 0u, 0u);
 }
 
-// thread `u` (0..127) of a 128-thread staging group owns rows (2*pr, 2*pr+1), columns oct*8..oct*8+7
-__device__ __forceinline__ void stage_rows_load(uint4 (&reg)[2], const bf16_t* base, int64_t stride, int64_t row0,
-                                                int64_t nrows, int u) {
+// thread `u` (0..127) of a 128-thread staging group owns tile rows (2*pr, 2*pr+1), columns oct*8..oct*8+7
+__device__ __forceinline__ void stage_rows_load(uint4 (&reg)[2], const bf16_t* base, int64_t stride, int row0, int nrows,
+                                                const int32_t* index, int u) {
   const int pr = u >> 3, oct = u & 7;
-  reg[0] = load_row16(base, row0 + 2 * pr, nrows, stride, oct * 8);
-  reg[1] = load_row16(base, row0 + 2 * pr + 1, nrows, stride, oct * 8);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = row0 + 2 * pr + e;
+    const bool ok = row < nrows;
+    const int src = (ok && index) ? index[row] : row;
+    reg[e] = load16(base + (int64_t)src * stride + oct * 8, ok);
+  }
 }
 __device__ __forceinline__ void stage_store_rm(const uint4 (&reg)[2], char* lds, int u) {
   const int pr = u >> 3, oct = u & 7;
@@ -113,12 +121,13 @@ __device__ __forceinline__ void store_token(bf16_t* dst, const f32x16 (&acc)[2],
                                                       pack2bf(acc[db][4 * rq + 2] * mul, acc[db][4 * rq + 3] * mul));
     }
 }
+// bit position of accumulator register r inside a visibility word already shifted right by 4*g
+__device__ __forceinline__ bool vis_bit(uint32_t vg, int r) { return (vg >> ((r & 3) + 8 * (r >> 2))) & 1u; }
+__device__ __forceinline__ uint32_t low_mask(int n) { return n >= 32 ? 0xffffffffu : ((1u << n) - 1u); }
 
-// block-level "is tile (qt..qt+3, kt) needed" and next needed tile
 __device__ __forceinline__ int tile_flag(const AttnKArgs& p, int qt, int kt) {
-  if (qt >= p.nqt) return 0;
-  if (p.tile_map) return p.tile_map[qt * p.nkt + kt];
-  return p.mask ? 2 : 1;
+  if (qt >= p.nqt || kt >= p.nkt) return 0;
+  return p.tile_map ? (int)p.tile_map[qt * p.nkt + kt] : 1;
 }
 
 // ====================================================================================================
@@ -130,25 +139,26 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int qt0 = blockIdx.x * 4;
   const int qt = qt0 + wave;
-  const int64_t q = (int64_t)qt * 32 + l31;
+  const int q = qt * 32 + l31;
+  const bool q_ok = q < p.Lq;
   const float scale_log2 = p.scale * LOG2E;
 
-  const bf16_t* qb = p.q + b * p.qsb + h * p.qsh;
-  const bf16_t* kb = p.k + b * p.ksb + h * p.ksh;
-  const bf16_t* vb = p.v + b * p.vsb + h * p.vsh;
+  const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
+  const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
+  const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
 
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const uint4 u = load_row16(qb, q, p.Lq, p.qst, 16 * s + 8 * g);
+    const uint4 u = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
     qf[s] = *reinterpret_cast<const bf16x8*>(&u);
   }
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 oacc[2] = {zero16(), zero16()};
+  const int rowid = (b * p.H + h) * p.Lq + q;
   uint32_t rowkey = 0;
-  if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(((int64_t)b * p.H + h) * p.Lq + q));
+  if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
 
-  // block-uniform list walk over needed key tiles
   auto blk_need = [&](int kt) -> bool {
     return (tile_flag(p, qt0, kt) | tile_flag(p, qt0 + 1, kt) | tile_flag(p, qt0 + 2, kt) | tile_flag(p, qt0 + 3, kt)) != 0;
   };
@@ -160,8 +170,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
   const int u = is_v_loader ? t : t - 128;
   uint4 reg[2];
   auto g_load = [&](int kt) {
-    if (is_v_loader) stage_rows_load(reg, vb, p.vst, (int64_t)kt * 32, p.Lk, u);
-    else stage_rows_load(reg, kb, p.kst, (int64_t)kt * 32, p.Lk, u);
+    if (is_v_loader) stage_rows_load(reg, vb, p.vst, kt * 32, p.Lk, p.key_index, u);
+    else stage_rows_load(reg, kb, p.kst, kt * 32, p.Lk, p.key_index, u);
   };
   auto l_store = [&](int buf) {
     char* base = smem + buf * (RM_BYTES + PI_BYTES);
@@ -183,30 +193,35 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
       f32x16 sacc = zero16();
 #pragma unroll
       for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
+      const int k0 = kt * 32;
+      uint32_t vis = 0xffffffffu;
+      if (flag == 2 && q_ok) vis = p.bits_q[q * p.nkt + kt];
+      if (k0 + 32 > p.Lk) vis &= low_mask(p.Lk - k0);
       float sv[16];
-      float mt = -INFINITY;
-      const int64_t k0 = (int64_t)kt * 32;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t key = k0 + acc_row(r, g);
-        float x = sacc[r] * scale_log2;
-        if (flag == 2 && q < p.Lq && key < p.Lk) x += p.mask[q * p.ldm + key] * LOG2E;
-        if (key >= p.Lk) x = -INFINITY;
-        sv[r] = x;
-        mt = fmaxf(mt, x);
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
+      if (__any(vis != 0xffffffffu)) {
+        const uint32_t vg = vis >> (4 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = vis_bit(vg, r) ? sv[r] : -INFINITY;
       }
+      float mt = sv[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sv[r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run, mt);
+      const float m_new = fmaxf(m_run, mt * scale_log2);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f(m_run - m_safe);
+      const float alpha = fast_exp2(m_run - m_safe);
       float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sv[r] = exp2f(sv[r] - m_safe); rs += sv[r]; }
+      for (int r = 0; r < 16; ++r) { sv[r] = fast_exp2(fmaf(sv[r], scale_log2, -m_safe)); rs += sv[r]; }
       rs += __shfl_xor(rs, 32, 64);
       l_run = l_run * alpha + rs;
       m_run = m_new;
+      if (__any(alpha != 1.0f)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+      }
       if (p.has_drop) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -226,11 +241,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
     cur ^= 1;
     kt = ktn;
   }
-  if (q < p.Lq) {
+  if (q_ok) {
     const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
-    store_token(p.o + b * p.osb + q * p.ost + h * p.osh, oacc, inv_l, g);
-    if (p.lse && g == 0)
-      p.lse[((int64_t)b * p.H + h) * p.Lq + q] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
+    store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g);
+    if (p.lse && g == 0) p.lse[rowid] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
   }
 }
 
@@ -271,24 +285,25 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int qt0 = blockIdx.x * 4;
   const int qt = qt0 + wave;
-  const int64_t q = (int64_t)qt * 32 + l31;
+  const int q = qt * 32 + l31;
+  const bool q_ok = q < p.Lq;
   const float scale_log2 = p.scale * LOG2E;
-  const bf16_t* qb = p.q + b * p.qsb + h * p.qsh;
-  const bf16_t* kb = p.k + b * p.ksb + h * p.ksh;
-  const bf16_t* vb = p.v + b * p.vsb + h * p.vsh;
-  const bf16_t* dob = p.dout + b * p.dsb + h * p.dsh;
+  const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
+  const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
+  const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
+  const bf16_t* dob = p.dout + (int64_t)b * p.dsb + (int64_t)h * p.dsh;
 
   bf16x8 qf[4], dof[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const uint4 a = load_row16(qb, q, p.Lq, p.qst, 16 * s + 8 * g);
-    const uint4 c = load_row16(dob, q, p.Lq, p.dst, 16 * s + 8 * g);
+    const uint4 a = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
+    const uint4 c = load16(dob + (int64_t)q * p.dst + 16 * s + 8 * g, q_ok);
     qf[s] = *reinterpret_cast<const bf16x8*>(&a);
     dof[s] = *reinterpret_cast<const bf16x8*>(&c);
   }
-  const int64_t rowid = ((int64_t)b * p.H + h) * p.Lq + q;
-  const float lse2 = (q < p.Lq) ? p.lse[rowid] * LOG2E : INFINITY;
-  const float dlt = (q < p.Lq) ? p.delta[rowid] : 0.f;
+  const int rowid = (b * p.H + h) * p.Lq + q;
+  const float lse2 = q_ok ? p.lse[rowid] * LOG2E : INFINITY;
+  const float dlt = q_ok ? p.delta[rowid] : 0.f;
   uint32_t rowkey = 0;
   if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
   f32x16 dqacc[2] = {zero16(), zero16()};
@@ -304,8 +319,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
   const int u = is_k_loader ? t : t - 128;
   uint4 reg[2];
   auto g_load = [&](int kt) {
-    if (is_k_loader) stage_rows_load(reg, kb, p.kst, (int64_t)kt * 32, p.Lk, u);
-    else stage_rows_load(reg, vb, p.vst, (int64_t)kt * 32, p.Lk, u);
+    if (is_k_loader) stage_rows_load(reg, kb, p.kst, kt * 32, p.Lk, p.key_index, u);
+    else stage_rows_load(reg, vb, p.vst, kt * 32, p.Lk, p.key_index, u);
   };
   auto l_store = [&](int buf) {
     char* base = smem + buf * BUF;
@@ -331,20 +346,26 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(k_rm, l31, s, g), qf[s], sacc, 0, 0, 0);
         dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(v_rm, l31, s, g), dof[s], dpacc, 0, 0, 0);
       }
+      const int k0 = kt * 32;
+      uint32_t vis = 0xffffffffu;
+      if (flag == 2 && q_ok) vis = p.bits_q[q * p.nkt + kt];
+      if (k0 + 32 > p.Lk) vis &= low_mask(p.Lk - k0);
       float ds[16];
-      const int64_t k0 = (int64_t)kt * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(sacc[r], scale_log2, -lse2));
+      if (__any(vis != 0xffffffffu)) {
+        const uint32_t vg = vis >> (4 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[r] = vis_bit(vg, r) ? ds[r] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t key = k0 + acc_row(r, g);
-        float x = sacc[r] * scale_log2;
-        if (flag == 2 && q < p.Lq && key < p.Lk) x += p.mask[q * p.ldm + key] * LOG2E;
-        float pr = (key < p.Lk) ? exp2f(x - lse2) : 0.f;
         float dp = dpacc[r];
         if (p.has_drop) {
-          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)key);
+          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)(k0 + acc_row(r, g)));
           dp = (hsh >= p.drop_thr) ? dp * p.inv_keep : 0.f;
         }
-        ds[r] = pr * (dp - dlt) * p.scale;
+        ds[r] = ds[r] * (dp - dlt) * p.scale;
       }
       const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
 #pragma unroll
@@ -358,47 +379,45 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
     cur ^= 1;
     kt = ktn;
   }
-  if (q < p.Lq) store_token(p.dq + b * p.dqsb + q * p.dqst + h * p.dqsh, dqacc, 1.0f, g);
+  if (q_ok) store_token(p.dq + (int64_t)b * p.dqsb + (int64_t)q * p.dqst + (int64_t)h * p.dqsh, dqacc, 1.0f, g);
 }
 
 // ====================================================================================================
 // backward: dK, dV  (one wave = 32 keys, loop over query tiles)
 //   S = Q.K^T orientation: mfma(a = Q fragment (row = query), b = K fragment) -> lane owns one key,
 //   registers = 16 queries.  dV^T[d][key] += dO^T[d][q] . Pdrop[q][key],  dK^T[d][key] += Q^T[d][q] . dS[q][key]
-//   LDS per buffer: Q row-major | Q pair-interleaved | dO row-major | dO pair-interleaved
+//   LDS per buffer: Q row-major | Q pair-interleaved | dO row-major | dO pair-interleaved | lse2[32] | delta[32]
 // ====================================================================================================
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
-  constexpr int BUF = 2 * RM_BYTES + 2 * PI_BYTES;
+  constexpr int STAT = 2 * 32 * 4;
+  constexpr int BUF = 2 * RM_BYTES + 2 * PI_BYTES + STAT;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, g = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int kt0 = blockIdx.x * 4;
   const int ktw = kt0 + wave;
-  const int64_t key = (int64_t)ktw * 32 + l31;
+  const int key = ktw * 32 + l31;
+  const bool key_ok = key < p.Lk;
+  const int key_row = (key_ok && p.key_index) ? p.key_index[key] : key;
   const float scale_log2 = p.scale * LOG2E;
-  const bf16_t* qb = p.q + b * p.qsb + h * p.qsh;
-  const bf16_t* kb = p.k + b * p.ksb + h * p.ksh;
-  const bf16_t* vb = p.v + b * p.vsb + h * p.vsh;
-  const bf16_t* dob = p.dout + b * p.dsb + h * p.dsh;
+  const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
+  const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
+  const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
+  const bf16_t* dob = p.dout + (int64_t)b * p.dsb + (int64_t)h * p.dsh;
 
   bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const uint4 a = load_row16(kb, key, p.Lk, p.kst, 16 * s + 8 * g);
-    const uint4 c = load_row16(vb, key, p.Lk, p.vst, 16 * s + 8 * g);
+    const uint4 a = load16(kb + (int64_t)key_row * p.kst + 16 * s + 8 * g, key_ok);
+    const uint4 c = load16(vb + (int64_t)key_row * p.vst + 16 * s + 8 * g, key_ok);
     kf[s] = *reinterpret_cast<const bf16x8*>(&a);
     vf[s] = *reinterpret_cast<const bf16x8*>(&c);
   }
   f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
-  const int64_t bh_row0 = ((int64_t)b * p.H + h) * p.Lq;
+  const int bh_row0 = (b * p.H + h) * p.Lq;
 
-  auto col_flag = [&](int qt, int kt) -> int {
-    if (kt >= p.nkt) return 0;
-    if (p.tile_map) return p.tile_map[qt * p.nkt + kt];
-    return p.mask ? 2 : 1;
-  };
   auto blk_need = [&](int qt) -> bool {
-    return (col_flag(qt, kt0) | col_flag(qt, kt0 + 1) | col_flag(qt, kt0 + 2) | col_flag(qt, kt0 + 3)) != 0;
+    return (tile_flag(p, qt, kt0) | tile_flag(p, qt, kt0 + 1) | tile_flag(p, qt, kt0 + 2) | tile_flag(p, qt, kt0 + 3)) != 0;
   };
   auto next_needed = [&](int qt) -> int {
     while (qt < p.nqt && !blk_need(qt)) ++qt;
@@ -407,14 +426,21 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
   const bool is_q_loader = t < 128;
   const int u = is_q_loader ? t : t - 128;
   uint4 reg[2];
+  float stat = 0.f;
   auto g_load = [&](int qt) {
-    if (is_q_loader) stage_rows_load(reg, qb, p.qst, (int64_t)qt * 32, p.Lq, u);
-    else stage_rows_load(reg, dob, p.dst, (int64_t)qt * 32, p.Lq, u);
+    if (is_q_loader) stage_rows_load(reg, qb, p.qst, qt * 32, p.Lq, nullptr, u);
+    else stage_rows_load(reg, dob, p.dst, qt * 32, p.Lq, nullptr, u);
+    if (t < 64) {
+      const int qq = qt * 32 + (t & 31);
+      if (t < 32) stat = qq < p.Lq ? p.lse[bh_row0 + qq] * LOG2E : INFINITY;
+      else stat = qq < p.Lq ? p.delta[bh_row0 + qq] : 0.f;
+    }
   };
   auto l_store = [&](int buf) {
     char* base = smem + buf * BUF + (is_q_loader ? 0 : (RM_BYTES + PI_BYTES));
     stage_store_rm(reg, base, u);
     stage_store_pi(reg, base + RM_BYTES, u);
+    if (t < 64) reinterpret_cast<float*>(smem + buf * BUF + 2 * RM_BYTES + 2 * PI_BYTES)[t] = stat;
   };
 
   int qt = next_needed(0);
@@ -424,43 +450,52 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
   while (qt >= 0) {
     const int qtn = next_needed(qt + 1);
     if (qtn >= 0) g_load(qtn);
-    const int flag = col_flag(qt, ktw);
+    const int flag = tile_flag(p, qt, ktw);
     if (flag != 0) {
       const char* q_rm = smem + cur * BUF;
       const char* q_pi = q_rm + RM_BYTES;
       const char* do_rm = q_pi + PI_BYTES;
       const char* do_pi = do_rm + RM_BYTES;
+      const float* st = reinterpret_cast<const float*>(do_pi + PI_BYTES);
       f32x16 sacc = zero16(), dpacc = zero16();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(q_rm, l31, s, g), kf[s], sacc, 0, 0, 0);
         dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(do_rm, l31, s, g), vf[s], dpacc, 0, 0, 0);
       }
-      float pd[16], ds[16];
-      const int64_t q0 = (int64_t)qt * 32;
+      const int q0 = qt * 32;
+      float lse2[16], dlt[16];
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 a = *reinterpret_cast<const float4*>(st + 8 * rq + 4 * g);
+        const float4 c = *reinterpret_cast<const float4*>(st + 32 + 8 * rq + 4 * g);
+        lse2[4 * rq] = a.x; lse2[4 * rq + 1] = a.y; lse2[4 * rq + 2] = a.z; lse2[4 * rq + 3] = a.w;
+        dlt[4 * rq] = c.x; dlt[4 * rq + 1] = c.y; dlt[4 * rq + 2] = c.z; dlt[4 * rq + 3] = c.w;
+      }
+      uint32_t vis = key_ok ? 0xffffffffu : 0u;  // bit i: query q0+i sees this lane's key
+      if (flag == 2 && key_ok) vis = p.bits_k[key * p.nqt + qt];
+      float pr[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[r] = fast_exp2(fmaf(sacc[r], scale_log2, -lse2[r]));  // q >= Lq: lse2 = +inf -> 0
+      if (__any(vis != 0xffffffffu)) {
+        const uint32_t vg = vis >> (4 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = vis_bit(vg, r) ? pr[r] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t q = q0 + acc_row(r, g);
-        const bool valid = (q < p.Lq) && (key < p.Lk);
-        float pr = 0.f, dlt = 0.f;
-        if (valid) {
-          float x = sacc[r] * scale_log2;
-          if (flag == 2) x += p.mask[q * p.ldm + key] * LOG2E;
-          pr = exp2f(x - p.lse[bh_row0 + q] * LOG2E);
-          dlt = p.delta[bh_row0 + q];
-        }
         float dp = dpacc[r];
-        float pdrop = pr;
+        float pdrop = pr[r];
         if (p.has_drop) {
-          const uint32_t rk = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + q));
+          const uint32_t rk = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + q0 + acc_row(r, g)));
           const bool keep = drop_hash_rk(rk, (uint32_t)key) >= p.drop_thr;
           dp = keep ? dp * p.inv_keep : 0.f;
-          pdrop = keep ? pr * p.inv_keep : 0.f;
+          pdrop = keep ? pdrop * p.inv_keep : 0.f;
         }
-        pd[r] = pdrop;
-        ds[r] = pr * (dp - dlt) * p.scale;
+        ds[r] = pr[r] * (dp - dlt[r]) * p.scale;
+        pr[r] = pdrop;
       }
-      const bf16x8 pf0 = pack_frag(pd), pf1 = pack_frag(pd + 8);
+      const bf16x8 pf0 = pack_frag(pr), pf1 = pack_frag(pr + 8);
       const bf16x8 sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
@@ -475,9 +510,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
     cur ^= 1;
     qt = qtn;
   }
-  if (key < p.Lk) {
-    store_token(p.dk + b * p.dksb + key * p.dkst + h * p.dksh, dkacc, 1.0f, g);
-    store_token(p.dv + b * p.dvsb + key * p.dvst + h * p.dvsh, dvacc, 1.0f, g);
+  if (key_ok) {
+    store_token(p.dk + (int64_t)b * p.dksb + (int64_t)key_row * p.dkst + (int64_t)h * p.dksh, dkacc, 1.0f, g);
+    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, 1.0f, g);
   }
 }
 
@@ -488,11 +523,13 @@ inline bool ok16(const void* ptr, int64_t s0, int64_t s1, int64_t s2) {
 int fill_args(const dvla_attn_params* q, AttnKArgs& a) {
   if (!q || !q->q || !q->k || !q->v || !q->o) return DVLA_ERR_ARG;
   if (q->B <= 0 || q->H <= 0 || q->Lq <= 0 || q->Lk <= 0) return DVLA_ERR_ARG;
-  if (q->dropout_p < 0.f || q->dropout_p >= 1.f) return DVLA_ERR_ARG;
+  if (q->dropout_p < 0.f || q->dropout_p >= 1.f || !(q->scale > 0.f)) return DVLA_ERR_ARG;
+  if ((int64_t)q->B * q->H * q->Lq >= (1LL << 31)) return DVLA_ERR_UNSUPPORTED;
   if (!ok16(q->q, q->q_stride_b, q->q_stride_t, q->q_stride_h) || !ok16(q->k, q->k_stride_b, q->k_stride_t, q->k_stride_h) ||
       !ok16(q->v, q->v_stride_b, q->v_stride_t, q->v_stride_h) ||
       !(reinterpret_cast<uintptr_t>(q->o) % 8 == 0 && q->o_stride_b % 4 == 0 && q->o_stride_t % 4 == 0 && q->o_stride_h % 4 == 0))
     return DVLA_ERR_UNSUPPORTED;
+  if (q->tile_map && !q->mask_bits_q) return DVLA_ERR_ARG;
   a.q = (const bf16_t*)q->q; a.k = (const bf16_t*)q->k; a.v = (const bf16_t*)q->v; a.o = (bf16_t*)q->o;
   a.qsb = q->q_stride_b; a.qst = q->q_stride_t; a.qsh = q->q_stride_h;
   a.ksb = q->k_stride_b; a.kst = q->k_stride_t; a.ksh = q->k_stride_h;
@@ -500,8 +537,9 @@ int fill_args(const dvla_attn_params* q, AttnKArgs& a) {
   a.osb = q->o_stride_b; a.ost = q->o_stride_t; a.osh = q->o_stride_h;
   a.B = q->B; a.H = q->H; a.Lq = q->Lq; a.Lk = q->Lk;
   a.scale = q->scale;
-  a.mask = q->mask; a.ldm = q->ld_mask;
-  a.tile_map = q->mask ? q->tile_map : nullptr;
+  a.key_index = q->key_index;
+  a.bits_q = q->mask_bits_q; a.bits_k = q->mask_bits_k;
+  a.tile_map = q->tile_map;
   a.nqt = (q->Lq + 31) / 32; a.nkt = (q->Lk + 31) / 32;
   a.has_drop = q->dropout_p > 0.f;
   a.inv_keep = a.has_drop ? 1.0f / (1.0f - q->dropout_p) : 1.0f;
@@ -538,6 +576,7 @@ extern "C" int dvla_attn_bwd(const dvla_attn_params* q, void* stream_) {
   int rc = fill_args(q, a);
   if (rc != DVLA_OK) return rc;
   if (!q->dout || !q->lse || !q->delta || !q->dq || !q->dk || !q->dv) return DVLA_ERR_ARG;
+  if (q->tile_map && !q->mask_bits_k) return DVLA_ERR_ARG;
   if (!ok16(q->dout, q->do_stride_b, q->do_stride_t, q->do_stride_h)) return DVLA_ERR_UNSUPPORTED;
   auto ok8 = [](const void* ptr, int64_t s0, int64_t s1, int64_t s2) {
     return (reinterpret_cast<uintptr_t>(ptr) % 8 == 0) && (s0 % 4 == 0) && (s1 % 4 == 0) && (s2 % 4 == 0);

@@ -19,16 +19,20 @@ enum DvlaAct { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_RELU = 3, 
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even float -> bf16 (same rounding as torch's float->bfloat16 cast)
+// round-to-nearest-even float -> bf16 (same rounding as torch's float->bfloat16 cast); both forms lower to
+// the gfx950 hardware converter v_cvt_pk_bf16_f32 (one instruction per PAIR of values).
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float hw_f32x2;
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const hw_f32x2 v = {lo, hi};
+  const hw_bf16x2 b = __builtin_convertvector(v, hw_bf16x2);
+  return __builtin_bit_cast(uint32_t, b);
 }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
 
 __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {

@@ -39,7 +39,7 @@ struct GemmKArgs {
   bf16_t* preact; int64_t ld_preact;
   const bf16_t* dact_aux; int64_t ld_dact; int dact;
   float drop_scale; uint32_t drop_thr; uint32_t seed_lo, seed_hi; int has_drop;
-  const bf16_t* residual; int64_t ld_res;
+  const bf16_t* residual; int64_t ld_res; int64_t res_rows;
   int accumulate;
   int split_k; int64_t k_per_split; float* workspace;
   int a_vec, b_vec, c_vec, aux_vec;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
   }
   if (p.residual) {
     float a[8];
-    load8_aux(p.residual + m * p.ld_res + n, n, p.N, p.aux_vec, a);
+    load8_aux(p.residual + (p.res_rows > 0 ? m % p.res_rows : m) * p.ld_res + n, n, p.N, p.aux_vec, a);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += a[e];
   }
@@ -337,7 +337,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     a.drop_thr = thr >= 4294967295.0 ? 4294967295u : (uint32_t)thr;
   }
   a.seed_lo = q->seed_lo; a.seed_hi = q->seed_hi;
-  a.residual = reinterpret_cast<const bf16_t*>(q->residual); a.ld_res = q->ld_res;
+  a.residual = reinterpret_cast<const bf16_t*>(q->residual); a.ld_res = q->ld_res; a.res_rows = q->res_rows;
   a.accumulate = q->accumulate;
   a.split_k = split_k; a.workspace = reinterpret_cast<float*>(q->workspace);
   {

@@ -90,7 +90,7 @@ def auto_split_k(M, N, K):
 
 
 def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=False, dact_aux=None, dact=0,
-         dropout_p=0.0, seed=(0, 0), residual=None, out_dtype=BF16, out=None, accumulate=False, split_k=1):
+         dropout_p=0.0, seed=(0, 0), residual=None, res_rows=0, out_dtype=BF16, out=None, accumulate=False, split_k=1):
     """C[M,N] = epilogue(A . B^T); see include/dvla.h.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
     Returns C (and the pre-activation tensor if want_preact)."""
     lib = _lib.load()
@@ -139,7 +139,7 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
         _req(residual, "gemm.residual")
         if residual.stride(1) != 1:
             residual = residual.contiguous()
-        p.residual, p.ld_res = residual.data_ptr(), residual.stride(0)
+        p.residual, p.ld_res, p.res_rows = residual.data_ptr(), residual.stride(0), int(res_rows)
     p.accumulate = int(accumulate)
     ws = None
     if split_k > 1:
@@ -249,31 +249,71 @@ def add_raw(a, b, period=0):
 # ---------------------------------------------------------------------------------------------------
 # attention launchers
 # ---------------------------------------------------------------------------------------------------
-def build_tile_map(mask):
-    """uint8 (ceil(Lq/32), ceil(Lk/32)) classification of an additive 0/-inf mask: 0 = all -inf (skip),
-    1 = all visible, 2 = mixed.  Host-side, once per mask (models/dreamvla_model.py:25-66 masks are static
-    outside the pretrain phase)."""
+class MaskTables:
+    """Device-side tables derived once from an additive 0/-inf attention mask (see include/dvla.h)."""
+
+    def __init__(self, Lq, Lk_full, Lk, key_index, bits_q, bits_k, tile_map, visible_fraction):
+        self.Lq, self.Lk_full, self.Lk = Lq, Lk_full, Lk
+        self.key_index, self.bits_q, self.bits_k, self.tile_map = key_index, bits_q, bits_k, tile_map
+        self.visible_fraction = visible_fraction
+
+
+def build_mask_tables(mask, device=None, compact_keys=True):
+    """mask: (Lq, Lk) additive mask whose entries are 0 or -inf (generate_attention_mask,
+    models/dreamvla_model.py:25-66; CLIP causal mask).  Host-side, once per mask."""
+    import numpy as np
+    device = mask.device if device is None else device
     m = mask.detach().float().cpu()
-    Lq, Lk = m.shape
-    nq, nk = (Lq + 31) // 32, (Lk + 31) // 32
-    vis = torch.zeros(nq * 32, nk * 32, dtype=torch.bool)
-    valid = torch.zeros(nq * 32, nk * 32, dtype=torch.bool)
-    vis[:Lq, :Lk] = m == 0
+    if m.dim() != 2:
+        raise ValueError("attention mask must be 2-D (Lq, Lk)")
+    if bool(((m != 0) & ~torch.isneginf(m)).any()):
+        raise ValueError("the HIP attention kernels take 0 / -inf masks only (all the reference ever builds)")
+    vis = (m == 0).numpy()
+    Lq, Lk_full = vis.shape
+    key_index = None
+    if compact_keys:
+        cols = np.nonzero(vis.any(axis=0))[0]
+        if len(cols) == 0:
+            raise ValueError("mask hides every key")
+        if len(cols) < Lk_full:
+            key_index = torch.from_numpy(cols.astype(np.int32)).to(device)
+            vis = vis[:, cols]
+    Lk = vis.shape[1]
+    nqt, nkt = (Lq + 31) // 32, (Lk + 31) // 32
+    vp = np.zeros((nqt * 32, nkt * 32), dtype=bool)
+    vp[:Lq, :Lk] = vis
+    valid = np.zeros_like(vp)
     valid[:Lq, :Lk] = True
-    other = torch.zeros(nq * 32, nk * 32, dtype=torch.bool)
-    other[:Lq, :Lk] = (m != 0) & ~torch.isinf(m)
-    v = vis.view(nq, 32, nk, 32).permute(0, 2, 1, 3).reshape(nq, nk, -1)
-    va = valid.view(nq, 32, nk, 32).permute(0, 2, 1, 3).reshape(nq, nk, -1)
-    ot = other.view(nq, 32, nk, 32).permute(0, 2, 1, 3).reshape(nq, nk, -1)
-    n_valid = va.sum(-1)
-    n_vis = (v & va).sum(-1)
-    tm = torch.full((nq, nk), 2, dtype=torch.uint8)
-    tm[(n_vis == n_valid) & ~ot.any(-1)] = 1
-    tm[(n_vis == 0) & ~ot.any(-1)] = 0
-    return tm.to(mask.device)
+    w = (np.uint64(1) << np.arange(32, dtype=np.uint64))
+    bits_q = (vp.reshape(nqt * 32, nkt, 32).astype(np.uint64) * w).sum(-1).astype(np.uint32)[:Lq]          # (Lq, nkt)
+    bits_k = (vp.T.reshape(nkt * 32, nqt, 32).astype(np.uint64) * w).sum(-1).astype(np.uint32)[:Lk]        # (Lk, nqt)
+    t_vis = vp.reshape(nqt, 32, nkt, 32).sum(axis=(1, 3))
+    t_val = valid.reshape(nqt, 32, nkt, 32).sum(axis=(1, 3))
+    tile_map = np.full((nqt, nkt), 2, dtype=np.uint8)
+    tile_map[t_vis == t_val] = 1
+    tile_map[t_vis == 0] = 0
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32) if a.dtype == np.uint32 else np.ascontiguousarray(a)).to(device)
+    return MaskTables(Lq, Lk_full, Lk, key_index, to_dev(bits_q), to_dev(bits_k), to_dev(tile_map),
+                      float(vis.mean()))
 
 
-def _attn_params(q, k, v, o, H, Lq, Lk, scale, mask, tile_map, dropout_p, seed, lse):
+_MASK_CACHE = {}
+
+
+def mask_tables_for(mask):
+    """Cached build_mask_tables keyed on the mask tensor's storage + version (the reference keeps the mask as an
+    nn.Parameter and regenerates it only in the pretrain phase, dreamvla_model.py:286-298,610-628)."""
+    key = (mask.data_ptr(), mask._version, tuple(mask.shape), str(mask.device))
+    mt = _MASK_CACHE.get(key)
+    if mt is None:
+        if len(_MASK_CACHE) > 16:
+            _MASK_CACHE.clear()
+        mt = build_mask_tables(mask)
+        _MASK_CACHE[key] = mt
+    return mt
+
+
+def _attn_params(q, k, v, o, H, Lq, scale, mt, dropout_p, seed, lse):
     p = AttnParams()
     B = q.shape[0]
     p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
@@ -283,44 +323,41 @@ def _attn_params(q, k, v, o, H, Lq, Lk, scale, mask, tile_map, dropout_p, seed, 
         setattr(p, name + "_stride_b", t.stride(0))
         setattr(p, name + "_stride_t", t.stride(1))
         setattr(p, name + "_stride_h", t.stride(2))
+    Lk = k.shape[1]
+    if mt is not None:
+        if mt.Lq != Lq or mt.Lk_full != k.shape[1]:
+            raise ValueError(f"attention mask is {mt.Lq}x{mt.Lk_full}, tensors are {Lq}x{k.shape[1]}")
+        Lk = mt.Lk
+        p.key_index = _ptr(mt.key_index)
+        p.mask_bits_q, p.mask_bits_k, p.tile_map = mt.bits_q.data_ptr(), mt.bits_k.data_ptr(), mt.tile_map.data_ptr()
     p.B, p.H, p.Lq, p.Lk = B, H, Lq, Lk
     p.scale = float(scale)
-    if mask is not None:
-        if mask.dtype != torch.float32 or mask.shape != (Lq, Lk) or mask.stride(1) != 1 or not mask.is_cuda:
-            raise ValueError("attention mask must be a CUDA fp32 (Lq, Lk) tensor")
-        p.mask, p.ld_mask = mask.data_ptr(), mask.stride(0)
-        if tile_map is not None:
-            if tile_map.dtype != torch.uint8 or not tile_map.is_contiguous() or \
-                    tile_map.shape != ((Lq + 31) // 32, (Lk + 31) // 32):
-                raise ValueError("bad tile_map")
-            p.tile_map = tile_map.data_ptr()
     p.dropout_p = float(dropout_p)
     p.seed_lo, p.seed_hi = int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF
     p.lse = _ptr(lse)
     return p
 
 
-def attn_fwd_raw(q, k, v, *, scale, mask=None, tile_map=None, dropout_p=0.0, seed=(0, 0), want_lse=True):
+def attn_fwd_raw(q, k, v, *, scale, mask_tables=None, dropout_p=0.0, seed=(0, 0), want_lse=True):
     """q: (B, Lq, H, 64), k/v: (B, Lk, H, 64) strided bf16 views.  Returns o (B, Lq, H, 64) contiguous, lse."""
     lib = _lib.load()
     for n, t in (("q", q), ("k", k), ("v", v)):
         _req(t, "attention." + n)
     B, Lq, H, _ = q.shape
-    Lk = k.shape[1]
     o = torch.empty((B, Lq, H, 64), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device) if want_lse else None
-    p = _attn_params(q, k, v, o, H, Lq, Lk, scale, mask, tile_map, dropout_p, seed, lse)
+    p = _attn_params(q, k, v, o, H, Lq, scale, mask_tables, dropout_p, seed, lse)
     check(lib.dvla_attn_fwd(C.byref(p), _stream()), "dvla_attn_fwd")
     return o, lse
 
 
-def attn_bwd_raw(q, k, v, o, lse, dout, dq, dk, dv, *, scale, mask=None, tile_map=None, dropout_p=0.0, seed=(0, 0)):
+def attn_bwd_raw(q, k, v, o, lse, dout, dq, dk, dv, *, scale, mask_tables=None, dropout_p=0.0, seed=(0, 0)):
+    """dk/dv rows that mask_tables.key_index does not name are NOT written: pass zero-filled buffers then."""
     lib = _lib.load()
     B, Lq, H, _ = q.shape
-    Lk = k.shape[1]
     if dout.stride(3) != 1:
         dout = dout.contiguous()
-    p = _attn_params(q, k, v, o, H, Lq, Lk, scale, mask, tile_map, dropout_p, seed, lse)
+    p = _attn_params(q, k, v, o, H, Lq, scale, mask_tables, dropout_p, seed, lse)
     delta = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
     p.dout = dout.data_ptr()
     p.do_stride_b, p.do_stride_t, p.do_stride_h = dout.stride(0), dout.stride(1), dout.stride(2)
@@ -340,18 +377,19 @@ class _Linear(torch.autograd.Function):
     """y = residual + dropout(act(x . W^T + b)).  conv1d=True: W is HF Conv1D (in, out) (models/gpt2.py:53)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, act, conv1d, dropout_p):
+    def forward(ctx, x, w, b, residual, act, conv1d, dropout_p, res_rows=0):
         _req(x, "linear.input"); _req(w, "linear.weight")
         K = w.shape[0] if conv1d else w.shape[1]
         N = w.shape[1] if conv1d else w.shape[0]
         x2 = _rows2d(x, K)
-        need_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)
-                                                 or (residual is not None and residual.requires_grad))
+        if res_rows and residual is not None and residual.requires_grad:
+            raise ValueError("a broadcast (res_rows) residual must not require grad")
+        need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
         seed = next_seed() if dropout_p > 0 else (0, 0)
         res2 = _rows2d(residual, N) if residual is not None else None
         want_pre = need_grad and act != 0
         r = gemm(x2, w, b_trans=conv1d, bias=b, act=act, want_preact=want_pre, dropout_p=dropout_p, seed=seed,
-                 residual=res2)
+                 residual=res2, res_rows=res_rows)
         y2, pre = r if want_pre else (r, None)
         ctx.act, ctx.conv1d, ctx.dropout_p, ctx.seed = act, conv1d, dropout_p, seed
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
@@ -386,12 +424,14 @@ class _Linear(torch.autograd.Function):
             db = cast_to(colsum(dz), ctx.bias_dtype)
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
-def linear(x, w, b=None, *, act="none", conv1d=False, residual=None, dropout_p=0.0):
+def linear(x, w, b=None, *, act="none", conv1d=False, residual=None, dropout_p=0.0, res_rows=0):
+    """res_rows > 0: `residual` is a (res_rows, N) table added to output row m at row m % res_rows (e.g. a fixed
+    position embedding shared by every image of the batch); it receives no gradient."""
     return _Linear.apply(x, w, b, residual, ACT[act] if isinstance(act, str) else int(act), bool(conv1d),
-                         float(dropout_p))
+                         float(dropout_p), int(res_rows))
 
 
 class _Mlp(torch.autograd.Function):
@@ -404,8 +444,7 @@ class _Mlp(torch.autograd.Function):
         K = w1.shape[0] if conv1d else w1.shape[1]
         N = w2.shape[1] if conv1d else w2.shape[0]
         x2 = _rows2d(x, K)
-        need_grad = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (x, w1, b1, w2, b2, residual))
+        need_grad = any(ctx.needs_input_grad)
         seed = next_seed() if dropout_p > 0 else (0, 0)
         res2 = _rows2d(residual, N) if residual is not None else None
         if need_grad:
@@ -465,7 +504,7 @@ class _LayerNorm(torch.autograd.Function):
         x2 = x.reshape(-1, cols)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        need_grad = torch.is_grad_enabled() and (x.requires_grad or (gamma is not None and gamma.requires_grad))
+        need_grad = any(ctx.needs_input_grad)
         y, mean, rstd = layernorm_fwd(x2, gamma, beta, eps, need_grad)
         ctx.has_affine = gamma is not None
         ctx.has_beta = beta is not None
@@ -499,7 +538,7 @@ class _SelfAttention(torch.autograd.Function):
     qkv.reshape(B,N,3,h,d) and GPT-2's c_attn(...).split(H) order.  Returns (B, L, H*64)."""
 
     @staticmethod
-    def forward(ctx, qkv, H, scale, mask, tile_map, dropout_p):
+    def forward(ctx, qkv, H, scale, mask_tables, dropout_p):
         _req(qkv, "attention.qkv")
         B, L, W = qkv.shape
         if W != 3 * H * 64:
@@ -508,32 +547,33 @@ class _SelfAttention(torch.autograd.Function):
             qkv = qkv.contiguous()
         v5 = qkv.view(B, L, 3, H, 64)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
-        need_grad = torch.is_grad_enabled() and qkv.requires_grad
+        need_grad = any(ctx.needs_input_grad)
         seed = next_seed() if dropout_p > 0 else (0, 0)
-        o, lse = attn_fwd_raw(q, k, v, scale=scale, mask=mask, tile_map=tile_map, dropout_p=dropout_p, seed=seed,
+        o, lse = attn_fwd_raw(q, k, v, scale=scale, mask_tables=mask_tables, dropout_p=dropout_p, seed=seed,
                               want_lse=need_grad)
-        ctx.H, ctx.scale, ctx.dropout_p, ctx.seed = H, scale, dropout_p, seed
+        ctx.H, ctx.scale, ctx.dropout_p, ctx.seed, ctx.mt = H, scale, dropout_p, seed, mask_tables
         if need_grad:
-            ctx.save_for_backward(qkv, o, lse, mask, tile_map)
+            ctx.save_for_backward(qkv, o, lse)
         return o.view(B, L, H * 64)
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, o, lse, mask, tile_map = ctx.saved_tensors
+        qkv, o, lse = ctx.saved_tensors
         B, L, _ = qkv.shape
-        H = ctx.H
+        H, mt = ctx.H, ctx.mt
         v5 = qkv.view(B, L, 3, H, 64)
-        dqkv = torch.empty_like(qkv)
+        # with a compacted key axis the kernel leaves dk/dv rows of never-visible keys untouched -> zeros
+        dqkv = torch.zeros_like(qkv) if (mt is not None and mt.key_index is not None) else torch.empty_like(qkv)
         d5 = dqkv.view(B, L, 3, H, 64)
         do = _req(dout, "attention.grad_output").contiguous().view(B, L, H, 64)
         attn_bwd_raw(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], o, lse, do, d5[:, :, 0], d5[:, :, 1], d5[:, :, 2],
-                     scale=ctx.scale, mask=mask, tile_map=tile_map, dropout_p=ctx.dropout_p, seed=ctx.seed)
-        return dqkv, None, None, None, None, None
+                     scale=ctx.scale, mask_tables=mt, dropout_p=ctx.dropout_p, seed=ctx.seed)
+        return dqkv, None, None, None, None
 
 
-def self_attention(qkv, num_heads, *, scale=None, mask=None, tile_map=None, dropout_p=0.0):
+def self_attention(qkv, num_heads, *, scale=None, mask_tables=None, dropout_p=0.0):
     scale = (1.0 / math.sqrt(64.0)) if scale is None else scale
-    return _SelfAttention.apply(qkv, int(num_heads), float(scale), mask, tile_map, float(dropout_p))
+    return _SelfAttention.apply(qkv, int(num_heads), float(scale), mask_tables, float(dropout_p))
 
 
 class _CrossAttention(torch.autograd.Function):
@@ -548,7 +588,7 @@ class _CrossAttention(torch.autograd.Function):
         q = q.contiguous(); kv = kv.contiguous()
         q4 = q.view(B, Lq, H, 64)
         kv5 = kv.view(B, Lk, 2, H, 64)
-        need_grad = torch.is_grad_enabled() and (q.requires_grad or kv.requires_grad)
+        need_grad = any(ctx.needs_input_grad)
         o, lse = attn_fwd_raw(q4, kv5[:, :, 0], kv5[:, :, 1], scale=scale, want_lse=need_grad)
         ctx.H, ctx.scale = H, scale
         if need_grad:
@@ -599,7 +639,7 @@ class _Act(torch.autograd.Function):
     def forward(ctx, x, act):
         _req(x, "act.input")
         ctx.act = act
-        if torch.is_grad_enabled() and x.requires_grad:
+        if ctx.needs_input_grad[0]:
             ctx.save_for_backward(x)
         return act_fwd_raw(x, act)
 

@@ -58,7 +58,7 @@ typedef struct dvla_gemm_params {
   void* preact; int64_t ld_preact;
   const void* dact_aux; int64_t ld_dact; int32_t dact;
   float dropout_p; uint32_t seed_lo; uint32_t seed_hi;
-  const void* residual; int64_t ld_res;
+  const void* residual; int64_t ld_res; int64_t res_rows; /* >0: residual row = m % res_rows (broadcast tables) */
   int32_t accumulate;
   int32_t split_k; void* workspace;
 } dvla_gemm_params;
@@ -83,13 +83,19 @@ int64_t dvla_layernorm_bwd_partial_rows(void);
 /* ---------------------------------------------------------------------------------------------------
  * Fused multi-head attention, head_dim = 64 (every attention in DreamVLA: ViT 768/12, trunk 1024/16,
  * dream-head decoders 1024/16, DiT 768/12, perceiver dim_head 64, CLIP text 512/8).
- *   O[b,i,h,:] = sum_j softmax_j( scale * q[b,i,h,:].k[b,j,h,:] + mask[i,j] ) * drop(.) * v[b,j,h,:]
+ *   O[b,i,h,:] = sum_j drop( softmax_j( scale * q[b,i,h,:].k[b,j,h,:] + mask[i,j] ) ) * v[b,j,h,:]
  * q/k/v/o element (b, token, head, d) lives at ptr[b*stride_b + token*stride_t + head*stride_h + d], so
  * the fused (B,N,3,h,d) timm qkv buffer, the GPT-2 c_attn (B,L,3H) buffer and the perceiver q / kv
- * buffers are read in place (no head-split copies).  mask: optional fp32 additive (Lq x Lk, row stride
- * ld_mask), values 0 / -inf as built by generate_attention_mask (models/dreamvla_model.py:25-66); the
- * optional tile map (ceil(Lq/32) x ceil(Lk/32) bytes: 0 = fully masked -> skipped, 1 = fully visible,
- * 2 = mixed) lets the kernel skip the 64-81 % of trunk tiles that are -inf.
+ * buffers are read in place (no head-split copies).
+ * Masks: the reference only ever builds 0 / -inf additive masks (generate_attention_mask,
+ * models/dreamvla_model.py:25-66; CLIP's causal mask).  The host converts such a mask once into
+ *   mask_bits_q (Lq x ceil(Lk/32) uint32): bit j of [i][kt] set <=> key 32*kt+j is visible to query i
+ *   mask_bits_k (Lk x ceil(Lq/32) uint32): bit i of [j][qt] set <=> query 32*qt+i sees key j   (backward)
+ *   tile_map    (ceil(Lq/32) x ceil(Lk/32) uint8): 0 = all -inf (tile skipped), 1 = all visible, 2 = mixed
+ * so masked tiles cost nothing (64-81 % of the trunk's score matrix) and a mixed tile
+ * costs one 32-bit load per lane.  key_index (Lk int32, optional) names the k/v (and dk/dv) token row that
+ * holds key j: keys that no query can see are dropped from the key axis without copying K/V; dk/dv rows
+ * that are not indexed are NOT written (the caller zero-fills them).
  * lse (B*H*Lq fp32, natural-log-sum-exp of the scaled+masked scores) is written when non-NULL.
  * Replaces: F.scaled_dot_product_attention in timm Attention (vit_mae.py:202-203, dreamvla_model.py:806-904,
  * action_model/models.py:137), GPT2Attention._attn / GPT2SdpaAttention (models/gpt2.py:61-84,267-274),
@@ -103,7 +109,9 @@ typedef struct dvla_attn_params {
   int64_t o_stride_b, o_stride_t, o_stride_h;
   int32_t B, H, Lq, Lk;
   float scale;
-  const float* mask; int64_t ld_mask;
+  const int32_t* key_index;
+  const uint32_t* mask_bits_q;
+  const uint32_t* mask_bits_k;
   const uint8_t* tile_map;
   float dropout_p; uint32_t seed_lo; uint32_t seed_hi;
   float* lse;

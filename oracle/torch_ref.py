@@ -87,12 +87,13 @@ def linear(x, w, b=None, conv1d=False):
     return y if b is None else y + b
 
 
-def attention(q, k, v, scale=None, mask=None, drop=None):
+def attention(q, k, v, scale=None, mask=None, drop=None, drop_cols=None):
     """softmax(q k^T * scale + mask) v over (B, H, L, d) tensors.
     timm Attention -> F.scaled_dot_product_attention (vit_mae.py:202-203 via Block);
     GPT2Attention._attn (gpt2.py:61-84): scores / sqrt(d) + additive mask, softmax, dropout, @ v;
     PerceiverAttention (perceiver_resampler.py:53-60).  drop = (p, seed) applies our hash mask to the probabilities
-    with idx_hi = (b*H + h)*Lq + i, idx_lo = j."""
+    with idx_hi = (b*H + h)*Lq + i, idx_lo = drop_cols[j] (default j; with a compacted key axis the kernel hashes the
+    compact key index)."""
     B, H, Lq, d = q.shape
     Lk = k.shape[2]
     scale = d ** -0.5 if scale is None else scale
@@ -103,7 +104,7 @@ def attention(q, k, v, scale=None, mask=None, drop=None):
     if drop is not None and drop[0] > 0:
         pd, seed = drop
         rows = torch.arange(B * H * Lq, dtype=torch.int64).view(B, H, Lq, 1)
-        cols = torch.arange(Lk, dtype=torch.int64).view(1, 1, 1, Lk)
+        cols = (torch.arange(Lk, dtype=torch.int64) if drop_cols is None else drop_cols.to(torch.int64)).view(1, 1, 1, Lk)
         keep = drop_keep_mask(seed, rows, cols, pd)
         p = torch.where(keep, p / (1.0 - pd), torch.zeros_like(p))
     return torch.matmul(p, v)

@@ -75,21 +75,21 @@ def main():
     for (B, H, L, mk) in [(32, 16, 651, "dense"), (32, 16, 651, "trunk"), (448, 12, 197, "dense"), (448, 16, 265, "dense")]:
         qkv = torch.randn(B, L, 3 * H * 64, device=DEV, dtype=BF)
         v5 = qkv.view(B, L, 3, H, 64)
-        mask = tm = None
+        mt = None
         vis = 1.0
         if mk == "trunk":
-            mask = make_block_mask(L, 93, 36).to(DEV)
-            tm = ops.build_tile_map(mask)
+            mask = make_block_mask(L, 93, 36)
+            mt = ops.build_mask_tables(mask, device=DEV)
             vis = float((mask == 0).float().mean())
         fl = 4 * B * H * L * L * 64
-        f = lambda: ops.attn_fwd_raw(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], scale=0.125, mask=mask, tile_map=tm)
+        f = lambda: ops.attn_fwd_raw(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], scale=0.125, mask_tables=mt)
         rec(f"attn fwd B{B} H{H} L{L} {mk} (dense-equivalent flops, visible {vis:.2f})", timeit(f), fl)
         o, lse = f()
         do = torch.randn_like(o)
         dqkv = torch.empty_like(qkv)
         d5 = dqkv.view(B, L, 3, H, 64)
         g = lambda: ops.attn_bwd_raw(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], o, lse, do, d5[:, :, 0], d5[:, :, 1], d5[:, :, 2],
-                                     scale=0.125, mask=mask, tile_map=tm)
+                                     scale=0.125, mask_tables=mt)
         rec(f"attn bwd B{B} H{H} L{L} {mk}", timeit(g), 2.5 * fl)
         if mk == "dense":
             q, k, v = [t.permute(0, 2, 1, 3) for t in (v5[:, :, 0], v5[:, :, 1], v5[:, :, 2])]
