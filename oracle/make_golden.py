@@ -1,0 +1,209 @@
+"""ORACLE -- generates the golden fixtures under tests/golden/ by running the REAL reference modules
+(imported from /root/reference through oracle/ref_loader.py) on seeded inputs.  Build container only; the
+fixtures travel to the GPU box, the reference does not.
+
+    python -m oracle.make_golden            # (re)writes tests/golden/{masks,modules,dreamvla_A,dreamvla_B}.pt
+
+Module fixtures carry their (small) weights; the full-model fixtures use the deterministic weight recipe of
+oracle/weights.py (every tensor a function of its state_dict key), so only inputs-by-seed and outputs are stored.
+"""
+import os
+import sys
+import tempfile
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_loader, weights  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+BF = torch.bfloat16
+
+
+def _bf(sd):
+    return {k: (v.to(BF) if torch.is_floating_point(v) else v) for k, v in sd.items()}
+
+
+def _round_module_(m, g):
+    """seeded bf16-representable parameters for a small reference module"""
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if p.dim() >= 2:
+                std = (2.0 / (p.shape[0] + int(np.prod(p.shape[1:])))) ** 0.5     # xavier-normal, layout agnostic
+                p.copy_((torch.randn(p.shape, generator=g) * std).to(BF).float())
+            elif name.endswith("weight"):
+                p.copy_((1.0 + 0.1 * torch.randn(p.shape, generator=g)).to(BF).float())
+            else:
+                p.copy_((0.05 * torch.randn(p.shape, generator=g)).to(BF).float())
+
+
+def rnd(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(BF).float()
+
+
+def module_fixtures():
+    out = {}
+    g = torch.Generator().manual_seed(2024)
+    # --- timm Block (via the reference's own import of it) and the MAE encoder
+    vit = ref_loader.ref_module("models.vit_mae")
+    blk = vit.Block(128, 2, 4.0, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6)).eval()
+    _round_module_(blk, g)
+    x = rnd(g, 3, 37, 128)
+    out["timm_block"] = dict(sd=_bf(blk.state_dict()), x=x, y=blk(x).detach(), heads=2, eps=1e-6)
+    mae = vit.MaskedAutoencoderViT(img_size=64, patch_size=16, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64,
+                                   decoder_depth=1, decoder_num_heads=1, mlp_ratio=4,
+                                   norm_layer=partial(nn.LayerNorm, eps=1e-6)).eval()
+    _round_module_(mae, g)
+    mae.pos_embed.data = mae.pos_embed.data.to(BF).float()
+    imgs = rnd(g, 3, 3, 64, 64)
+    torch.manual_seed(0)
+    y, _, ids_restore = mae.forward_encoder(imgs, 0.0)
+    y = y.detach()
+    patches = torch.gather(y[:, 1:], 1, ids_restore.unsqueeze(-1).expand(-1, -1, y.shape[-1]))  # un-shuffle
+    out["vit_encoder"] = dict(sd=_bf(mae.state_dict()), imgs=imgs, y=torch.cat((y[:, :1], patches), 1), depth=2, heads=2)
+    # --- perceiver resampler
+    pr = ref_loader.ref_module("models.perceiver_resampler")
+    res = pr.PerceiverResampler(dim=128, depth=2, dim_head=64, heads=2, num_latents=5).eval()
+    _round_module_(res, g)
+    x = rnd(g, 4, 1, 1, 21, 128)
+    out["perceiver"] = dict(sd=_bf(res.state_dict()), x=x, y=res(x).detach(), depth=2, heads=2)
+    # --- GPT-2 trunk (eager and sdpa must agree; block mask)
+    g2 = ref_loader.ref_module("models.gpt2")
+    dv = ref_loader.ref_module("models.dreamvla_model")
+    for impl in ("eager", "sdpa"):
+        cfg = g2.GPT2Config()
+        cfg.hidden_size, cfg.n_layer, cfg.n_head, cfg.vocab_size, cfg.attn_implementation = 128, 2, 2, 1, impl
+        tr = g2.GPT2Model(cfg).eval()
+        gg = torch.Generator().manual_seed(77)
+        _round_module_(tr, gg)
+        mask = dv.generate_attention_mask(3, 6, 7, 0, False, False, False, 0.0, 4, 3)
+        x = rnd(gg, 2, mask.shape[0], 128)
+        m = mask if impl == "eager" else mask[None, None].expand(2, -1, -1, -1).contiguous()
+        out["gpt2_" + impl] = dict(sd=_bf(tr.state_dict()), x=x, mask=mask, y=tr(inputs_embeds=x, attention_mask=m).detach(),
+                                   layers=2, heads=2)
+    # --- DiT + diffusion
+    am = ref_loader.ref_module("models.action_model.action_model")
+    mdl = ref_loader.ref_module("models.action_model.models")
+    net = mdl.DiT(depth=2, hidden_size=128, num_heads=2, token_size=96, in_channels=7, future_action_window_size=2).eval()
+    _round_module_(net, g)
+    x, z = rnd(g, 6, 3, 7), rnd(g, 6, 3, 96)
+    t = torch.randint(0, 100, (6,), generator=g)
+    out["dit"] = dict(sd=_bf(net.state_dict()), x=x, t=t, z=z, y=net(x, t, z).detach(), depth=2, heads=2)
+    a = am.ActionModel(token_size=1024, model_type="DiT-B", in_channels=7, future_action_window_size=2, past_action_window_size=0)
+    out["diffusion"] = dict(sqrt_acp=torch.from_numpy(a.diffusion.sqrt_alphas_cumprod), betas=torch.from_numpy(a.diffusion.betas),
+                            ddim_map=torch.tensor(a.create_ddim(10).timestep_map),
+                            ddim_acp=torch.from_numpy(a.ddim_diffusion.alphas_cumprod))
+    # --- CLIP text tower (restated shim; small config)
+    clip = ref_loader.ref_module("clip")
+    ct = clip.CLIPText(embed_dim=64, context_length=16, vocab_size=100, width=128, heads=2, layers=2).eval()
+    _round_module_(ct, g)
+    tok = torch.randint(1, 90, (5, 16), generator=g)
+    tok[torch.arange(5), torch.randint(3, 16, (5,), generator=g)] = 99
+    out["clip_text"] = dict(sd=_bf(ct.state_dict()), tokens=tok, y=ct.encode_text(tok).detach(), layers=2, heads=2)
+    return out
+
+
+FULL_CFGS = {
+    "A": dict(finetune_type="calvin", sequence_length=2, num_resampler_query=16, num_obs_token_per_image=9,
+              action_pred_steps=3, transformer_layers=2, hidden_dim=1024, transformer_heads=16, phase="finetune",
+              obs_pred=True, depth_pred=True, sam_feat_pred=True, use_dit_head=False, attn_implementation="sdpa"),
+    "B": dict(finetune_type="calvin", sequence_length=2, num_resampler_query=16, num_obs_token_per_image=9,
+              action_pred_steps=3, transformer_layers=2, hidden_dim=1024, transformer_heads=16, phase="finetune",
+              obs_pred=True, use_dit_head=True, attn_implementation="sdpa"),
+}
+
+
+def fake_mae_ckpt():
+    vit = ref_loader.ref_module("models.vit_mae")
+    mae = vit.MaskedAutoencoderViT(patch_size=16, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512,
+                                   decoder_depth=8, decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    path = os.path.join(tempfile.gettempdir(), "dvla_fake_mae.pth")
+    torch.save({"model": mae.state_dict()}, path)
+    return path
+
+
+def build_reference_model(cfg):
+    dv = ref_loader.ref_module("models.dreamvla_model")
+    m = dv.DreamVLA(clip_device="cpu", vit_checkpoint_path=fake_mae_ckpt(), **cfg).float()
+    m.load_state_dict(weights.fill_state_dict(m.state_dict()), strict=True)
+    m.clip_model.requires_grad_(False)
+    m.vision_encoder.requires_grad_(False)
+    m._init_model_type()
+    return m.eval()
+
+
+def full_fixture(name):
+    cfg = FULL_CFGS[name]
+    m = build_reference_model(cfg)
+    B, S = 1, cfg["sequence_length"]
+    b = weights.synthetic_batch(B, S, window=S + 3, seed=4321)
+    # label actions exactly as utils/train_utils.py:145 builds them
+    label = torch.cat([b["actions"][:, j:S + j, :].unsqueeze(-2) for j in range(cfg["action_pred_steps"])], dim=-2)
+    for k in ("image_primary", "image_wrist", "state", "text_token"):
+        b[k] = b[k][:, :S]
+    fx = dict(cfg=cfg, B=B, S=S, window=S + 3, seed=4321, action_label=label)
+    torch.manual_seed(0)
+    real = {k: getattr(torch, k) for k in ("randn_like", "randint", "randn")}
+    if cfg["use_dit_head"]:
+        g = torch.Generator().manual_seed(99)
+        n_rep = 8 * B * S
+        noise = torch.randn(n_rep, 3, 7, generator=g).to(BF).float()
+        tstep = torch.randint(0, 100, (n_rep,), generator=g)
+        test_noise = torch.randn(B * S, 3, 7, generator=g).to(BF).float()
+        fx.update(dit_noise=noise, dit_timestep=tstep, test_noise=test_noise)
+        torch.randn_like = lambda x, **k: noise.clone()
+        torch.randint = lambda *a, **k: tstep.clone()
+    try:
+        with torch.no_grad():
+            out = m(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], action=None,
+                    action_label=label, mode="train")
+            fx["train"] = [None if o is None else o.detach().clone() for o in out]
+            if cfg["use_dit_head"]:
+                torch.randn_like, torch.randint = real["randn_like"], real["randint"]
+                torch.randn = lambda *a, **k: test_noise.clone()
+                out = m(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], mode="test")
+                fx["test"] = [None if o is None else o.detach().clone() for o in out]
+    finally:
+        for k, v in real.items():
+            setattr(torch, k, v)
+    # keep the fixture small: store big dream-head outputs as a strided sample + checksum
+    for key in ("train",):
+        outs = fx[key]
+        for i, o in enumerate(outs):
+            if o is not None and o.numel() > 20000:
+                flat = o.flatten()
+                idx = torch.linspace(0, flat.numel() - 1, 4096).long()
+                outs[i] = dict(shape=list(o.shape), idx=idx, vals=flat[idx].clone(), mean=float(flat.mean()),
+                               l2=float(flat.norm()))
+    return fx
+
+
+def main():
+    assert ref_loader.available(), "needs /root/reference"
+    os.makedirs(GOLD, exist_ok=True)
+    src = "generated by oracle/make_golden.py from the REAL reference modules under /root/reference"
+    # masks
+    from tests.test_mask import COMBOS
+    ref = ref_loader.ref_module("models.dreamvla_model").generate_attention_mask
+    packed = []
+    for kw in COMBOS:
+        np.random.seed(123)
+        packed.append(torch.from_numpy(np.packbits((ref(**kw) == 0).numpy())))
+    torch.save({"packed": packed, "source": src}, os.path.join(GOLD, "masks.pt"))
+    mf = module_fixtures()
+    mf["source"] = src
+    torch.save(mf, os.path.join(GOLD, "modules.pt"))
+    for name in FULL_CFGS:
+        fx = full_fixture(name)
+        fx["source"] = src
+        torch.save(fx, os.path.join(GOLD, f"dreamvla_{name}.pt"))
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,10 @@ class _RefImport:
                             if k == "models" or k.startswith("models.") or k == "utils" or k.startswith("utils.")}
         for k in self._saved_mods:
             del sys.modules[k]
+        # the reference's `models/` has no __init__.py (namespace package): a regular `models` package anywhere later
+        # on sys.path -- this repo's drop-in package -- would win, so hide the repo root while importing.
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path[:] = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != repo]
         sys.path[:0] = [_SHIMS, REF_ROOT]
         self._saved_dwb = sys.dont_write_bytecode
         sys.dont_write_bytecode = True  # never write __pycache__ into the read-only reference tree

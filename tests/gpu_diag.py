@@ -14,11 +14,17 @@ from tests import gpu_checks  # noqa: E402
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "diag.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else os.path.join(ROOT, "gpurun_out", "diag.json")
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     results, nfail = [], 0
     t0 = time.time()
-    for fn, kw in gpu_checks.all_checks():
+    from tests import model_checks
+    extra = []
+    if "--models" in sys.argv or "--only-models" in sys.argv:
+        extra = [(model_checks.hip_module_checks, {}), (model_checks.hip_full_model_checks, {"name": "A"}),
+                 (model_checks.hip_full_model_checks, {"name": "B"}), (model_checks.hip_grad_checks, {})]
+    base = [] if "--only-models" in sys.argv else gpu_checks.all_checks()
+    for fn, kw in base + extra:
         try:
             ms = fn(**kw)
             torch.cuda.synchronize()

@@ -1,0 +1,230 @@
+"""Shared helpers for model-level parity (oracle / golden / HIP)."""
+import os
+
+import torch
+
+from oracle import model_ref as M
+from oracle import torch_ref as R
+from oracle import weights
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BF = torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    if not torch.isfinite(a).all():
+        return float("inf")
+    return float((a - b).norm() / max(float(b.norm()), 1e-12))
+
+
+def load(name):
+    return torch.load(os.path.join(GOLD, name), map_location="cpu")
+
+
+def f32(sd):
+    return {k: (v.float() if torch.is_floating_point(v) else v) for k, v in sd.items()}
+
+
+def oracle_module_outputs(fx):
+    """oracle results for every entry of tests/golden/modules.pt -> {name: (got, want)}"""
+    out = {}
+    d = fx["timm_block"]; out["timm_block"] = (M.timm_block(f32(d["sd"]), "x", d["x"], d["heads"], d["eps"]) if False else
+                                                M.timm_block({"x." + k: v for k, v in f32(d["sd"]).items()}, "x", d["x"], d["heads"], d["eps"]), d["y"])
+    d = fx["vit_encoder"]; out["vit_encoder"] = (M.vit_encoder({"v." + k: v for k, v in f32(d["sd"]).items()}, "v", d["imgs"], d["depth"], d["heads"]), d["y"])
+    d = fx["perceiver"]; out["perceiver"] = (M.perceiver({"p." + k: v for k, v in f32(d["sd"]).items()}, "p", d["x"].flatten(0, 2), d["depth"], d["heads"]), d["y"].flatten(0, 1))
+    for impl in ("eager", "sdpa"):
+        d = fx["gpt2_" + impl]
+        out["gpt2_" + impl] = (M.gpt2({"t." + k: v for k, v in f32(d["sd"]).items()}, "t", d["x"], d["mask"], d["layers"], d["heads"]), d["y"])
+    d = fx["dit"]; out["dit"] = (M.dit({"n." + k: v for k, v in f32(d["sd"]).items()}, "n", d["x"], d["t"], d["z"], d["depth"], d["heads"]), d["y"])
+    d = fx["clip_text"]; out["clip_text"] = (M.clip_text({"c." + k: v for k, v in f32(d["sd"]).items()}, "c", d["tokens"], d["layers"], d["heads"]), d["y"])
+    return out
+
+
+def compare_outputs(got, want_list, tol, tag):
+    """got: 10-tuple of tensors/None; want_list: golden list (tensors, None or sampled dicts) -> list of metric dicts"""
+    names = ["arm_action", "gripper_action", "image_pred", "arm_state", "gripper_state", "loss_arm", "depth_pred",
+             "traj_pred", "dino_pred", "sam_pred"]
+    res = []
+    for nm, g, w in zip(names, got, want_list):
+        if w is None:
+            assert g is None, f"{tag}.{nm}: expected None"
+            continue
+        assert g is not None, f"{tag}.{nm}: missing output"
+        if isinstance(w, dict):
+            assert list(g.shape) == w["shape"], f"{tag}.{nm}: shape {list(g.shape)} vs {w['shape']}"
+            gv = g.detach().float().cpu().flatten()[w["idx"]]
+            r = rel_l2(gv, w["vals"])
+        else:
+            assert tuple(g.shape) == tuple(w.shape), f"{tag}.{nm}: shape {tuple(g.shape)} vs {tuple(w.shape)}"
+            r = rel_l2(g, w)
+        res.append({"name": f"{tag}.{nm}", "rel_l2": r, "tol": tol, "ok": r <= tol})
+    return res
+
+
+def golden_inputs(fx):
+    b = weights.synthetic_batch(fx["B"], fx["S"], window=fx["window"], seed=fx["seed"])
+    S = fx["S"]
+    return {k: b[k][:, :S] for k in ("image_primary", "image_wrist", "state", "text_token")}
+
+
+def build_hip_model(cfg, device="cuda", dtype=BF):
+    from dreamvla_amd.dreamvla_model import DreamVLA
+    m = DreamVLA(clip_device="cpu", vit_checkpoint_path=None, **cfg)
+    m.load_state_dict(weights.fill_state_dict(m.state_dict()), strict=True)
+    m.clip_model.requires_grad_(False)
+    m.vision_encoder.requires_grad_(False)
+    return m
+
+
+def smoke_checks():
+    """one tiny end-to-end forward + backward of the DreamVLA module on cuda:0 against the golden fixture."""
+    fx = load("dreamvla_A.pt")
+    m = build_hip_model(fx["cfg"]).to(BF).to("cuda")
+    m._init_model_type()
+    m.eval()
+    inp = {k: v.to("cuda") for k, v in golden_inputs(fx).items()}
+    out = m(inp["image_primary"].to(BF), inp["image_wrist"].to(BF), inp["state"].to(BF), inp["text_token"],
+            action_label=fx["action_label"].to("cuda", BF), mode="train")
+    res = compare_outputs(out, fx["train"], 3e-2, "smoke.A")
+    loss = sum(o.float().pow(2).mean() for o in out if o is not None)
+    loss.backward()
+    gn = sum(float(p.grad.float().norm()) for p in m.parameters() if p.grad is not None)
+    res.append({"name": "smoke.A.backward finite grad norm", "rel_l2": 0.0, "tol": 0.0, "ok": gn == gn and gn > 0})
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------
+# HIP modules vs golden module fixtures (GPU)
+# ---------------------------------------------------------------------------------------------------
+TOL_MODULE = 1e-2   # 2-layer bf16 pipelines vs the fp32 reference: every op boundary rounds to bf16
+TOL_MODEL = 3e-2    # whole model (ViT-B 12 layers + resampler + trunk + heads) in bf16 vs fp32 reference
+
+
+def _dev(sd):
+    return {k: (v.to("cuda", BF) if torch.is_floating_point(v) else v.to("cuda")) for k, v in sd.items()}
+
+
+def hip_module_checks():
+    from functools import partial
+    import dreamvla_amd.nn as dnn
+    from dreamvla_amd.action_model.models import DiT
+    from dreamvla_amd.clip_text import CLIPTextEncoder
+    from dreamvla_amd.gpt2 import GPT2Config, GPT2Model
+    from dreamvla_amd.perceiver_resampler import PerceiverResampler
+    from dreamvla_amd.vit_mae import MaskedAutoencoderViT
+    fx = load("modules.pt")
+    res = []
+
+    def add(name, got, want, tol=TOL_MODULE):
+        r = rel_l2(got, want)
+        res.append({"name": "hip." + name, "rel_l2": r, "tol": tol, "ok": r <= tol})
+
+    with torch.no_grad():
+        d = fx["timm_block"]
+        blk = dnn.Block(128, 2, 4.0, qkv_bias=True, norm_layer=lambda n: dnn.LayerNorm(n, eps=1e-6))
+        blk.load_state_dict(d["sd"], strict=True); blk = blk.to("cuda", BF).eval()
+        add("timm_block", blk(d["x"].to("cuda", BF)), d["y"])
+        d = fx["vit_encoder"]
+        mae = MaskedAutoencoderViT(img_size=64, patch_size=16, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=64,
+                                   decoder_depth=1, decoder_num_heads=1, mlp_ratio=4, norm_layer=lambda n: dnn.LayerNorm(n, eps=1e-6))
+        mae.load_state_dict(d["sd"], strict=True); mae = mae.to("cuda", BF).eval()
+        add("vit_encoder", mae.forward_encoder(d["imgs"].to("cuda", BF), 0.0)[0], d["y"])
+        d = fx["perceiver"]
+        pr = PerceiverResampler(dim=128, depth=2, dim_head=64, heads=2, num_latents=5)
+        pr.load_state_dict(d["sd"], strict=True); pr = pr.to("cuda", BF).eval()
+        add("perceiver", pr(d["x"].to("cuda", BF)), d["y"])
+        d = fx["gpt2_sdpa"]
+        cfg = GPT2Config(hidden_size=128, n_layer=2, n_head=2, vocab_size=1)
+        tr = GPT2Model(cfg)
+        tr.load_state_dict(d["sd"], strict=True); tr = tr.to("cuda", BF).eval()
+        add("gpt2", tr(inputs_embeds=d["x"].to("cuda", BF), attention_mask=d["mask"].to("cuda")), d["y"])
+        m4 = d["mask"][None, None].expand(2, -1, -1, -1).contiguous().to("cuda")
+        add("gpt2 (B,1,L,L) mask", tr(inputs_embeds=d["x"].to("cuda", BF), attention_mask=m4), d["y"])
+        d = fx["dit"]
+        net = DiT(depth=2, hidden_size=128, num_heads=2, token_size=96, in_channels=7, future_action_window_size=2)
+        net.load_state_dict(d["sd"], strict=True); net = net.to("cuda", BF).eval()
+        add("dit", net(d["x"].to("cuda", BF), d["t"].to("cuda"), d["z"].to("cuda", BF)), d["y"])
+        d = fx["clip_text"]
+        ct = CLIPTextEncoder(embed_dim=64, context_length=16, vocab_size=100, width=128, heads=2, layers=2)
+        ct.load_state_dict(d["sd"], strict=False); ct = ct.to("cuda", BF).eval()
+        add("clip_text", ct.encode_text(d["tokens"].to("cuda")), d["y"])
+    return res
+
+
+def hip_full_model_checks(name):
+    fx = load(f"dreamvla_{name}.pt")
+    m = build_hip_model(fx["cfg"]).to(BF).to("cuda")
+    m._init_model_type()
+    m.eval()
+    inp = {k: v.to("cuda") for k, v in golden_inputs(fx).items()}
+    args = (inp["image_primary"].to(BF), inp["image_wrist"].to(BF), inp["state"].to(BF), inp["text_token"])
+    res = []
+    with torch.no_grad():
+        if fx["cfg"]["use_dit_head"]:
+            m.action_model._injected = (fx["dit_noise"].to("cuda", BF), fx["dit_timestep"].to("cuda"))
+        out = m(*args, action_label=fx["action_label"].to("cuda", BF), mode="train")
+        res += compare_outputs(out, fx["train"], TOL_MODEL, f"hip.{name}.train")
+        if fx["cfg"]["use_dit_head"]:
+            want, got = float(fx["train"][0]), float(out[0])
+            res.append({"name": f"hip.{name}.train.action_mse_abs_err", "rel_l2": abs(got - want), "tol": 1e-3,
+                        "ok": abs(got - want) <= 1e-3, "want": want, "got": got})
+            m.action_model._injected = None
+            real = torch.randn
+            tn = fx["test_noise"].to("cuda")
+            torch.randn = lambda *a, **k: tn.clone()
+            try:
+                out = m(*args, mode="test")
+            finally:
+                torch.randn = real
+            res += compare_outputs(out, fx["test"], TOL_MODEL, f"hip.{name}.test")
+    return res
+
+
+def hip_grad_checks():
+    """whole-model backward on config A (dream heads + MLP action head) vs oracle autograd in fp32: per-parameter
+    gradient cosine similarity for the trainable tensors that receive gradient."""
+    fx = load("dreamvla_A.pt")
+    cfg = fx["cfg"]
+    m = build_hip_model(cfg)
+    sd32 = f32(m.state_dict())
+    m = m.to(BF).to("cuda")
+    m._init_model_type()
+    m.eval()
+    inp = golden_inputs(fx)
+    g = torch.Generator().manual_seed(5)
+    # oracle: trainable leaves = everything except clip / vision encoder / tables
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd32.items()
+              if torch.is_floating_point(v) and not k.startswith(("clip_model.", "vision_encoder.")) and k != "attention_mask"
+              and "decoder_position_embedding" not in k}
+    sdr = dict(sd32); sdr.update(leaves)
+    out_r = M.dreamvla_forward(sdr, cfg, inp["image_primary"], inp["image_wrist"], inp["state"], inp["text_token"],
+                               action_label=fx["action_label"], mode="train")
+    ws = [torch.randn(o.shape, generator=g).to(BF).float() if o is not None else None for o in out_r]
+    loss_r = sum((o * w).sum() for o, w in zip(out_r, ws) if o is not None)
+    loss_r.backward()
+    out = m(inp["image_primary"].to("cuda", BF), inp["image_wrist"].to("cuda", BF), inp["state"].to("cuda", BF),
+            inp["text_token"].to("cuda"), action_label=fx["action_label"].to("cuda", BF), mode="train")
+    loss = sum((o.float() * w.to("cuda")).sum() for o, w in zip(out, ws) if o is not None)
+    loss.backward()
+    res = []
+    params = dict(m.named_parameters())
+    worst = (1.0, "")
+    n_checked = 0
+    for k, leaf in leaves.items():
+        if leaf.grad is None or float(leaf.grad.norm()) == 0.0:
+            continue
+        p = params.get(k)
+        if p is None or p.grad is None:
+            res.append({"name": f"grad.{k}", "rel_l2": 1.0, "tol": 0.0, "ok": False, "error": "no gradient on the HIP side"})
+            continue
+        a, b = p.grad.detach().float().cpu().flatten(), leaf.grad.flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        n_checked += 1
+        if cos < worst[0]:
+            worst = (cos, k)
+        if cos < 0.98:
+            res.append({"name": f"grad.{k}", "rel_l2": 1 - cos, "tol": 0.02, "ok": False})
+    res.append({"name": f"grad cosine over {n_checked} parameter tensors (worst {worst[1]})", "rel_l2": 1 - worst[0], "tol": 0.02,
+                "ok": worst[0] >= 0.98 and n_checked > 50})
+    return res
