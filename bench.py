@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""bench.py -- DreamVLA training-step throughput on MI355X (the metric of BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank / GPU)
+
+One "step" = one full optimizer step of the hot path on one synthetic batch that is already resident in HBM:
+DreamVLA.forward (frozen CLIP text tower + frozen ViT-B/16 on 2 views, resampler, 24-layer trunk with dropout, dream
+heads, DiT diffusion head) -> reference loss block -> backward -> gradient all-reduce (N > 1) -> clip_grad_norm_(0.1)
+-> AdamW, in bf16 (`--precision bf16` semantics of train.py:122-123).  Workload = BASELINE.json configs[1]
+(B = 32 per GPU, S = 7, 2 x 224^2 views, 77 text tokens) with the head set of the shipped CALVIN finetune script
+(obs + depth + sam dream heads, DiT head; L = 651).  rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     : the dominant kernel (gemm_kernel, bf16 MFMA).  achieved = algorithmic FLOPs of every GEMM launch of one
+                 instrumented step / summed launch durations (HIP events on the launch stream), peak = 2500 TFLOP/s dense.
+  cpu_baseline : the oracle (oracle/model_ref.py, "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HEAD_SETS = {
+    "A": dict(obs_pred=True, use_dit_head=False),
+    "B": dict(obs_pred=True, use_dit_head=True),
+    "C": dict(obs_pred=True, depth_pred=True, sam_feat_pred=True, use_dit_head=True),      # CALVIN finetune.sh
+    "D": dict(obs_pred=True, sam_feat_pred=True, use_dit_head=True),                      # LIBERO finetune_*.sh
+    "E": dict(obs_pred=True, dino_feat_pred=True, sam_feat_pred=True, trajectory_pred=True, use_dit_head=True),
+}
+# algorithmic training GFLOP per sample (SURVEY.md section 8d / BASELINE.md section 4; mask-aware trunk attention)
+TRAIN_GFLOP_PER_SAMPLE = {"A": 1802.0, "B": 1974.0, "C": 3485.0, "D": 2798.0, "E": 4317.0}
+BF16_PEAK_TFLOPS = 2500.0
+
+
+def model_cfg(heads, S, layers=24):
+    cfg = dict(finetune_type="calvin", sequence_length=S, num_resampler_query=16, num_obs_token_per_image=9,
+               action_pred_steps=3, transformer_layers=layers, hidden_dim=1024, transformer_heads=16, phase="finetune",
+               attn_implementation="sdpa")
+    cfg.update(HEAD_SETS[heads])
+    return cfg
+
+
+def label_heads(heads):
+    h = HEAD_SETS[heads]
+    return tuple(k for k, f in (("depth", "depth_pred"), ("dino", "dino_feat_pred"), ("sam", "sam_feat_pred"),
+                                ("traj", "trajectory_pred")) if h.get(f))
+
+
+def cpu_baseline(heads, S):
+    """Oracle forward + loss + backward on the host cores, B = 1 (bounded: ~10-30 s)."""
+    from oracle import model_ref as M
+    from oracle import weights
+    from dreamvla_amd.dreamvla_model import DreamVLA
+    from dreamvla_amd import losses
+    torch.set_num_threads(os.cpu_count())
+    cfg = model_cfg(heads, S)
+    m = DreamVLA(clip_device="cpu", vit_checkpoint_path=None, **cfg)
+    sd = {k: (v.float() if torch.is_floating_point(v) else v) for k, v in m.state_dict().items()}
+    del m
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items()
+              if torch.is_floating_point(v) and not k.startswith(("clip_model.", "vision_encoder.")) and k != "attention_mask"
+              and "decoder_position_embedding" not in k}
+    B = 1
+    b = weights.synthetic_batch(B, S, window=S + 3, seed=7, heads=label_heads(heads))
+    b["actions"][..., 6:] = (b["actions"][..., 6:] > 0.5).float()
+    lab = losses.label_actions(b["actions"], S, 3)
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(8 * B * S, 3, 7, generator=g)
+    tstep = torch.randint(0, 100, (8 * B * S,), generator=g)
+    t0 = time.time()
+    out = M.dreamvla_forward(sd, cfg, b["image_primary"][:, :S], b["image_wrist"][:, :S], b["state"][:, :S],
+                             b["text_token"][:, :S], action_label=lab, mode="train", dit_noise=noise, dit_timestep=tstep)
+    t_fwd = time.time() - t0
+    total, _ = losses.calvin_losses(out, b, sequence_length=S, use_dit_head=cfg["use_dit_head"], label_action=lab)
+    total.backward()
+    dt = time.time() - t0
+    return {"value": B / dt, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 un-warmed step of oracle/model_ref.py forward+loss+backward, fp32, B={B}, S={S}, head set {heads}, "
+                      f"full 1024/24/16 model, {os.cpu_count()} threads; fwd {t_fwd:.1f}s of {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--seq", type=int, default=7)
+    ap.add_argument("--heads", default="C", choices=sorted(HEAD_SETS))
+    ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--torch-ddp", action="store_true", help="use torch DDP instead of dreamvla_amd.ddp.GradBucketReducer")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dreamvla_amd import losses, ops
+    from dreamvla_amd.ddp import GradBucketReducer
+    from dreamvla_amd.dreamvla_model import DreamVLA
+    from dreamvla_amd.synthetic import synthetic_batch
+
+    torch.manual_seed(1234 + rank)
+    ops.set_seed_salt(rank)
+    BF = torch.bfloat16
+    S, B = args.seq, args.batch
+    cfg = model_cfg(args.heads, S, args.layers)
+    model = DreamVLA(clip_device="cpu", vit_checkpoint_path=None, **cfg).bfloat16()
+    model.clip_model.requires_grad_(False)
+    model.vision_encoder.requires_grad_(False)
+    model = model.to(dev)
+    model._init_model_type()
+    model.train()
+    if world > 1:  # identical initial weights on every rank (DDP's constructor broadcast)
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    n_train = sum(p.numel() for p in params)
+    reducer = None
+    ddp_model = model
+    if args.torch_ddp and world > 1:
+        ddp_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True,
+                                                              gradient_as_bucket_view=True)
+    else:
+        reducer = GradBucketReducer(params)
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4, fused=True)   # finetune.sh:23,26
+
+    b = synthetic_batch(B, S, window=S + 3, seed=1234 + rank, heads=label_heads(args.heads))
+    b["actions"][..., 6:] = (b["actions"][..., 6:] > 0.5).float()
+    batch = {k: (v.to(dev, BF) if torch.is_floating_point(v) else v.to(dev)) for k, v in b.items()}
+    lab = losses.label_actions(batch["actions"], S, 3)
+    inputs = (batch["image_primary"][:, :S].contiguous(), batch["image_wrist"][:, :S].contiguous(),
+              batch["state"][:, :S].contiguous(), batch["text_token"][:, :S].contiguous())
+
+    def forward_loss():
+        out = ddp_model(*inputs, action=batch["actions"][:, :S], action_label=lab, mode="train")
+        total, _ = losses.calvin_losses(out, batch, sequence_length=S, use_dit_head=cfg["use_dit_head"], label_action=lab)
+        return total
+
+    def step():
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=False)
+        total = forward_loss()
+        total.backward()
+        if reducer is not None:
+            reducer.finish()
+        torch.nn.utils.clip_grad_norm_(params, 0.1)
+        opt.step()
+        return total
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    loss_val = float(last)
+
+    # forward-only latency (train mode, autograd graph recorded, no backward)
+    fwd_ms = None
+    if rank == 0 or world > 1:
+        for _ in range(1):
+            forward_loss()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            forward_loss()
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t1) / 3 * 1e3
+
+    roofline = None
+    if not args.no_roofline:
+        prof = ops.GemmProfiler()
+        with prof:
+            step()
+        torch.cuda.synchronize()
+        r = prof.summary()
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA 32x32x16, all launches of one training step)",
+                    "achieved": r["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["tflops"] / BF16_PEAK_TFLOPS,
+                    "traffic": None, "launches": r["launches"], "avg_launch_us": r["avg_us"],
+                    "gflop_per_launch": r["gflop_per_launch"], "gemm_ms_per_step": r["total_ms"],
+                    "whole_step_frac_of_bf16_peak": TRAIN_GFLOP_PER_SAMPLE[args.heads] * (B * 1e3 / ms_per_step) / 1e3 / BF16_PEAK_TFLOPS}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args.heads, S)
+        except Exception as e:  # noqa: BLE001
+            cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+
+    if rank == 0:
+        line = {
+            "metric": "train samples/sec (CALVIN ABC->D, seq_len=7)", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "fwd_ms_per_step": fwd_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"DreamVLA CALVIN finetune step, head set {args.heads} "
+                                   f"({'+'.join(k for k in HEAD_SETS[args.heads] if HEAD_SETS[args.heads][k])}), "
+                                   f"B={B}/GPU, S={S}, window {S + 3}, 2x224^2 views, 77 text tokens, hidden 1024 / "
+                                   f"{args.layers} layers / 16 heads, dropout 0.1 on, AdamW + clip 0.1",
+                       "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
+                       "trainable_params_M": n_train / 1e6, "loss": loss_val,
+                       "grad_exchange": "torch DDP" if reducer is None else "GradBucketReducer (flat bf16 buckets, async all-reduce)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""Training-loss block of the reference train loop (utils/train_utils.py:98-588, utils/sigloss.py), restated as a
+function so bench.py / a trainer can run forward + loss + backward without the reference's dataloader plumbing.
+
+Round-1 status: these reductions are the CALLER's code in the reference (plain ATen ops on the outputs of
+`DreamVLA.forward`) and are still plain torch tensor ops here (HBM-bound, ~1 % of step time; SURVEY.md section 8f
+item 1 ranks fusing them as the first follow-up).  They run on whatever device the predictions live on.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def patchify(imgs, patch_size):
+    """(N,3,H,W) -> (N, L, p*p*3)  'nchpwq->nhwpqc'   (train_utils.py:37-50)"""
+    h = w = imgs.shape[2] // patch_size
+    x = imgs.reshape(imgs.shape[0], 3, h, patch_size, w, patch_size)
+    x = torch.einsum('nchpwq->nhwpqc', x)
+    return x.reshape(imgs.shape[0], h * w, patch_size ** 2 * 3)
+
+
+def normalize_patchfied_image(p):
+    """per-patch (x - mean) / sqrt(var_unbiased + 1e-6)   (train_utils.py:52-57)"""
+    mean = p.mean(dim=-1, keepdim=True)
+    var = p.var(dim=-1, keepdim=True)
+    return (p - mean) / (var + 1.e-6) ** .5
+
+
+def unpatchify(patches, patch_size=16, img_size=(224, 224)):
+    """(B, P, 196, ps*ps*C) -> (B, P, C, H, W)   (train_utils.py:783-799)"""
+    B, P, num_patches, patch_dim = patches.shape
+    H, W = img_size
+    gs = int(num_patches ** 0.5)
+    C = patch_dim // (patch_size * patch_size)
+    patches = patches.view(B, P, gs, gs, patch_size, patch_size, C)
+    return patches.permute(0, 1, 6, 2, 4, 3, 5).contiguous().view(B, P, C, H, W)
+
+
+def silog_loss(pred, target, lambd=0.5):
+    """utils/sigloss.py:11-15"""
+    d = torch.log(target + 1e-6) - torch.log(pred + 1e-6)
+    return torch.sqrt(torch.pow(d, 2).mean() - lambd * torch.pow(d.mean(), 2))
+
+
+def label_actions(actions, sequence_length, action_pred_steps, atten_goal=0):
+    """train_utils.py:138,145: gripper {-1,1} -> {0,1} is done by the caller; windows of future actions."""
+    return torch.cat([actions[:, j:sequence_length - atten_goal + j, :].unsqueeze(-2) for j in range(action_pred_steps)], dim=-2)
+
+
+def calvin_losses(outputs, batch, *, sequence_length, future_steps=3, atten_goal=0, pred_num=1, patch_size=16,
+                  use_dit_head=True, loss_arm_action_ratio=1.0, loss_gripper_action_ratio=0.01, label_action=None,
+                  compute_dtype=torch.float32):
+    """outputs: the 10-tuple of DreamVLA.forward(mode='train'); batch: dict with window-length tensors
+    (image_primary/image_wrist (B,W,3,224,224), optional depth_*/dino_*/sam_*/tracks*).  Returns (total, parts).
+    The reference computes these in the model dtype; `compute_dtype=float32` (default) evaluates the reductions in
+    fp32, which is at least as accurate."""
+    (arm, grip, image_pred, _, _, _, depth_pred, traj_pred, dino_pred, sam_pred) = outputs
+    S, T = sequence_length, sequence_length - atten_goal
+    lo, hi = future_steps, future_steps + T + pred_num - 1
+    bs = batch["image_primary"].shape[0]
+    dev = batch["image_primary"].device
+    zero = torch.zeros((), device=dev, dtype=compute_dtype)
+    parts = {}
+    if use_dit_head:
+        parts["arm_action"], parts["gripper_action"] = arm.to(compute_dtype), zero
+    else:
+        parts["arm_action"] = F.smooth_l1_loss(arm[:, :T].to(compute_dtype), label_action[:, :T, :, :6].to(compute_dtype))
+        parts["gripper_action"] = F.binary_cross_entropy(grip[:, :T].to(compute_dtype), label_action[:, :T, :, 6:].to(compute_dtype))
+    parts["image"] = zero
+    if image_pred is not None:
+        def lab(key):
+            x = batch[key][:, lo:hi].flatten(0, 1).to(compute_dtype)
+            x = normalize_patchfied_image(patchify(x, patch_size))
+            x = x.view(bs, T + pred_num - 1, *x.shape[1:])
+            return x.unfold(1, pred_num, 1).permute(0, 1, 4, 2, 3).flatten(0, 1)
+        ip = image_pred.reshape(bs, S, *image_pred.shape[1:])[:, :T].reshape(-1, *image_pred.shape[1:]).to(compute_dtype)
+        parts["image"] = 0.5 * (F.mse_loss(ip[:, 0], lab("image_primary")) + F.mse_loss(ip[:, 1], lab("image_wrist")))
+    parts["depth"] = zero
+    if depth_pred is not None:
+        def dlab(key):
+            return batch[key][:, lo:hi].to(compute_dtype).unfold(1, pred_num, 1).permute(0, 1, 5, 2, 3, 4).flatten(0, 1)
+        dp = depth_pred.reshape(bs, S, *depth_pred.shape[1:])[:, :T].reshape(-1, *depth_pred.shape[1:]).to(compute_dtype)
+        dx, dg = unpatchify(dp[:, 0], patch_size), unpatchify(dp[:, 1], patch_size)
+        parts["depth"] = 0.5 * (silog_loss(dx, dlab("depth_primary")) + silog_loss(dg, dlab("depth_wrist")))
+
+    def cos_loss(pred, key_p, key_w):
+        pp = pred.reshape(bs, S, *pred.shape[1:])[:, :T].reshape(-1, *pred.shape[1:]).to(compute_dtype)
+        lp = batch[key_p][:, lo:hi].reshape(-1, *batch[key_p].shape[2:]).to(compute_dtype)
+        lw = batch[key_w][:, lo:hi].reshape(-1, *batch[key_w].shape[2:]).to(compute_dtype)
+        return 0.5 * ((1 - F.cosine_similarity(pp[:, 0, 0], lp, dim=-1)).mean()
+                      + (1 - F.cosine_similarity(pp[:, 1, 0], lw, dim=-1)).mean())
+    parts["dino"] = cos_loss(dino_pred, "dino_primary", "dino_wrist") if dino_pred is not None else zero
+    parts["sam"] = cos_loss(sam_pred, "sam_primary", "sam_wrist") if sam_pred is not None else zero
+    parts["trajectory"] = zero
+    if traj_pred is not None:
+        def tlab(key):
+            t = batch[key][:, 0:T + pred_num - 1].to(compute_dtype)
+            h = w = int(math.sqrt(t.shape[-2]))
+            t = t.view(bs, t.shape[1], h, w, t.shape[-1]).permute(0, 1, 4, 2, 3)           # b p c h w
+            t = F.pixel_unshuffle(t, downscale_factor=h // 14)
+            t = t.flatten(3).permute(0, 1, 3, 2)                                           # b p (h w) c
+            return t.unfold(1, pred_num, 1).permute(0, 1, 4, 2, 3).flatten(0, 1)
+        tp = traj_pred.reshape(bs, S, *traj_pred.shape[1:])[:, :T].reshape(-1, *traj_pred.shape[1:]).to(compute_dtype)
+        parts["trajectory"] = 0.1 * (F.mse_loss(tp[:, 0], tlab("tracks")) + F.mse_loss(tp[:, 1], tlab("tracks_gripper")))
+    total = (loss_arm_action_ratio * parts["arm_action"] + loss_gripper_action_ratio * parts["gripper_action"]
+             + 0.1 * parts["image"] + 0.001 * parts["depth"] + 0.1 * parts["trajectory"] + 0.01 * parts["dino"]
+             + 0.01 * parts["sam"])                                                          # train_utils.py:585
+    return total, parts

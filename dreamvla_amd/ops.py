@@ -89,6 +89,31 @@ def auto_split_k(M, N, K):
     return max(1, s)
 
 
+class GemmProfiler:
+    """Brackets every GEMM launch with HIP events on the launch stream (torch's current stream) and accumulates the
+    algorithmic FLOPs (2*M*N*K) -- bench.py's roofline leg.  Not active unless used as a context manager."""
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        GemmProfiler.active = self
+        return self
+
+    def __exit__(self, *exc):
+        GemmProfiler.active = None
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        total_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        flops = sum(f for _, _, f in self.records)
+        n = max(len(self.records), 1)
+        return {"launches": len(self.records), "total_ms": total_ms, "avg_us": total_ms * 1e3 / n,
+                "gflop_per_launch": flops / n / 1e9, "tflops": (flops / (total_ms * 1e-3) / 1e12) if total_ms > 0 else 0.0}
+
+
 def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=False, dact_aux=None, dact=0,
          dropout_p=0.0, seed=(0, 0), residual=None, res_rows=0, out_dtype=BF16, out=None, accumulate=False, split_k=1):
     """C[M,N] = epilogue(A . B^T); see include/dvla.h.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
@@ -147,7 +172,14 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
         p.split_k, p.workspace = int(split_k), ws.data_ptr()
     else:
         p.split_k = 1
+    prof = GemmProfiler.active
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.dvla_gemm_bf16(C.byref(p), _stream()), "dvla_gemm_bf16")
+    if prof is not None:
+        e1.record()
+        prof.records.append((e0, e1, 2.0 * M * N * K))
     return (out, preact) if want_preact else out
 
 

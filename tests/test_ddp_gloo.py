@@ -1,0 +1,86 @@
+"""CPU, world_size 2, gloo: the gradient-bucket reducer used for data-parallel training (dreamvla_amd/ddp.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(16, 32)
+        self.b = nn.Linear(32, 8)
+        self.unused = nn.Linear(4, 4)          # constructed but never used (like the reference's action_projector)
+        self.tok = nn.Parameter(torch.zeros(1, 8))
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x))) + self.tok
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dreamvla_amd.ddp import GradBucketReducer
+    torch.manual_seed(0)
+    m = Tiny()
+    red = GradBucketReducer(m.parameters(), bucket_bytes=1500)      # force several buckets
+    assert len(red.buckets) >= 3 and red.grads_are_views()
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    out = {}
+    for it in range(2):                                              # two steps: buffers must re-arm correctly
+        red.zero_grad()
+        loss = ((m(xs) - ys) ** 2).mean()
+        loss.backward()
+        red.finish()
+        assert red.grads_are_views()
+        out[it] = {n: p.grad.clone() for n, p in m.named_parameters()}
+        with torch.no_grad():
+            for p in m.parameters():
+                p -= 0.1 * p.grad
+    if rank == 0:
+        q.put({it: {k: v.numpy() for k, v in d.items()} for it, d in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucket_reducer_matches_full_batch_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the full batch (mean over 8 samples == average of the two ranks' means over 4)
+    torch.manual_seed(0)
+    m = Tiny()
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    for it in range(2):
+        m.zero_grad()
+        ((m(X) - Y) ** 2).mean().backward()
+        for n, p in m.named_parameters():
+            want = torch.zeros_like(p) if p.grad is None else p.grad
+            assert torch.allclose(torch.from_numpy(got[it][n]), want, atol=1e-6), (it, n)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.grad is not None:
+                    p -= 0.1 * p.grad
