@@ -58,7 +58,8 @@ def cpu_baseline(heads, S):
     from oracle import weights
     from dreamvla_amd.dreamvla_model import DreamVLA
     from dreamvla_amd import losses
-    torch.set_num_threads(os.cpu_count())
+    nthreads = min(os.cpu_count(), 16)   # oversubscribing a 256-thread host made this leg take 8 minutes
+    torch.set_num_threads(nthreads)
     cfg = model_cfg(heads, S)
     m = DreamVLA(clip_device="cpu", vit_checkpoint_path=None, **cfg)
     sd = {k: (v.float() if torch.is_floating_point(v) else v) for k, v in m.state_dict().items()}
@@ -80,9 +81,9 @@ def cpu_baseline(heads, S):
     total, _ = losses.calvin_losses(out, b, sequence_length=S, use_dit_head=cfg["use_dit_head"], label_action=lab)
     total.backward()
     dt = time.time() - t0
-    return {"value": B / dt, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": B / dt, "unit": "samples/s", "cores": nthreads, "kind": "port",
             "sample": f"1 un-warmed step of oracle/model_ref.py forward+loss+backward, fp32, B={B}, S={S}, head set {heads}, "
-                      f"full 1024/24/16 model, {os.cpu_count()} threads; fwd {t_fwd:.1f}s of {dt:.1f}s"}
+                      f"full 1024/24/16 model, {nthreads} threads of {os.cpu_count()}; fwd {t_fwd:.1f}s of {dt:.1f}s"}
 
 
 def main():
@@ -187,7 +188,7 @@ def main():
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
-    loss_val = float(last)
+    loss_val = float(last.detach())
 
     # forward-only latency (train mode, autograd graph recorded, no backward)
     fwd_ms = None
@@ -208,6 +209,9 @@ def main():
             step()
         torch.cuda.synchronize()
         r = prof.summary()
+        if os.environ.get("DVLA_GEMM_BREAKDOWN"):
+            with open(os.environ["DVLA_GEMM_BREAKDOWN"], "w") as f:
+                json.dump(prof.breakdown(), f, indent=1)
         roofline = {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA 32x32x16, all launches of one training step)",
                     "achieved": r["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["tflops"] / BF16_PEAK_TFLOPS,
                     "traffic": None, "launches": r["launches"], "avg_launch_us": r["avg_us"],

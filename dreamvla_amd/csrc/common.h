@@ -34,18 +34,38 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
 
+// ---- fast transcendental helpers (epilogue-resident: they must cost a handful of VALU ops, not a libm call) ----
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }            // v_rcp_f32 (1 ulp)
+__device__ __forceinline__ float fast_exp(float x) { return fast_exp2(x * 1.4426950408889634f); }  // e^x
+// erf by Abramowitz-Stegun 7.1.26: |error| <= 1.5e-7 (three orders below bf16 resolution)
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = fast_rcp(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float r = 1.0f - poly * t * fast_exp(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = fast_exp(-2.0f * fabsf(x));
+  return copysignf((1.0f - e) * fast_rcp(1.0f + e), x);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+
 __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {
-    case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    case ACT_GELU_ERF: return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
     case ACT_GELU_TANH: {
-      float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-      return 0.5f * x * (1.0f + tanhf(u));
+      const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      return 0.5f * x * (1.0f + fast_tanh(u));
     }
     case ACT_RELU: return x > 0.f ? x : 0.f;
-    case ACT_SILU: return x / (1.0f + __expf(-x));
-    case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
-    case ACT_TANH: return tanhf(x);
-    case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+    case ACT_SILU: return x * fast_sigmoid(x);
+    case ACT_QUICK_GELU: return x * fast_sigmoid(1.702f * x);
+    case ACT_TANH: return fast_tanh(x);
+    case ACT_SIGMOID: return fast_sigmoid(x);
     default: return x;
   }
 }
@@ -54,28 +74,28 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
 __device__ __forceinline__ float act_bwd(float x, int act) {
   switch (act) {
     case ACT_GELU_ERF: {
-      float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-      float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+      const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
+      const float pdf = 0.3989422804014327f * fast_exp(-0.5f * x * x);
       return cdf + x * pdf;
     }
     case ACT_GELU_TANH: {
-      float x2 = x * x;
-      float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
-      float t = tanhf(u);
-      float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
+      const float x2 = x * x;
+      const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+      const float t = fast_tanh(u);
+      const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
       return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
     }
     case ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case ACT_SILU: {
-      float s = 1.0f / (1.0f + __expf(-x));
+      const float s = fast_sigmoid(x);
       return s * (1.0f + x * (1.0f - s));
     }
     case ACT_QUICK_GELU: {
-      float s = 1.0f / (1.0f + __expf(-1.702f * x));
+      const float s = fast_sigmoid(1.702f * x);
       return s * (1.0f + 1.702f * x * (1.0f - s));
     }
-    case ACT_TANH: { float t = tanhf(x); return 1.0f - t * t; }
-    case ACT_SIGMOID: { float s = 1.0f / (1.0f + __expf(-x)); return s * (1.0f - s); }
+    case ACT_TANH: { const float t = fast_tanh(x); return 1.0f - t * t; }
+    case ACT_SIGMOID: { const float s = fast_sigmoid(x); return s * (1.0f - s); }
     default: return 1.0f;
   }
 }

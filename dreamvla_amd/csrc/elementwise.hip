@@ -5,41 +5,55 @@
 
 namespace {
 
-constexpr int CS_BLOCKS = 512;  // persistent row-slabs for colsum
+constexpr int CS_BLOCKS = 128;  // row slabs (stage-1 partial rows)
 
-// out_partial[slab][c] = sum over the slab's rows of x[r][c]; thread = one column pair-of-8? keep simple:
-// block = 256 threads covers 256*8 = 2048 columns per pass with 16-B loads when cols % 8 == 0.
-__global__ void colsum_partial_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows, int64_t cols,
-                                      float* __restrict__ partial, int vec_ok) {
-  const int64_t slab = blockIdx.y;
-  const int64_t nslab = gridDim.y;
+// stage 1: block = 4 waves over one 512-column strip of one row slab.  Wave w takes rows r_begin + w, + 4, ...; a lane
+// owns 8 consecutive columns (16-B loads, a wave reads 1 KiB contiguous per row).  The 4 waves are combined through LDS.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows, int64_t cols,
+                                                             float* __restrict__ partial, int vec_ok) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t slab = blockIdx.y, nslab = gridDim.y;
   const int64_t r_begin = rows * slab / nslab, r_end = rows * (slab + 1) / nslab;
-  const int64_t c0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
-  if (c0 >= cols) return;
+  const int64_t c0 = (int64_t)blockIdx.x * 512 + lane * 8;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (vec_ok && c0 + 8 <= cols) {
-    for (int64_t r = r_begin; r < r_end; ++r) {
-      const uint4 u = *reinterpret_cast<const uint4*>(x + r * ld + c0);
-      s[0] += bf2f((bf16_t)(u.x & 0xffff)); s[1] += bf2f((bf16_t)(u.x >> 16));
-      s[2] += bf2f((bf16_t)(u.y & 0xffff)); s[3] += bf2f((bf16_t)(u.y >> 16));
-      s[4] += bf2f((bf16_t)(u.z & 0xffff)); s[5] += bf2f((bf16_t)(u.z >> 16));
-      s[6] += bf2f((bf16_t)(u.w & 0xffff)); s[7] += bf2f((bf16_t)(u.w >> 16));
+  if (c0 < cols) {
+    if (vec_ok && c0 + 8 <= cols) {
+      for (int64_t r = r_begin + wave; r < r_end; r += 4) {
+        const uint4 u = *reinterpret_cast<const uint4*>(x + r * ld + c0);
+        s[0] += bf2f((bf16_t)(u.x & 0xffff)); s[1] += bf2f((bf16_t)(u.x >> 16));
+        s[2] += bf2f((bf16_t)(u.y & 0xffff)); s[3] += bf2f((bf16_t)(u.y >> 16));
+        s[4] += bf2f((bf16_t)(u.z & 0xffff)); s[5] += bf2f((bf16_t)(u.z >> 16));
+        s[6] += bf2f((bf16_t)(u.w & 0xffff)); s[7] += bf2f((bf16_t)(u.w >> 16));
+      }
+    } else {
+      for (int64_t r = r_begin + wave; r < r_end; r += 4)
+        for (int e = 0; e < 8; ++e)
+          if (c0 + e < cols) s[e] += bf2f(x[r * ld + c0 + e]);
     }
-  } else {
-    for (int64_t r = r_begin; r < r_end; ++r)
-      for (int e = 0; e < 8; ++e)
-        if (c0 + e < cols) s[e] += bf2f(x[r * ld + c0 + e]);
   }
-  for (int e = 0; e < 8; ++e)
-    if (c0 + e < cols) partial[slab * cols + c0 + e] = s[e];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = s[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int64_t c = (int64_t)blockIdx.x * 512 + i;
+    if (c < cols) partial[slab * cols + c] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+  }
 }
 
-__global__ void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab, int64_t cols) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// stage 2 (also used for the LayerNorm parameter gradients): out[c] = sum_k partial[k*stride + c]; block = 64 columns x 4
+// interleaved slab subsets, combined through LDS (fixed order -> deterministic).
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab,
+                                                            int64_t cols, int64_t stride) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += partial[(int64_t)k * cols + c];
-  out[c] = s;
+  if (c < cols)
+    for (int k = part; k < nslab; k += 4) s += partial[(int64_t)k * stride + c];
+  red[part][cl] = s;
+  __syncthreads();
+  if (part == 0 && c < cols) out[c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
 __global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int64_t cols,
@@ -112,17 +126,17 @@ extern "C" int64_t dvla_colsum_partial_rows(void) { return CS_BLOCKS; }
 extern "C" int dvla_colsum(const void* x, int64_t ld, int64_t rows, int64_t cols, float* out, float* partial, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!x || !out || !partial || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
-  int64_t nslab = rows < CS_BLOCKS ? (rows > 0 ? rows : 1) : CS_BLOCKS;
-  // keep the grid reasonable for very wide matrices
-  const int64_t colblocks = (cols + 2047) / 2048;
-  while (nslab > 1 && nslab * colblocks > 2048) nslab /= 2;
+  const int64_t colblocks = (cols + 511) / 512;
+  int64_t nslab = rows / 16;
+  if (nslab > CS_BLOCKS) nslab = CS_BLOCKS;
+  if (nslab < 1) nslab = 1;
   const int vec_ok = (ld % 8 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)colblocks, (unsigned)nslab), dim3(256), 0, stream,
                      reinterpret_cast<const bf16_t*>(x), ld, rows, cols, partial, vec_ok);
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, partial, out,
-                     (int)nslab, cols);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream, partial, out,
+                     (int)nslab, cols, cols);
   return dvla_check_launch();
 }
 

@@ -2,17 +2,19 @@
 //
 //   C[M,N] = epilogue( A[M,K] . B[N,K]^T ),   fp32 accumulate on v_mfma_f32_32x32x16_bf16
 //
-// Tiling: 128x128x32 block tile, 256 threads = 4 waves in a 2(M) x 2(N) grid, each wave a 64x64 patch
-// made of 2x2 MFMA 32x32 tiles (64 accumulator VGPRs).  Operands are staged global -> registers -> LDS
-// with the next K-tile's global loads issued before the current tile's MFMAs and written to the
-// other LDS buffer after them (one barrier per K-tile).
+// Tiling: 128x128x64 block tile, 256 threads = 4 waves in a 2(M) x 2(N) grid, each wave a 64x64 patch
+// made of 2x2 MFMA 32x32 tiles (64 accumulator VGPRs, 16 MFMAs per wave per K-tile).  Operands are staged
+// global -> registers -> LDS with the next K-tile's global loads (8 x 16 B per thread) issued before the
+// current tile's MFMAs and written to the other LDS buffer after them: one barrier per K-tile, 72 KiB of
+// dynamic LDS, 2 workgroups per CU.
 //
 // Both operands may have either memory order (the autograd backward GEMMs need every combination):
-//   "k-contiguous" : element (r,k) at P[r*ld + k] -> LDS row-major [128][32+8] bf16, fragments by
-//                    one ds_read_b128 per lane (rows are 80 B apart: conflict-free for 16 rows).
-//   "r-contiguous" : element (r,k) at P[k*ld + r] -> LDS "pair-interleaved" dwords [k/2][128 rows]
-//                    (dword = {k even, k odd} of one row): written with two ds_write_b128 per thread
-//                    straight from two coalesced 16-B global loads, fragments by four ds_read_b32.
+//   "k-contiguous" : element (r,k) at P[r*ld + k] -> LDS row-major [128][64+8] bf16, fragments by
+//                    one ds_read_b128 per lane (rows are 144 B apart: conflict-free for 16 rows).
+//   "r-contiguous" : element (r,k) at P[k*ld + r] -> LDS "quad-interleaved" 8-byte units [k/4][128 rows]
+//                    (unit = {k..k+3} of one row): each thread transposes a 4(k) x 8(rows) block in
+//                    registers between its four coalesced 16-B global loads and four ds_write_b128;
+//                    fragments by two conflict-free ds_read_b64 per lane.
 // The MFMA k-slot <-> k mapping is the same for both layouts (slot (g,j) <-> k = 16*ks + 8*g + j).
 //
 // The MFMA is issued as mfma(a = B-operand fragment (n), b = A-operand fragment (m)) so that a lane
@@ -24,9 +26,10 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int RM_STRIDE = BK + 8;           // bf16 elements per row-major LDS row (80 B)
-constexpr int OPER_BYTES = BM * RM_STRIDE * 2;  // 10240 B  (pair-interleaved image needs 8192 B)
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int RM_STRIDE = BK + 8;               // bf16 elements per row-major LDS row (144 B: 16-B aligned, conflict-free)
+constexpr int OPER_BYTES = BM * RM_STRIDE * 2;  // 18432 B  (the quad-interleaved image needs 16384 B)
+constexpr int SMEM_BYTES = 2 * 2 * OPER_BYTES;  // double-buffered A|B : 73728 B of dynamic LDS
 constexpr int NTHREADS = 256;
 
 struct GemmKArgs {
@@ -42,59 +45,96 @@ struct GemmKArgs {
   const bf16_t* residual; int64_t ld_res; int64_t res_rows;
   int accumulate;
   int split_k; int64_t k_per_split; float* workspace;
-  int a_vec, b_vec, c_vec, aux_vec;
+  int a_vec, b_vec, c_vec, aux_vec, epi_vec;
   int tiles_m, tiles_n;
 };
 
-// ---- staging: global -> registers ------------------------------------------------------------------
-// k-contiguous operand: thread t loads rows (t>>2) and (t>>2)+64, k-octet (t&3)
-// r-contiguous operand: thread t loads k = 2*(t>>4), 2*(t>>4)+1, rows (t&15)*8 .. +7
+// ---- staging: global -> registers (4 x 16 B per thread and operand) -------------------------------------
+// k-contiguous operand: thread t loads rows (t>>3) + 32*i (i = 0..3), k-octet (t&7): 8 lanes = one 128-B row segment
+// r-contiguous operand: thread t loads k = 4*(t>>4) + kk (kk = 0..3), rows (t&15)*8 .. +7: 16 lanes = 256 B of one k
 template <bool TRANS>
-__device__ __forceinline__ void stage_load(uint4 (&reg)[2], const bf16_t* __restrict__ P, int64_t ld, int64_t row0,
+__device__ __forceinline__ void stage_load(uint4 (&reg)[4], const bf16_t* __restrict__ P, int64_t ld, int64_t row0,
                                            int64_t rows, int64_t k0, int64_t k_end, bool vec_ok, int t) {
   if (!TRANS) {
-    const int r = t >> 2, kc = (t & 3) * 8;
-    reg[0] = load8_guard(P, ld, row0 + r, k0 + kc, rows, k_end, vec_ok);
-    reg[1] = load8_guard(P, ld, row0 + r + 64, k0 + kc, rows, k_end, vec_ok);
+    const int r = t >> 3, kc = (t & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reg[i] = load8_guard(P, ld, row0 + r + 32 * i, k0 + kc, rows, k_end, vec_ok);
   } else {
-    const int kp = t >> 4, r0 = (t & 15) * 8;
-    reg[0] = load8_guard(P, ld, k0 + 2 * kp, row0 + r0, k_end, rows, vec_ok);
-    reg[1] = load8_guard(P, ld, k0 + 2 * kp + 1, row0 + r0, k_end, rows, vec_ok);
+    const int kq = t >> 4, r0 = (t & 15) * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) reg[kk] = load8_guard(P, ld, k0 + 4 * kq + kk, row0 + r0, k_end, rows, vec_ok);
+  }
+}
+
+// Fast path (interior K-tile of a 16-B-vectorisable operand): four unconditional 16-B loads from per-thread pointers that
+// simply advance by one K-tile per iteration.  Rows past the end of a k-contiguous operand are clamped to the last row
+// (their products land in output rows the epilogue never stores); an r-contiguous operand takes the fast path only when
+// the whole 128-row panel is in range.  Everything else (K tail, ragged / unaligned operands) goes through stage_load.
+template <bool TRANS>
+__device__ __forceinline__ void fast_ptrs(const bf16_t* (&ptr)[4], const bf16_t* __restrict__ P, int64_t ld, int64_t row0,
+                                          int64_t rows, int64_t k0, int t) {
+  if (!TRANS) {
+    const int r = t >> 3, kc = (t & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t row = row0 + r + 32 * i;
+      row = row < rows ? row : rows - 1;
+      ptr[i] = P + row * ld + k0 + kc;
+    }
+  } else {
+    const int kq = t >> 4, r0 = (t & 15) * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ptr[kk] = P + (k0 + 4 * kq + kk) * ld + row0 + r0;
+  }
+}
+template <bool TRANS>
+__device__ __forceinline__ void fast_load(uint4 (&reg)[4], const bf16_t* (&ptr)[4], int64_t ld) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    reg[i] = *reinterpret_cast<const uint4*>(ptr[i]);
+    ptr[i] += TRANS ? (int64_t)BK * ld : (int64_t)BK;
   }
 }
 
 // ---- staging: registers -> LDS ---------------------------------------------------------------------
+// k-contiguous: row-major [128][72] bf16.
+// r-contiguous: "quad-interleaved" 8-byte units [k/4][128 rows] = {k, k+1, k+2, k+3} of one row; the 4(k) x 8(rows)
+// register block is transposed in registers (two 16-bit merges per output dword) and leaves as four ds_write_b128.
 template <bool TRANS>
-__device__ __forceinline__ void stage_store(const uint4 (&reg)[2], char* lds, int t) {
+__device__ __forceinline__ void stage_store(const uint4 (&reg)[4], char* lds, int t) {
   if (!TRANS) {
-    const int r = t >> 2, kc = (t & 3) * 8;
-    *reinterpret_cast<uint4*>(lds + ((r)*RM_STRIDE + kc) * 2) = reg[0];
-    *reinterpret_cast<uint4*>(lds + ((r + 64) * RM_STRIDE + kc) * 2) = reg[1];
-  } else {
-    const int kp = t >> 4, r0 = (t & 15) * 8;
-    const uint32_t a[4] = {reg[0].x, reg[0].y, reg[0].z, reg[0].w};  // k even : rows r0..r0+7 (2 per dword)
-    const uint32_t b[4] = {reg[1].x, reg[1].y, reg[1].z, reg[1].w};  // k odd
-    uint32_t o[8];
+    const int r = t >> 3, kc = (t & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      o[2 * i] = (a[i] & 0xffffu) | (b[i] << 16);             // row r0+2i   : {k even, k odd}
-      o[2 * i + 1] = (a[i] >> 16) | (b[i] & 0xffff0000u);     // row r0+2i+1
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(lds + ((r + 32 * i) * RM_STRIDE + kc) * 2) = reg[i];
+  } else {
+    const int kq = t >> 4, r0 = (t & 15) * 8;
+    uint32_t in[4][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { in[kk][0] = reg[kk].x; in[kk][1] = reg[kk].y; in[kk][2] = reg[kk].z; in[kk][3] = reg[kk].w; }
+    uint32_t o[16];  // row r0+i -> dwords o[2i] = {k0,k1}, o[2i+1] = {k2,k3}
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {  // dword w of every k-vector holds rows r0+2w (low half) and r0+2w+1 (high half)
+      o[4 * w + 0] = (in[0][w] & 0xffffu) | (in[1][w] << 16);
+      o[4 * w + 1] = (in[2][w] & 0xffffu) | (in[3][w] << 16);
+      o[4 * w + 2] = (in[0][w] >> 16) | (in[1][w] & 0xffff0000u);
+      o[4 * w + 3] = (in[2][w] >> 16) | (in[3][w] & 0xffff0000u);
     }
-    uint32_t* dst = reinterpret_cast<uint32_t*>(lds) + kp * BM + r0;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
-    *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+    uint4* dst = reinterpret_cast<uint4*>(lds + ((size_t)(kq * BM + r0)) * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
   }
 }
 
-// ---- LDS -> MFMA fragment: row `row` of the tile, k16-step ks, lane group g ---------------------------
+// ---- LDS -> MFMA fragment: row `row` of the tile, k16-step ks (0..3), lane group g; slot (g,j) <-> k = 16ks+8g+j --
 template <bool TRANS>
 __device__ __forceinline__ bf16x8 frag_load(const char* lds, int row, int ks, int g) {
   if (!TRANS) {
     return *reinterpret_cast<const bf16x8*>(lds + (row * RM_STRIDE + ks * 16 + g * 8) * 2);
   } else {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(lds) + (ks * 8 + g * 4) * BM + row;
-    union { uint32_t w[4]; bf16x8 v; } u;
-    u.w[0] = src[0]; u.w[1] = src[BM]; u.w[2] = src[2 * BM]; u.w[3] = src[3 * BM];
+    const int q0 = ks * 4 + g * 2;
+    union { uint2 h[2]; bf16x8 v; } u;
+    u.h[0] = *reinterpret_cast<const uint2*>(lds + ((size_t)(q0 * BM + row)) * 8);
+    u.h[1] = *reinterpret_cast<const uint2*>(lds + ((size_t)((q0 + 1) * BM + row)) * 8);
     return u.v;
   }
 }
@@ -106,7 +146,7 @@ __device__ __forceinline__ void unpack8f(const uint4& u, float (&f)[8]) {
   f[6] = bf2f((bf16_t)(u.w & 0xffff)); f[7] = bf2f((bf16_t)(u.w >> 16));
 }
 __device__ __forceinline__ void load8_aux(const bf16_t* q, int64_t n, int64_t N, bool vec, float (&f)[8]) {
-  if (vec && n + 8 <= N) {
+  if (vec) {
     unpack8f(*reinterpret_cast<const uint4*>(q), f);
   } else {
 #pragma unroll
@@ -114,7 +154,7 @@ __device__ __forceinline__ void load8_aux(const bf16_t* q, int64_t n, int64_t N,
   }
 }
 __device__ __forceinline__ void store8_bf16(bf16_t* q, int64_t n, int64_t N, bool vec, const float (&v)[8]) {
-  if (vec && n + 8 <= N) {
+  if (vec) {
     *reinterpret_cast<uint4*>(q) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
   } else {
 #pragma unroll
@@ -122,11 +162,13 @@ __device__ __forceinline__ void store8_bf16(bf16_t* q, int64_t n, int64_t N, boo
   }
 }
 
-// eight consecutive outputs of row m: columns n .. n+7 (values arrive in fp32 from the LDS transpose)
+// eight consecutive outputs of row m: columns n .. n+7 (values arrive in fp32 from the LDS transpose).
+// FULL = the whole octet is in range and every pointer involved is 16-B vectorisable: no per-element guards.
+template <bool FULL>
 __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int64_t n, float (&v)[8], int split) {
   if (p.split_k > 1) {  // raw partial sums -> workspace[split][m][n]
     float* w = p.workspace + ((int64_t)split * p.M + m) * p.N + n;
-    if (n + 8 <= p.N && (p.N & 3) == 0) {
+    if (FULL) {
       *reinterpret_cast<float4*>(w) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(w + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
@@ -136,14 +178,25 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
     return;
   }
   if (p.bias) {
+    if (FULL && !p.bias_f32) {
+      float bv[8];
+      unpack8f(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bias) + n), bv);
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (n + e < p.N)
-        v[e] += p.bias_f32 ? reinterpret_cast<const float*>(p.bias)[n + e]
-                           : bf2f(reinterpret_cast<const bf16_t*>(p.bias)[n + e]);
+      for (int e = 0; e < 8; ++e) v[e] += bv[e];
+    } else if (FULL) {
+      const float4 b0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n);
+      const float4 b1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N)
+          v[e] += p.bias_f32 ? reinterpret_cast<const float*>(p.bias)[n + e]
+                             : bf2f(reinterpret_cast<const bf16_t*>(p.bias)[n + e]);
+    }
   }
   if (p.preact) {
-    store8_bf16(p.preact + m * p.ld_preact + n, n, p.N, p.aux_vec, v);
+    store8_bf16(p.preact + m * p.ld_preact + n, n, p.N, FULL, v);
     // the activation sees the value that was stored (bf16), exactly like act(preact_tensor)
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
@@ -154,7 +207,7 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
   }
   if (p.dact_aux) {
     float a[8];
-    load8_aux(p.dact_aux + m * p.ld_dact + n, n, p.N, p.aux_vec, a);
+    load8_aux(p.dact_aux + m * p.ld_dact + n, n, p.N, FULL, a);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= act_bwd(a[e], p.dact);
   }
@@ -168,7 +221,8 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
   }
   if (p.residual) {
     float a[8];
-    load8_aux(p.residual + (p.res_rows > 0 ? m % p.res_rows : m) * p.ld_res + n, n, p.N, p.aux_vec, a);
+    const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)m % (uint32_t)p.res_rows) : m;
+    load8_aux(p.residual + rr * p.ld_res + n, n, p.N, FULL, a);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += a[e];
   }
@@ -176,8 +230,8 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
     float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
     if (p.accumulate) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) if (n + e < p.N) c[e] += v[e];
-    } else if (p.c_vec && n + 8 <= p.N) {
+      for (int e = 0; e < 8; ++e) if (FULL || n + e < p.N) c[e] += v[e];
+    } else if (FULL) {
       *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
@@ -185,13 +239,13 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
       for (int e = 0; e < 8; ++e) if (n + e < p.N) c[e] = v[e];
     }
   } else {
-    store8_bf16(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n, n, p.N, p.c_vec, v);
+    store8_bf16(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n, n, p.N, FULL, v);
   }
 }
 
 template <bool A_T, bool B_T>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * OPER_BYTES];  // [buf][A|B]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][A|B], SMEM_BYTES
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave & 1, wn = wave >> 1;
@@ -220,26 +274,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (int)((k_end - k_begin + BK - 1) / BK);
-  uint4 ra[2], rb[2];
-  if (nk > 0) {
-    stage_load<A_T>(ra, p.A, p.lda, m0, p.M, k_begin, k_end, p.a_vec, t);
-    stage_load<B_T>(rb, p.B, p.ldb, n0, p.N, k_begin, k_end, p.b_vec, t);
-    stage_store<A_T>(ra, smem, t);
-    stage_store<B_T>(rb, smem + OPER_BYTES, t);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * 2 * OPER_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * 2 * OPER_BYTES;
-    const bool more = (kt + 1 < nk);
-    if (more) {
-      const int64_t k0 = k_begin + (int64_t)(kt + 1) * BK;
-      stage_load<A_T>(ra, p.A, p.lda, m0, p.M, k0, k_end, p.a_vec, t);
-      stage_load<B_T>(rb, p.B, p.ldb, n0, p.N, k0, k_end, p.b_vec, t);
-    }
+  // number of leading K-tiles that are complete (fast path eligible); the ragged tail tile takes the guarded loader
+  const int nk_full = (int)((k_end - k_begin) / BK);
+  const bool a_fast = p.a_vec && (!A_T || m0 + BM <= p.M);
+  const bool b_fast = p.b_vec && (!B_T || n0 + BN <= p.N);
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+  fast_ptrs<A_T>(pa, p.A, p.lda, m0, p.M, k_begin, t);
+  fast_ptrs<B_T>(pb, p.B, p.ldb, n0, p.N, k_begin, t);
+  // Two register sets: while tile kt is multiplied out of LDS, tile kt+1 sits in one set (written to the other LDS
+  // buffer after the MFMAs) and the global loads of tile kt+2 are already in flight into the other set -> a load has
+  // two full K-tile periods (~1000+ cycles) to land before its ds_write needs it.
+  uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+  auto load_tile = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
+    const int64_t k0 = k_begin + (int64_t)kt * BK;
+    if (a_fast && kt < nk_full) fast_load<A_T>(ra, pa, p.lda);
+    else stage_load<A_T>(ra, p.A, p.lda, m0, p.M, k0, k_end, p.a_vec, t);
+    if (b_fast && kt < nk_full) fast_load<B_T>(rb, pb, p.ldb);
+    else stage_load<B_T>(rb, p.B, p.ldb, n0, p.N, k0, k_end, p.b_vec, t);
+  };
+  auto store_tile = [&](const uint4 (&ra)[4], const uint4 (&rb)[4], char* buf) {
+    stage_store<A_T>(ra, buf, t);
+    stage_store<B_T>(rb, buf + OPER_BYTES, t);
+  };
+  auto compute = [&](const char* cur) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 fa[2], fb[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) fa[j] = frag_load<A_T>(cur, wm * 64 + j * 32 + l31, ks, g);
@@ -251,10 +311,46 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
     }
-    if (more) {
-      stage_store<A_T>(ra, nxt, t);
-      stage_store<B_T>(rb, nxt + OPER_BYTES, t);
+  };
+  char* buf0 = smem;
+  char* buf1 = smem + 2 * OPER_BYTES;
+  if (nk > 0) {
+    load_tile(0, ra0, rb0);
+    store_tile(ra0, rb0, buf0);
+    if (nk > 1) load_tile(1, ra1, rb1);
+  }
+  __syncthreads();
+  int kt = 0;
+  if (a_fast && b_fast) {
+    // steady state, no conditionals inside: the compiler can then count the 8 newer loads and wait with vmcnt(8)
+    // (a conditional prefetch forces s_waitcnt vmcnt(0) at the join and serialises load latency with the MFMAs)
+    while (kt + 3 < nk_full) {
+      fast_load<A_T>(ra0, pa, p.lda);
+      fast_load<B_T>(rb0, pb, p.ldb);
+      __builtin_amdgcn_sched_barrier(0);  // issue the prefetch BEFORE the MFMAs (the scheduler would sink it)
+      compute(buf0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the ds_writes (and their vmcnt wait) BEHIND the MFMAs
+      store_tile(ra1, rb1, buf1);
+      __syncthreads();
+      fast_load<A_T>(ra1, pa, p.lda);
+      fast_load<B_T>(rb1, pb, p.ldb);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(buf1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_tile(ra0, rb0, buf0);
+      __syncthreads();
+      kt += 2;
     }
+  }
+  for (; kt < nk; kt += 2) {   // remaining (<= 3 full tiles + ragged tail) and the generic / guarded path
+    if (kt + 2 < nk) load_tile(kt + 2, ra0, rb0);
+    compute(buf0);
+    if (kt + 1 < nk) store_tile(ra1, rb1, buf1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) load_tile(kt + 3, ra1, rb1);
+    compute(buf1);
+    if (kt + 2 < nk) store_tile(ra0, rb0, buf0);
     __syncthreads();
   }
 
@@ -274,6 +370,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
         *reinterpret_cast<float4*>(patch + l31 * PATCH_LD + 32 * i + 8 * rq + 4 * g) =
             make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
     __syncthreads();
+    // whole-tile fast path: every octet of this wave's columns is in range and all pointers are 16-B vectorisable
+    const bool tile_full = (n0 + wn * 64 + 64 <= p.N) && p.c_vec && p.aux_vec && p.epi_vec;
+#pragma unroll 2
     for (int it = 0; it < 4; ++it) {
       const int item = it * 64 + lane;
       const int row = item >> 3, cg = item & 7;
@@ -283,7 +382,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
         const float4 lo = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8);
         const float4 hi = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8 + 4);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        epilogue_oct(p, m, n, v, split);
+        if (tile_full) epilogue_oct<true>(p, m, n, v, split);
+        else epilogue_oct<false>(p, m, n, v, split);
       }
     }
   }
@@ -352,16 +452,27 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   if (q->preact && !((q->ld_preact % 8 == 0) && aligned(q->preact, 16))) a.aux_vec = 0;
   if (q->dact_aux && !((q->ld_dact % 8 == 0) && aligned(q->dact_aux, 16))) a.aux_vec = 0;
   if (q->residual && !((q->ld_res % 8 == 0) && aligned(q->residual, 16))) a.aux_vec = 0;
+  a.epi_vec = 1;  // bias / split-K workspace vector access
+  if (q->bias && !aligned(q->bias, 16)) a.epi_vec = 0;
+  if (split_k > 1 && ((q->N & 3) != 0 || !aligned(q->workspace, 16))) a.epi_vec = 0;
   a.tiles_m = (int)((q->M + BM - 1) / BM);
   a.tiles_n = (int)((q->N + BN - 1) / BN);
 
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KiB of LDS per workgroup needs the opt-in (160 KiB per CU on gfx950)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_set = true;
+  }
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)split_k, 1), block(NTHREADS, 1, 1);
   const int combo = (q->a_trans ? 2 : 0) | (q->b_trans ? 1 : 0);
   switch (combo) {
-    case 0: hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, stream, a); break;
-    case 1: hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, stream, a); break;
+    case 0: hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, SMEM_BYTES, stream, a); break;
+    case 1: hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, SMEM_BYTES, stream, a); break;
+    case 2: hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, SMEM_BYTES, stream, a); break;
+    default: hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, SMEM_BYTES, stream, a); break;
   }
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;

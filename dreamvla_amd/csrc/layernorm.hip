@@ -16,7 +16,7 @@ namespace {
 
 constexpr int LN_THREADS = 256;
 constexpr int LN_MAX_VPL = 4;          // vectors per lane -> cols <= 64*8*4 = 2048
-constexpr int LN_BWD_BLOCKS = 1024;    // persistent grid for backward (partial rows)
+constexpr int LN_BWD_BLOCKS = 512;     // persistent grid for backward (partial rows)
 
 __device__ __forceinline__ float param_at(const void* p, int f32, int64_t i) {
   return f32 ? reinterpret_cast<const float*>(p)[i] : bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
@@ -175,17 +175,25 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
   }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int nblocks, int cols) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// out[c] = sum over blocks of partial[b][which][c]; 64 columns x 4 interleaved block subsets per workgroup (deterministic)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nblocks, int cols) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float sg = 0.f, sb = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
-    sg += partial[(int64_t)b * 2 * cols + c];
-    sb += partial[(int64_t)b * 2 * cols + cols + c];
+  if (c < cols)
+    for (int b = part; b < nblocks; b += 4) {
+      sg += partial[(int64_t)b * 2 * cols + c];
+      sb += partial[(int64_t)b * 2 * cols + cols + c];
+    }
+  red[0][part][cl] = sg;
+  red[1][part][cl] = sb;
+  __syncthreads();
+  if (part == 0 && c < cols) {
+    if (dgamma) dgamma[c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    if (dbeta) dbeta[c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
   }
-  if (dgamma) dgamma[c] = sg;
-  if (dbeta) dbeta[c] = sb;
 }
 
 int fwd_blocks(int64_t rows) {
@@ -245,7 +253,7 @@ extern "C" int dvla_layernorm_bwd(const void* dy, const void* x, const void* gam
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
   if (part) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, part, dgamma,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream, part, dgamma,
                        dbeta, (int)nb, (int)cols);
     rc = dvla_check_launch();
   }

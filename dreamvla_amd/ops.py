@@ -82,10 +82,12 @@ def next_seed():
 # raw kernel launchers (no autograd)
 # ---------------------------------------------------------------------------------------------------
 def auto_split_k(M, N, K):
+    """weight-gradient GEMMs: small output, very long contraction.  Aim at >= ~1000 workgroups (256 CUs x 2 resident
+    x 2 waves of blocks) while keeping >= 2048 of K per slice."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 160 or K < 4096:
+    if tiles >= 768 or K < 4096:
         return 1
-    s = min(16, max(1, 384 // tiles), K // 1024)
+    s = min(16, -(-1024 // tiles), K // 2048)
     return max(1, s)
 
 
@@ -96,6 +98,17 @@ class GemmProfiler:
 
     def __init__(self):
         self.records = []
+        self.shapes = []
+
+    def breakdown(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for (e0, e1, f), sh in zip(self.records, self.shapes):
+            a = agg.setdefault(sh, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
+        rows = [{"M": k[0], "N": k[1], "K": k[2], "a_trans": k[3], "b_trans": k[4], "split_k": k[5], "launches": v[0],
+                 "ms": v[1], "tflops": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for k, v in agg.items()]
+        return sorted(rows, key=lambda r: -r["ms"])
 
     def __enter__(self):
         GemmProfiler.active = self
@@ -180,6 +193,7 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     if prof is not None:
         e1.record()
         prof.records.append((e0, e1, 2.0 * M * N * K))
+        prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k)))
     return (out, preact) if want_preact else out
 
 

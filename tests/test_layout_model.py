@@ -41,29 +41,32 @@ def mfma_32x32x16(a, b, c):
 
 
 # ---------------------------------------------------------------------------------------------------
-# GEMM tile model (gemm.hip): 128x128x32 tile, both operand layouts
+# GEMM tile model (gemm.hip): 128x128x64 tile, both operand layouts
 # ---------------------------------------------------------------------------------------------------
-BM, BK, RM_STRIDE = 128, 32, 40
+BM, BK, RM_STRIDE = 128, 64, 72
 
 
-def gemm_stage_rm(tile):  # tile[row][k] (128 x 32)  ->  LDS element array (row-major, padded)
+def gemm_stage_rm(tile):  # tile[row][k] (128 x 64)  ->  LDS element array (row-major, padded)
     lds = np.zeros(BM * RM_STRIDE)
     for t in range(256):
-        r, kc = t >> 2, (t & 3) * 8
-        for rr in (r, r + 64):
+        r, kc = t >> 3, (t & 7) * 8
+        for i in range(4):
+            rr = r + 32 * i
             lds[rr * RM_STRIDE + kc: rr * RM_STRIDE + kc + 8] = tile[rr, kc:kc + 8]
     return lds
 
 
-def gemm_stage_pi(tile):  # same logical tile, but memory is [k][row]; LDS dwords [k/2][128] -> model as (dword, half)
-    lds = np.zeros((16 * BM, 2))
+def gemm_stage_quad(tile):  # same logical tile, memory is [k][row]; LDS 8-byte units [k/4][128] -> model as (unit, 4)
+    lds = np.zeros((16 * BM, 4))
     for t in range(256):
-        kp, r0 = t >> 4, (t & 15) * 8
-        v0 = tile[r0:r0 + 8, 2 * kp]       # 16-B vector: 8 rows at k even
-        v1 = tile[r0:r0 + 8, 2 * kp + 1]   # 8 rows at k odd
-        for i in range(8):
-            lds[kp * BM + r0 + i, 0] = v0[i]
-            lds[kp * BM + r0 + i, 1] = v1[i]
+        kq, r0 = t >> 4, (t & 15) * 8
+        vec = [tile[r0:r0 + 8, 4 * kq + kk] for kk in range(4)]    # four 16-B vectors: 8 rows at k = 4kq+kk
+        # register transpose exactly as stage_store<true>: dword w of a vector = rows (r0+2w, r0+2w+1)
+        for w in range(4):
+            lo = [vec[kk][2 * w] for kk in range(4)]
+            hi = [vec[kk][2 * w + 1] for kk in range(4)]
+            lds[kq * BM + r0 + 2 * w] = lo       # o[4w+0], o[4w+1] = {k0,k1},{k2,k3} of row r0+2w
+            lds[kq * BM + r0 + 2 * w + 1] = hi   # o[4w+2], o[4w+3]
     return lds
 
 
@@ -76,13 +79,13 @@ def gemm_frag_rm(lds, row_base, ks):
     return f
 
 
-def gemm_frag_pi(lds, row_base, ks):
+def gemm_frag_quad(lds, row_base, ks):
     f = np.zeros((64, 8))
     for l in range(64):
         row, g = row_base + (l & 31), l >> 5
-        for jj in range(4):
-            dw = (ks * 8 + g * 4 + jj) * BM + row
-            f[l, 2 * jj], f[l, 2 * jj + 1] = lds[dw, 0], lds[dw, 1]
+        q0 = ks * 4 + g * 2
+        f[l, 0:4] = lds[q0 * BM + row]
+        f[l, 4:8] = lds[(q0 + 1) * BM + row]
     return f
 
 
@@ -91,15 +94,15 @@ def test_gemm_tile_dataflow(a_t, b_t):
     rng = np.random.default_rng(0)
     A = rng.integers(-4, 5, (BM, BK)).astype(np.float64)   # A[m][k]
     B = rng.integers(-4, 5, (BM, BK)).astype(np.float64)   # B[n][k]
-    la = gemm_stage_pi(A) if a_t else gemm_stage_rm(A)
-    lb = gemm_stage_pi(B) if b_t else gemm_stage_rm(B)
-    fa = gemm_frag_pi if a_t else gemm_frag_rm
-    fb = gemm_frag_pi if b_t else gemm_frag_rm
+    la = gemm_stage_quad(A) if a_t else gemm_stage_rm(A)
+    lb = gemm_stage_quad(B) if b_t else gemm_stage_rm(B)
+    fa = gemm_frag_quad if a_t else gemm_frag_rm
+    fb = gemm_frag_quad if b_t else gemm_frag_rm
     C = np.zeros((BM, BM))
     for wave in range(4):
         wm, wn = wave & 1, wave >> 1
         acc = [[np.zeros((64, 16)) for _ in range(2)] for _ in range(2)]
-        for ks in range(2):
+        for ks in range(BK // 16):
             for i in range(2):
                 for j in range(2):
                     acc[i][j] = mfma_32x32x16(fb(lb, wn * 64 + i * 32, ks), fa(la, wm * 64 + j * 32, ks), acc[i][j])
