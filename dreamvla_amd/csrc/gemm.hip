@@ -2,16 +2,23 @@
 //
 //   C[M,N] = epilogue( A[M,K] . B[N,K]^T ),   fp32 accumulate on v_mfma_f32_32x32x16_bf16
 //
-// Tiling: 128x128x64 block tile, 256 threads = 4 waves in a 2(M) x 2(N) grid, each wave a 64x64 patch
-// made of 2x2 MFMA 32x32 tiles (64 accumulator VGPRs, 16 MFMAs per wave per K-tile).  Operands are staged
-// global -> registers -> LDS with the next K-tile's global loads (8 x 16 B per thread) issued before the
-// current tile's MFMAs and written to the other LDS buffer after them: one barrier per K-tile, 72 KiB of
-// dynamic LDS, 2 workgroups per CU.
+// Two tile configurations of ONE kernel template (K-tile = 64 in both):
+//   S : 128x128 block tile, 4 waves (2x2), 64x64 per wave (2x2 MFMA tiles),  64 KiB LDS, 2 workgroups / CU   [default]
+//   L : 256x256 block tile, 8 waves (2x4), 128x64 per wave (4x2 MFMA tiles), 128 KiB LDS, 1 workgroup / CU
+// Ablation on MI355X (profiles/r01_gemm_ablation.txt): the S kernel without MFMAs takes 96 % of the full kernel's time
+// and without global loads / LDS writes 58 %, i.e. it is bound by the operand staging path (~22 B/clk/CU from L2), not by
+// the matrix pipe.  The L tile halves that traffic per flop but currently loses more to its single staging set and
+// 1-workgroup occupancy than it gains (805 vs 880 TFLOP/s at 8192^3), so it is opt-in (DVLA_GEMM_VARIANT=3).
+//
+// Operands are staged global -> registers -> LDS.  Two register sets per operand: while tile kt is multiplied out of
+// LDS, tile kt+1 waits in one set (written to the other LDS buffer after the MFMAs) and the 16-byte global loads of
+// tile kt+2 are already in flight into the other set (the steady-state loop is branch-free so the compiler can wait
+// with a counted s_waitcnt vmcnt(8) instead of draining the queue).  One barrier per K-tile.
 //
 // Both operands may have either memory order (the autograd backward GEMMs need every combination):
-//   "k-contiguous" : element (r,k) at P[r*ld + k] -> LDS row-major [128][64+8] bf16, fragments by
-//                    one ds_read_b128 per lane (rows are 144 B apart: conflict-free for 16 rows).
-//   "r-contiguous" : element (r,k) at P[k*ld + r] -> LDS "quad-interleaved" 8-byte units [k/4][128 rows]
+//   "k-contiguous" : element (r,k) at P[r*ld + k] -> swizzled row-major LDS image (rm_off), fragments by one
+//                    conflict-free ds_read_b128 per lane.
+//   "r-contiguous" : element (r,k) at P[k*ld + r] -> LDS "quad-interleaved" 8-byte units [k/4][rows]
 //                    (unit = {k..k+3} of one row): each thread transposes a 4(k) x 8(rows) block in
 //                    registers between its four coalesced 16-B global loads and four ds_write_b128;
 //                    fragments by two conflict-free ds_read_b64 per lane.
@@ -19,18 +26,44 @@
 //
 // The MFMA is issued as mfma(a = B-operand fragment (n), b = A-operand fragment (m)) so that a lane
 // owns ONE output row m and 4 consecutive n per accumulator quad; the epilogue transposes each 32-row
-// half through a wave-private fp32 LDS patch so a lane ends up with 8 consecutive n of one row and
+// slab through a wave-private fp32 LDS patch so a lane ends up with 8 consecutive n of one row and
 // reads bias / residual / aux and writes C with 16-byte accesses.
+//
+// Measured and rejected (kept out of the tree): LDS-DMA staging (global_load_lds_dwordx4) of the k-contiguous operand
+// with a 2-buffer ring was 8-12 % SLOWER than the 2-deep register prefetch (the barrier drains vmcnt(0)).
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/dvla.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int RM_STRIDE = BK + 8;               // bf16 elements per row-major LDS row (144 B: 16-B aligned, conflict-free)
-constexpr int OPER_BYTES = BM * RM_STRIDE * 2;  // 18432 B  (the quad-interleaved image needs 16384 B)
-constexpr int SMEM_BYTES = 2 * 2 * OPER_BYTES;  // double-buffered A|B : 73728 B of dynamic LDS
-constexpr int NTHREADS = 256;
+constexpr int BK = 64;
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  `#pragma unroll` is only a request
+// (the optimizer declines it for the large epilogue body) and a rolled loop would index the accumulator array
+// dynamically, i.e. put 128 accumulator registers into scratch.
+template <int V> struct IntC { static constexpr int value = V; };
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(IntC<N - 1>{});
+  }
+}
+
+template <int WM_, int WN_, int TM_, int TN_, bool DEEP_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr bool DEEP = DEEP_;   // two register sets (prefetch distance 2) vs one (distance 1: fewer VGPRs)
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + B_BYTES;
+  static constexpr int SMEM_BYTES = 2 * BUF_BYTES;
+  static_assert(NT == 2 * BM && NT == 2 * BN, "staging maps assume 4 x 16 B per thread and operand");
+  static_assert(TN == 2, "epilogue patch is 64 columns wide");
+};
+using CfgS = Cfg<2, 2, 2, 2, true>;   // 128 x 128, 256 threads
+using CfgL = Cfg<2, 4, 4, 2, false>;  // 256 x 256, 512 threads (128 accumulator registers: one staging set only)
 
 struct GemmKArgs {
   const bf16_t* A; int64_t lda;
@@ -49,18 +82,23 @@ struct GemmKArgs {
   int tiles_m, tiles_n;
 };
 
-// ---- staging: global -> registers (4 x 16 B per thread and operand) -------------------------------------
-// k-contiguous operand: thread t loads rows (t>>3) + 32*i (i = 0..3), k-octet (t&7): 8 lanes = one 128-B row segment
-// r-contiguous operand: thread t loads k = 4*(t>>4) + kk (kk = 0..3), rows (t&15)*8 .. +7: 16 lanes = 256 B of one k
-template <bool TRANS>
+// Row-major image of a k-contiguous operand: row r = 128 B = 8 slots of 16 B; k-octet o of row r lives in slot
+// o ^ ((r >> 1) & 7).  Unpadded and conflict-free for ds_read_b128: in every 16-lane read group the rows of equal
+// parity have distinct (r >> 1) & 7.
+__device__ __forceinline__ int rm_off(int row, int oct) { return row * 128 + ((oct ^ ((row >> 1) & 7)) << 4); }
+
+// ---- staging: global -> registers (4 x 16 B per thread and operand; ROWS = tile rows, NT = 2 * ROWS threads) ----
+// k-contiguous operand: thread t loads rows (t>>3) + (NT/8)*i (i = 0..3), k-octet (t&7): 8 lanes = one 128-B row segment
+// r-contiguous operand: thread t loads k = 4*(t / (ROWS/8)) + kk (kk = 0..3), rows (t % (ROWS/8))*8 .. +7
+template <bool TRANS, int ROWS>
 __device__ __forceinline__ void stage_load(uint4 (&reg)[4], const bf16_t* __restrict__ P, int64_t ld, int64_t row0,
                                            int64_t rows, int64_t k0, int64_t k_end, bool vec_ok, int t) {
   if (!TRANS) {
     const int r = t >> 3, kc = (t & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) reg[i] = load8_guard(P, ld, row0 + r + 32 * i, k0 + kc, rows, k_end, vec_ok);
+    for (int i = 0; i < 4; ++i) reg[i] = load8_guard(P, ld, row0 + r + (ROWS / 4) * i, k0 + kc, rows, k_end, vec_ok);
   } else {
-    const int kq = t >> 4, r0 = (t & 15) * 8;
+    const int kq = t / (ROWS / 8), r0 = (t % (ROWS / 8)) * 8;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) reg[kk] = load8_guard(P, ld, k0 + 4 * kq + kk, row0 + r0, k_end, rows, vec_ok);
   }
@@ -69,20 +107,20 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[4], const bf16_t* __rest
 // Fast path (interior K-tile of a 16-B-vectorisable operand): four unconditional 16-B loads from per-thread pointers that
 // simply advance by one K-tile per iteration.  Rows past the end of a k-contiguous operand are clamped to the last row
 // (their products land in output rows the epilogue never stores); an r-contiguous operand takes the fast path only when
-// the whole 128-row panel is in range.  Everything else (K tail, ragged / unaligned operands) goes through stage_load.
-template <bool TRANS>
+// the whole row panel is in range.  Everything else (K tail, ragged / unaligned operands) goes through stage_load.
+template <bool TRANS, int ROWS>
 __device__ __forceinline__ void fast_ptrs(const bf16_t* (&ptr)[4], const bf16_t* __restrict__ P, int64_t ld, int64_t row0,
                                           int64_t rows, int64_t k0, int t) {
   if (!TRANS) {
     const int r = t >> 3, kc = (t & 7) * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int64_t row = row0 + r + 32 * i;
+      int64_t row = row0 + r + (ROWS / 4) * i;
       row = row < rows ? row : rows - 1;
       ptr[i] = P + row * ld + k0 + kc;
     }
   } else {
-    const int kq = t >> 4, r0 = (t & 15) * 8;
+    const int kq = t / (ROWS / 8), r0 = (t % (ROWS / 8)) * 8;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ptr[kk] = P + (k0 + 4 * kq + kk) * ld + row0 + r0;
   }
@@ -97,17 +135,17 @@ __device__ __forceinline__ void fast_load(uint4 (&reg)[4], const bf16_t* (&ptr)[
 }
 
 // ---- staging: registers -> LDS ---------------------------------------------------------------------
-// k-contiguous: row-major [128][72] bf16.
-// r-contiguous: "quad-interleaved" 8-byte units [k/4][128 rows] = {k, k+1, k+2, k+3} of one row; the 4(k) x 8(rows)
+// k-contiguous: swizzled row-major image (rm_off).
+// r-contiguous: "quad-interleaved" 8-byte units [k/4][ROWS] = {k, k+1, k+2, k+3} of one row; the 4(k) x 8(rows)
 // register block is transposed in registers (two 16-bit merges per output dword) and leaves as four ds_write_b128.
-template <bool TRANS>
+template <bool TRANS, int ROWS>
 __device__ __forceinline__ void stage_store(const uint4 (&reg)[4], char* lds, int t) {
   if (!TRANS) {
-    const int r = t >> 3, kc = (t & 7) * 8;
+    const int r = t >> 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(lds + ((r + 32 * i) * RM_STRIDE + kc) * 2) = reg[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(lds + rm_off(r + (ROWS / 4) * i, t & 7)) = reg[i];
   } else {
-    const int kq = t >> 4, r0 = (t & 15) * 8;
+    const int kq = t / (ROWS / 8), r0 = (t % (ROWS / 8)) * 8;
     uint32_t in[4][4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) { in[kk][0] = reg[kk].x; in[kk][1] = reg[kk].y; in[kk][2] = reg[kk].z; in[kk][3] = reg[kk].w; }
@@ -119,22 +157,22 @@ __device__ __forceinline__ void stage_store(const uint4 (&reg)[4], char* lds, in
       o[4 * w + 2] = (in[0][w] >> 16) | (in[1][w] & 0xffff0000u);
       o[4 * w + 3] = (in[2][w] >> 16) | (in[3][w] & 0xffff0000u);
     }
-    uint4* dst = reinterpret_cast<uint4*>(lds + ((size_t)(kq * BM + r0)) * 8);
+    uint4* dst = reinterpret_cast<uint4*>(lds + ((size_t)(kq * ROWS + r0)) * 8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dst[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
   }
 }
 
 // ---- LDS -> MFMA fragment: row `row` of the tile, k16-step ks (0..3), lane group g; slot (g,j) <-> k = 16ks+8g+j --
-template <bool TRANS>
+template <bool TRANS, int ROWS>
 __device__ __forceinline__ bf16x8 frag_load(const char* lds, int row, int ks, int g) {
   if (!TRANS) {
-    return *reinterpret_cast<const bf16x8*>(lds + (row * RM_STRIDE + ks * 16 + g * 8) * 2);
+    return *reinterpret_cast<const bf16x8*>(lds + rm_off(row, ks * 2 + g));
   } else {
     const int q0 = ks * 4 + g * 2;
     union { uint2 h[2]; bf16x8 v; } u;
-    u.h[0] = *reinterpret_cast<const uint2*>(lds + ((size_t)(q0 * BM + row)) * 8);
-    u.h[1] = *reinterpret_cast<const uint2*>(lds + ((size_t)((q0 + 1) * BM + row)) * 8);
+    u.h[0] = *reinterpret_cast<const uint2*>(lds + ((size_t)(q0 * ROWS + row)) * 8);
+    u.h[1] = *reinterpret_cast<const uint2*>(lds + ((size_t)((q0 + 1) * ROWS + row)) * 8);
     return u.v;
   }
 }
@@ -243,12 +281,13 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
   }
 }
 
-template <bool A_T, bool B_T>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][A|B], SMEM_BYTES
+template <class CF, bool A_T, bool B_T, int DBG = 0>
+__global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
+  constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][A|B]
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % CF::WM, wn = wave / CF::WM;
   const int l31 = lane & 31, g = lane >> 5;
 
   // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of tile ids so that
@@ -265,11 +304,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
   const int64_t k_begin = (int64_t)split * p.k_per_split;
   const int64_t k_end = (k_begin + p.k_per_split < p.K) ? (k_begin + p.k_per_split) : p.K;
 
-  f32x16 acc[2][2];  // [n-subtile i][m-subtile j]
+  f32x16 acc[TN][TM];  // [n-subtile i][m-subtile j]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -280,91 +319,121 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
   const bool b_fast = p.b_vec && (!B_T || n0 + BN <= p.N);
   const bf16_t* pa[4];
   const bf16_t* pb[4];
-  fast_ptrs<A_T>(pa, p.A, p.lda, m0, p.M, k_begin, t);
-  fast_ptrs<B_T>(pb, p.B, p.ldb, n0, p.N, k_begin, t);
-  // Two register sets: while tile kt is multiplied out of LDS, tile kt+1 sits in one set (written to the other LDS
-  // buffer after the MFMAs) and the global loads of tile kt+2 are already in flight into the other set -> a load has
-  // two full K-tile periods (~1000+ cycles) to land before its ds_write needs it.
-  uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+  fast_ptrs<A_T, BM>(pa, p.A, p.lda, m0, p.M, k_begin, t);
+  fast_ptrs<B_T, BN>(pb, p.B, p.ldb, n0, p.N, k_begin, t);
+  uint4 ra0[4], rb0[4], ra1[CF::DEEP ? 4 : 1], rb1[CF::DEEP ? 4 : 1];
   auto load_tile = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
     const int64_t k0 = k_begin + (int64_t)kt * BK;
     if (a_fast && kt < nk_full) fast_load<A_T>(ra, pa, p.lda);
-    else stage_load<A_T>(ra, p.A, p.lda, m0, p.M, k0, k_end, p.a_vec, t);
+    else stage_load<A_T, BM>(ra, p.A, p.lda, m0, p.M, k0, k_end, p.a_vec, t);
     if (b_fast && kt < nk_full) fast_load<B_T>(rb, pb, p.ldb);
-    else stage_load<B_T>(rb, p.B, p.ldb, n0, p.N, k0, k_end, p.b_vec, t);
+    else stage_load<B_T, BN>(rb, p.B, p.ldb, n0, p.N, k0, k_end, p.b_vec, t);
   };
   auto store_tile = [&](const uint4 (&ra)[4], const uint4 (&rb)[4], char* buf) {
-    stage_store<A_T>(ra, buf, t);
-    stage_store<B_T>(rb, buf + OPER_BYTES, t);
+    stage_store<A_T, BM>(ra, buf, t);
+    stage_store<B_T, BN>(rb, buf + CF::A_BYTES, t);
   };
   auto compute = [&](const char* cur) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[TM], fb[TN];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fa[j] = frag_load<A_T>(cur, wm * 64 + j * 32 + l31, ks, g);
+      for (int j = 0; j < TM; ++j) fa[j] = frag_load<A_T, BM>(cur, wm * (TM * 32) + j * 32 + l31, ks, g);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fb[i] = frag_load<B_T>(cur + OPER_BYTES, wn * 64 + i * 32 + l31, ks, g);
+      for (int i = 0; i < TN; ++i) fb[i] = frag_load<B_T, BN>(cur + CF::A_BYTES, wn * (TN * 32) + i * 32 + l31, ks, g);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
     }
   };
   char* buf0 = smem;
-  char* buf1 = smem + 2 * OPER_BYTES;
-  if (nk > 0) {
-    load_tile(0, ra0, rb0);
-    store_tile(ra0, rb0, buf0);
-    if (nk > 1) load_tile(1, ra1, rb1);
-  }
-  __syncthreads();
-  int kt = 0;
-  if (a_fast && b_fast) {
-    // steady state, no conditionals inside: the compiler can then count the 8 newer loads and wait with vmcnt(8)
-    // (a conditional prefetch forces s_waitcnt vmcnt(0) at the join and serialises load latency with the MFMAs)
-    while (kt + 3 < nk_full) {
-      fast_load<A_T>(ra0, pa, p.lda);
-      fast_load<B_T>(rb0, pb, p.ldb);
-      __builtin_amdgcn_sched_barrier(0);  // issue the prefetch BEFORE the MFMAs (the scheduler would sink it)
-      compute(buf0);
-      __builtin_amdgcn_sched_barrier(0);  // keep the ds_writes (and their vmcnt wait) BEHIND the MFMAs
-      store_tile(ra1, rb1, buf1);
-      __syncthreads();
-      fast_load<A_T>(ra1, pa, p.lda);
-      fast_load<B_T>(rb1, pb, p.ldb);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(buf1);
-      __builtin_amdgcn_sched_barrier(0);
+  char* buf1 = smem + CF::BUF_BYTES;
+  if constexpr (CF::DEEP) {
+    if (nk > 0) {
+      load_tile(0, ra0, rb0);
       store_tile(ra0, rb0, buf0);
-      __syncthreads();
-      kt += 2;
+      if (nk > 1) load_tile(1, ra1, rb1);
     }
-  }
-  for (; kt < nk; kt += 2) {   // remaining (<= 3 full tiles + ragged tail) and the generic / guarded path
-    if (kt + 2 < nk) load_tile(kt + 2, ra0, rb0);
-    compute(buf0);
-    if (kt + 1 < nk) store_tile(ra1, rb1, buf1);
     __syncthreads();
-    if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) load_tile(kt + 3, ra1, rb1);
-    compute(buf1);
-    if (kt + 2 < nk) store_tile(ra0, rb0, buf0);
+    int kt = 0;
+    if (a_fast && b_fast) {
+      // steady state, no conditionals inside: the compiler can then count the 8 newer loads and wait with vmcnt(8)
+      // (a conditional prefetch forces s_waitcnt vmcnt(0) at the join and serialises load latency with the MFMAs)
+      while (kt + 3 < nk_full) {
+        // DBG (ablation builds only): 1 = no global loads / LDS writes, 2 = no MFMAs, 4 = no barriers
+        if (!(DBG & 1)) { fast_load<A_T>(ra0, pa, p.lda); fast_load<B_T>(rb0, pb, p.ldb); }
+        __builtin_amdgcn_sched_barrier(0);  // issue the prefetch BEFORE the MFMAs (the scheduler would sink it)
+        if (!(DBG & 2)) compute(buf0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the ds_writes (and their vmcnt wait) BEHIND the MFMAs
+        if (!(DBG & 1)) store_tile(ra1, rb1, buf1);
+        if (!(DBG & 4)) __syncthreads();
+        if (!(DBG & 1)) { fast_load<A_T>(ra1, pa, p.lda); fast_load<B_T>(rb1, pb, p.ldb); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 2)) compute(buf1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 1)) store_tile(ra0, rb0, buf0);
+        if (!(DBG & 4)) __syncthreads();
+        kt += 2;
+      }
+    }
+    for (; kt < nk; kt += 2) {   // remaining (<= 3 full tiles + ragged tail) and the generic / guarded path
+      if (kt + 2 < nk) load_tile(kt + 2, ra0, rb0);
+      compute(buf0);
+      if (kt + 1 < nk) store_tile(ra1, rb1, buf1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) load_tile(kt + 3, ra1, rb1);
+      compute(buf1);
+      if (kt + 2 < nk) store_tile(ra0, rb0, buf0);
+      __syncthreads();
+    }
+  } else {
+    // one register set: tile kt+1 is loaded while tile kt is multiplied (128 accumulator + 24 fragment registers per
+    // lane leave no room for a second set under the 256-register / 2-waves-per-SIMD budget of a 512-thread workgroup)
+    if (nk > 0) { load_tile(0, ra0, rb0); store_tile(ra0, rb0, buf0); }
     __syncthreads();
+    int kt = 0;
+    if (a_fast && b_fast) {
+      while (kt + 2 < nk_full) {
+        fast_load<A_T>(ra0, pa, p.lda); fast_load<B_T>(rb0, pb, p.ldb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(ra0, rb0, buf1);
+        __syncthreads();
+        fast_load<A_T>(ra0, pa, p.lda); fast_load<B_T>(rb0, pb, p.ldb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(ra0, rb0, buf0);
+        __syncthreads();
+        kt += 2;
+      }
+    }
+    for (; kt < nk; ++kt) {
+      char* cur = (kt & 1) ? buf1 : buf0;
+      char* nxt = (kt & 1) ? buf0 : buf1;
+      const bool more = kt + 1 < nk;
+      if (more) load_tile(kt + 1, ra0, rb0);
+      compute(cur);
+      if (more) store_tile(ra0, rb0, nxt);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue --------------------------------------------------------------------------------------
-  // acc[i][j][r] holds (m = 32j + l31, n = 32i + 8*(r>>2) + 4*g + (r&3)) of the wave's 64x64 patch.  Each
-  // 32-row half is transposed through a wave-private fp32 LDS patch [32][64+4] so that a lane then owns 8
+  // acc[i][j][r] holds (m = 32j + l31, n = 32i + 8*(r>>2) + 4*g + (r&3)) of the wave's (TM*32) x 64 patch.  Each
+  // 32-row slab is transposed through a wave-private fp32 LDS patch [32][64+4] so that a lane then owns 8
   // consecutive n of one row: 16-byte aux loads / C stores, and the (large) epilogue body is emitted once.
   constexpr int PATCH_LD = 68;  // floats per patch row (272 B: 16-B aligned, 4-bank skew per row)
   float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PATCH_LD);
+  static_for<TM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    __syncthreads();  // operand buffers (j = 0) / previous slab (j > 0) no longer read
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    __syncthreads();  // operand buffers (j = 0) / previous half (j = 1) no longer read
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq)
         *reinterpret_cast<float4*>(patch + l31 * PATCH_LD + 32 * i + 8 * rq + 4 * g) =
@@ -376,7 +445,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
     for (int it = 0; it < 4; ++it) {
       const int item = it * 64 + lane;
       const int row = item >> 3, cg = item & 7;
-      const int64_t m = m0 + wm * 64 + j * 32 + row;
+      const int64_t m = m0 + wm * (TM * 32) + j * 32 + row;
       const int64_t n = n0 + wn * 64 + cg * 8;
       if (m < p.M && n < p.N) {
         const float4 lo = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8);
@@ -386,7 +455,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmKArgs p) {
         else epilogue_oct<false>(p, m, n, v, split);
       }
     }
-  }
+  });
 }
 
 // split-K reduction: C[m,n] (+)= sum_s ws[s][m][n]
@@ -405,9 +474,50 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* C, int6
   }
 }
 
+int g_gemm_variant = -1;   // 0 auto, 2 force S (128^2), 3 force L (256^2), 11..16 ablation builds of the S NT kernel
+inline int gemm_variant() {
+  if (g_gemm_variant < 0) {
+    const char* e = getenv("DVLA_GEMM_VARIANT");
+    g_gemm_variant = e ? atoi(e) : 0;
+  }
+  return g_gemm_variant;
+}
+
 inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+template <class CF, bool A_T, bool B_T, int DBG = 0>
+void launch_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = &gemm_kernel<CF, A_T, B_T, DBG>;
+  if (!attr_set) {  // > 64 KiB of LDS per workgroup needs the opt-in (160 KiB per CU on gfx950)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM_BYTES);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)split_k, 1), block(CF::NT, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, CF::SMEM_BYTES, stream, a);
+}
+
+template <class CF>
+void launch_cfg(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
+  a.tiles_m = (int)((a.M + CF::BM - 1) / CF::BM);
+  a.tiles_n = (int)((a.N + CF::BN - 1) / CF::BN);
+  switch (combo) {
+    case 0: launch_one<CF, false, false>(a, split_k, stream); break;
+    case 1: launch_one<CF, false, true>(a, split_k, stream); break;
+    case 2: launch_one<CF, true, false>(a, split_k, stream); break;
+    default: launch_one<CF, true, true>(a, split_k, stream); break;
+  }
+}
+
+// fraction of workgroup slots kept busy when `tiles` workgroups run `slots` at a time
+inline double fill(int64_t tiles, int64_t slots) {
+  const int64_t rounds = (tiles + slots - 1) / slots;
+  return (double)tiles / (double)(rounds * slots);
+}
+
 }  // namespace
+
+extern "C" void dvla_set_gemm_variant(int v) { g_gemm_variant = v; }
 
 extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -455,24 +565,27 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   a.epi_vec = 1;  // bias / split-K workspace vector access
   if (q->bias && !aligned(q->bias, 16)) a.epi_vec = 0;
   if (split_k > 1 && ((q->N & 3) != 0 || !aligned(q->workspace, 16))) a.epi_vec = 0;
-  a.tiles_m = (int)((q->M + BM - 1) / BM);
-  a.tiles_n = (int)((q->N + BN - 1) / BN);
 
-  static bool attr_set = false;
-  if (!attr_set) {  // > 64 KiB of LDS per workgroup needs the opt-in (160 KiB per CU on gfx950)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    attr_set = true;
-  }
-  dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)split_k, 1), block(NTHREADS, 1, 1);
   const int combo = (q->a_trans ? 2 : 0) | (q->b_trans ? 1 : 0);
-  switch (combo) {
-    case 0: hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, SMEM_BYTES, stream, a); break;
-    case 1: hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, SMEM_BYTES, stream, a); break;
-    case 2: hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, SMEM_BYTES, stream, a); break;
-    default: hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, SMEM_BYTES, stream, a); break;
+  const int variant = gemm_variant();
+  if (variant >= 11 && combo == 0) {   // ablation builds of the S NT kernel (results are garbage by design)
+    a.tiles_m = (int)((a.M + CfgS::BM - 1) / CfgS::BM);
+    a.tiles_n = (int)((a.N + CfgS::BN - 1) / CfgS::BN);
+    switch (variant - 10) {
+      case 1: launch_one<CfgS, false, false, 1>(a, split_k, stream); break;
+      case 2: launch_one<CfgS, false, false, 2>(a, split_k, stream); break;
+      case 4: launch_one<CfgS, false, false, 4>(a, split_k, stream); break;
+      case 5: launch_one<CfgS, false, false, 5>(a, split_k, stream); break;
+      default: launch_one<CfgS, false, false, 6>(a, split_k, stream); break;
+    }
+  } else {
+    // tile choice.  Measured on MI355X (profiles/r01_gemm_variants.txt): the L (256^2, 1 workgroup / CU, one staging
+    // set, a few spilled address registers) kernel is 5-30 % SLOWER than S on every DreamVLA shape and on 8192^3
+    // (805 vs 880 TFLOP/s), so S is the default and L is kept selectable (variant 3) for the next tuning round.
+    bool use_l = false;
+    if (variant == 3 && q->M >= 256 && q->N >= 256) use_l = true;
+    if (use_l) launch_cfg<CfgL>(a, combo, split_k, stream);
+    else launch_cfg<CfgS>(a, combo, split_k, stream);
   }
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;

@@ -63,6 +63,9 @@ typedef struct dvla_gemm_params {
   int32_t split_k; void* workspace;
 } dvla_gemm_params;
 int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
+/* kernel variant: 0 = register-staged operands (2-deep prefetch), 1 = LDS-DMA (global_load_lds) for k-contiguous
+ * operands.  Same results bit for bit; default from env DVLA_GEMM_VARIANT (0). */
+void dvla_set_gemm_variant(int variant);
 
 /* ---------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (rows x cols, bf16 in/out, fp32 statistics).

@@ -43,16 +43,34 @@ def mfma_32x32x16(a, b, c):
 # ---------------------------------------------------------------------------------------------------
 # GEMM tile model (gemm.hip): 128x128x64 tile, both operand layouts
 # ---------------------------------------------------------------------------------------------------
-BM, BK, RM_STRIDE = 128, 64, 72
+BM, BK = 128, 64
+
+
+def rm_off(row, octet):  # element offset of k-octet `octet` of row `row` in the swizzled row-major image (gemm.hip rm_off / 2)
+    return row * 64 + ((octet ^ ((row >> 1) & 7)) << 3)
 
 
 def gemm_stage_rm(tile):  # tile[row][k] (128 x 64)  ->  LDS element array (row-major, padded)
-    lds = np.zeros(BM * RM_STRIDE)
+    lds = np.zeros(BM * BK)
     for t in range(256):
         r, kc = t >> 3, (t & 7) * 8
         for i in range(4):
             rr = r + 32 * i
-            lds[rr * RM_STRIDE + kc: rr * RM_STRIDE + kc + 8] = tile[rr, kc:kc + 8]
+            o = rm_off(rr, t & 7)
+            lds[o:o + 8] = tile[rr, kc:kc + 8]
+    return lds
+
+
+def gemm_stage_dma(tile):  # LDS-DMA image: wave w, chunk c = 4w+i, lane -> LDS byte (c*1024 + lane*16), global octet swizzled
+    lds = np.zeros(BM * BK)
+    for wave in range(4):
+        for i in range(4):
+            c = wave * 4 + i
+            for lane in range(64):
+                rl = c * 8 + (lane >> 3)
+                octet = (lane & 7) ^ ((rl >> 1) & 7)
+                dst = (c * 1024 + lane * 16) // 2
+                lds[dst:dst + 8] = tile[rl, octet * 8: octet * 8 + 8]
     return lds
 
 
@@ -74,9 +92,31 @@ def gemm_frag_rm(lds, row_base, ks):
     f = np.zeros((64, 8))
     for l in range(64):
         row, g = row_base + (l & 31), l >> 5
-        off = row * RM_STRIDE + ks * 16 + g * 8
+        off = rm_off(row, ks * 2 + g)
         f[l] = lds[off:off + 8]
     return f
+
+
+def test_gemm_dma_image_equals_register_staged_image():
+    rng = np.random.default_rng(3)
+    tile = rng.integers(-9, 10, (BM, BK)).astype(np.float64)
+    np.testing.assert_array_equal(gemm_stage_dma(tile), gemm_stage_rm(tile))
+
+
+def test_gemm_rm_image_bank_conflict_free():
+    # ds_read_b128 is served in 4 groups of 16 lanes; within a group every 4-dword access must hit distinct banks (64 banks)
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for base in (0, 32, 64, 96):
+        for ks in range(4):
+            for g in range(2):
+                for grp in groups:
+                    banks = set()
+                    for l in grp:
+                        dw = rm_off(base + l, ks * 2 + g) * 2 // 4
+                        for d in range(4):
+                            banks.add((dw + d) % 64)
+                    assert len(banks) == 64
 
 
 def gemm_frag_quad(lds, row_base, ks):
