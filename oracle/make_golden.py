@@ -197,6 +197,17 @@ def main():
     mf = module_fixtures()
     mf["source"] = src
     torch.save(mf, os.path.join(GOLD, "modules.pt"))
+    # state_dict surface (keys + shapes) of the shipped CALVIN finetune configuration at full size
+    import json
+    cfgC = dict(finetune_type="calvin", sequence_length=7, num_resampler_query=16, num_obs_token_per_image=9,
+                action_pred_steps=3, transformer_layers=24, hidden_dim=1024, transformer_heads=16, phase="finetune",
+                obs_pred=True, depth_pred=True, sam_feat_pred=True, use_dit_head=True, attn_implementation="sdpa")
+    dv = ref_loader.ref_module("models.dreamvla_model")
+    mC = dv.DreamVLA(clip_device="cpu", vit_checkpoint_path=fake_mae_ckpt(), **cfgC)
+    with open(os.path.join(GOLD, "state_dict_surface_C.json"), "w") as f:
+        json.dump({"cfg": cfgC, "source": src, "trainable": sorted(n for n, p in mC.named_parameters() if p.requires_grad),
+                   "entries": {k: list(v.shape) for k, v in mC.state_dict().items()}}, f)
+    del mC
     for name in FULL_CFGS:
         fx = full_fixture(name)
         fx["source"] = src
