@@ -458,6 +458,211 @@ __global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
   });
 }
 
+// ====================================================================================================
+// Ring kernel: LDS-DMA operand staging (global_load_lds_dwordx4) through a 4-stage LDS ring, 8 waves, big tiles.
+//
+//   stage = K-slice of 32: (BM + BN) x 32 bf16.  Three stages are always in flight while one is multiplied; a wave
+//   waits for ITS pieces of stage s with a counted s_waitcnt vmcnt(2 * chunks-per-wave), then ONE raw s_barrier makes
+//   every wave's pieces visible and proves everybody is done with stage s-1, whose buffer is immediately refilled
+//   with stage s+3.  No VGPR staging, no ds_write, no vmcnt(0) in the steady state.
+//   k-contiguous operand : LDS rows of 64 B (4 slots of 16 B), k-octet o of row r in slot o ^ ((r>>2)&3)
+//                          (the swizzle is applied on the per-lane GLOBAL address; the LDS image is lane-linear as
+//                          LDS-DMA requires), fragments by conflict-free ds_read_b128.
+//   r-contiguous operand : copied as it is, [32 k][ROWS] (16-B piece (k, ro) in slot ro ^ 4*(k&3) of its k-row), and read
+//                          with the hardware transpose ds_read_b64_tr_b16 (lane i of a 16-lane group receives 4 consecutive k
+//                          of row i; semantics probed on hardware: tests/probes/tr_probe.hip) -- so Conv1D weights and
+//                          the weight-gradient GEMMs need no register transpose either.
+// Requirements (host falls back to the register-staged kernel otherwise): 16-B-vectorisable operands, K-range % 32 == 0,
+// r-contiguous operands with rows % tile == 0.
+// ====================================================================================================
+template <int WM_, int WN_, int TM_, int TN_>
+struct RCfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVES = WM * WN, NT = NWAVES * 64;
+  static constexpr int BKS = 32, NS = 4;
+  static constexpr int A_BYTES = BM * BKS * 2, B_BYTES = BN * BKS * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int SMEM_BYTES = NS * STAGE_BYTES;
+  static constexpr int A_CHUNKS = A_BYTES / 1024, B_CHUNKS = B_BYTES / 1024;
+  static constexpr int CPW = (A_CHUNKS + B_CHUNKS) / NWAVES;   // DMA instructions per wave and stage
+  static_assert((A_CHUNKS + B_CHUNKS) % NWAVES == 0, "chunks must divide evenly over the waves");
+  static_assert(TN == 2, "epilogue patch is 64 columns wide");
+  static_assert(NWAVES * 32 * 68 * 4 <= SMEM_BYTES, "epilogue patches must fit");
+};
+using RCfgL = RCfg<2, 4, 4, 2>;   // 256 x 256, 128 KiB ring
+using RCfgM = RCfg<4, 2, 2, 2>;   // 256 x 128,  96 KiB ring
+using RCfgS = RCfg<2, 2, 2, 2>;   // 128 x 128,  64 KiB ring, 4 waves, 2 workgroups / CU
+
+// per-lane global source address of chunk c of an operand tile at k0 (the LDS destination of lane l is chunk base + 16 l)
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ const bf16_t* dma_src(const bf16_t* __restrict__ P, int64_t ld, int64_t row0, int64_t rows,
+                                                 int64_t k0, int c, int lane) {
+  if (!TRANS) {   // chunk c = rows 16c .. 16c+15, four 16-B slots per row
+    const int rl = c * 16 + (lane >> 2);
+    const int o = (lane & 3) ^ ((rl >> 2) & 3);
+    int64_t row = row0 + rl;
+    row = row < rows ? row : rows - 1;
+    return P + row * ld + k0 + o * 8;
+  } else {        // chunk c = 64 consecutive 16-B pieces of the [k][ROWS] image
+    constexpr int PPR = ROWS / 8;   // pieces per k-row
+    const int piece = c * 64 + lane;
+    const int k = piece / PPR, slot = piece % PPR;
+    const int ro = slot ^ (4 * (k & 3));
+    return P + (k0 + k) * ld + row0 + ro * 8;
+  }
+}
+
+// One LDS-DMA instruction, issued from inline asm so that hipcc does not count it (it would otherwise put an
+// s_waitcnt vmcnt(0) in front of the next ds_read and serialise the ring).  M0 (LDS base of the transfer) is saved and
+// restored inside the statement (cdna guide section 5.7).  lds_dst must be wave-uniform.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// fragment of the 32-row sub-tile starting at tile row `rbase`, k16-step ks (0..1) of the stage
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ bf16x8 ring_frag(const char* lds_oper, int rbase, int ks, int lane) {
+  if (!TRANS) {
+    const int row = rbase + (lane & 31), o = 2 * ks + (lane >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds_oper + row * 64 + ((o ^ ((row >> 2) & 3)) << 4));
+  } else {
+    const int gi = lane >> 4, c = lane & 15;
+    const int r = rbase + 16 * (gi & 1) + 4 * (c & 3);                 // first of the 4 rows this lane FETCHES
+    union { s16x4 h[2]; bf16x8 v; } u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 16 * ks + 8 * (gi >> 1) + 4 * h + (c >> 2);       // k-row this lane fetches from
+      const int byte = k * (ROWS * 2) + ((((r >> 3) ^ (4 * (c >> 2)))) << 4) + (r & 7) * 2;
+      u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_oper + byte));
+    }
+    return u.v;
+  }
+}
+
+template <class RC, bool A_T, bool B_T>
+__global__ __launch_bounds__(RC::NT) void gemm_ring_kernel(GemmKArgs p) {
+  constexpr int BM = RC::BM, BN = RC::BN, TM = RC::TM, TN = RC::TN, CPW = RC::CPW, NS = RC::NS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave % RC::WM, wn = wave / RC::WM;
+  const int l31 = lane & 31, g = lane >> 5;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int tile;
+  {
+    const int b = blockIdx.x, q = ntiles / 8, r = ntiles % 8, xcd = b % 8, idx = b / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int split = blockIdx.y;
+  const int64_t k_begin = (int64_t)split * p.k_per_split;
+  const int64_t k_end = (k_begin + p.k_per_split < p.K) ? (k_begin + p.k_per_split) : p.K;
+  const int ns = (int)((k_end - k_begin) / RC::BKS);
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-wave DMA plan: CPW chunks per stage, fixed operand / chunk per slot i, per-lane source pointers that advance by
+  // one stage (32 k) per issue; destinations are wave-uniform byte offsets inside a stage buffer.
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const bf16_t* src[CPW];
+  int64_t step[CPW];
+  uint32_t dst[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int q = wave * CPW + i;   // wave-uniform
+    if (q < RC::A_CHUNKS) {
+      src[i] = dma_src<A_T, BM>(p.A, p.lda, m0, p.M, k_begin, q, lane);
+      step[i] = A_T ? (int64_t)RC::BKS * p.lda : (int64_t)RC::BKS;
+      dst[i] = (uint32_t)(q * 1024);
+    } else {
+      src[i] = dma_src<B_T, BN>(p.B, p.ldb, n0, p.N, k_begin, q - RC::A_CHUNKS, lane);
+      step[i] = B_T ? (int64_t)RC::BKS * p.ldb : (int64_t)RC::BKS;
+      dst[i] = (uint32_t)(RC::A_BYTES + (q - RC::A_CHUNKS) * 1024);
+    }
+  }
+  auto issue = [&](int s) {
+    const uint32_t st = smem_base + (uint32_t)((s % NS) * RC::STAGE_BYTES);
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      glds16(src[i], __builtin_amdgcn_readfirstlane(st + dst[i]));
+      src[i] += step[i];
+    }
+  };
+  auto compute = [&](const char* st) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[j] = ring_frag<A_T, BM>(st, wm * (TM * 32) + j * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[i] = ring_frag<B_T, BN>(st + RC::A_BYTES, wn * (TN * 32) + i * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (ns > 0) issue(0);
+  if (ns > 1) issue(1);
+  if (ns > 2) issue(2);
+  for (int s = 0; s < ns; ++s) {
+    // wait for this wave's pieces of stage s: the (up to two) younger stages stay in flight
+    if (s + 2 < ns) { if (CPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else if (s + 1 < ns) { if (CPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 3 < ns) issue(s + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(smem + (s % NS) * RC::STAGE_BYTES);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue (same as the register-staged kernel) ----
+  constexpr int PATCH_LD = 68;
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PATCH_LD);
+  static_for<TM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        *reinterpret_cast<float4*>(patch + l31 * PATCH_LD + 32 * i + 8 * rq + 4 * g) =
+            make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
+    __syncthreads();
+    const bool tile_full = (n0 + wn * 64 + 64 <= p.N) && p.c_vec && p.aux_vec && p.epi_vec;
+#pragma unroll 2
+    for (int it = 0; it < 4; ++it) {
+      const int item = it * 64 + lane;
+      const int row = item >> 3, cg = item & 7;
+      const int64_t m = m0 + wm * (TM * 32) + j * 32 + row;
+      const int64_t n = n0 + wn * 64 + cg * 8;
+      if (m < p.M && n < p.N) {
+        const float4 lo = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (tile_full) epilogue_oct<true>(p, m, n, v, split);
+        else epilogue_oct<false>(p, m, n, v, split);
+      }
+    }
+  });
+}
+
 // split-K reduction: C[m,n] (+)= sum_s ws[s][m][n]
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* C, int64_t ldc, int c_f32, int accumulate,
                                      int64_t M, int64_t N, int splits) {
@@ -474,7 +679,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* C, int6
   }
 }
 
-int g_gemm_variant = -1;   // 0 auto, 2 force S (128^2), 3 force L (256^2), 11..16 ablation builds of the S NT kernel
+int g_gemm_variant = -1;   // 0 auto; force: 2 S, 3 L (register-staged), 4 / 5 / 6 ring 256^2 / 256x128 / 128^2; 11..16 ablations
 inline int gemm_variant() {
   if (g_gemm_variant < 0) {
     const char* e = getenv("DVLA_GEMM_VARIANT");
@@ -507,6 +712,38 @@ void launch_cfg(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
     case 2: launch_one<CF, true, false>(a, split_k, stream); break;
     default: launch_one<CF, true, true>(a, split_k, stream); break;
   }
+}
+
+template <class RC, bool A_T, bool B_T>
+void launch_ring_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = &gemm_ring_kernel<RC, A_T, B_T>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RC::SMEM_BYTES);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)split_k, 1), block(RC::NT, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, RC::SMEM_BYTES, stream, a);
+}
+template <class RC>
+void launch_ring(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
+  a.tiles_m = (int)((a.M + RC::BM - 1) / RC::BM);
+  a.tiles_n = (int)((a.N + RC::BN - 1) / RC::BN);
+  switch (combo) {
+    case 0: launch_ring_one<RC, false, false>(a, split_k, stream); break;
+    case 1: launch_ring_one<RC, false, true>(a, split_k, stream); break;
+    case 2: launch_ring_one<RC, true, false>(a, split_k, stream); break;
+    default: launch_ring_one<RC, true, true>(a, split_k, stream); break;
+  }
+}
+template <class RC>
+bool ring_ok(const GemmKArgs& a, int combo) {
+  if (!a.a_vec || !a.b_vec) return false;
+  if (a.K % 32 != 0 || a.k_per_split % 32 != 0) return false;
+  if (a.M < RC::BM || a.N < RC::BN) return false;
+  if ((combo & 2) && (a.M % RC::BM != 0)) return false;   // r-contiguous A: whole row panels only
+  if ((combo & 1) && (a.N % RC::BN != 0)) return false;
+  return true;
 }
 
 // fraction of workgroup slots kept busy when `tiles` workgroups run `slots` at a time
@@ -582,10 +819,32 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     // tile choice.  Measured on MI355X (profiles/r01_gemm_variants.txt): the L (256^2, 1 workgroup / CU, one staging
     // set, a few spilled address registers) kernel is 5-30 % SLOWER than S on every DreamVLA shape and on 8192^3
     // (805 vs 880 TFLOP/s), so S is the default and L is kept selectable (variant 3) for the next tuning round.
-    bool use_l = false;
-    if (variant == 3 && q->M >= 256 && q->N >= 256) use_l = true;
-    if (use_l) launch_cfg<CfgL>(a, combo, split_k, stream);
-    else launch_cfg<CfgS>(a, combo, split_k, stream);
+    // Configuration choice (measured on MI355X, profiles/r01_gemm_variants.txt): the LDS-DMA ring kernels beat the
+    // register-staged S kernel whenever they apply; among them pick max(relative tile speed x chip fill): the 256^2
+    // ring is ~1.25x the 128^2 one per tile, the 256x128 one ~1.12x, but they run 256 workgroups at a time, not 512.
+    int choice = 0;   // 0 = register-staged S (always valid), 1 = ring L, 2 = ring M, 3 = ring S, 4 = register-staged L
+    if (variant == 0) {
+      double best = 0.0;
+      if (ring_ok<RCfgS>(a, combo)) { best = fill(((q->M + 127) / 128) * ((q->N + 127) / 128) * split_k, 512); choice = 3; }
+      if (ring_ok<RCfgM>(a, combo)) {
+        const double e = 1.12 * fill(((q->M + 255) / 256) * ((q->N + 127) / 128) * split_k, 256);
+        if (e > best) { best = e; choice = 2; }
+      }
+      if (ring_ok<RCfgL>(a, combo)) {
+        const double e = 1.25 * fill(((q->M + 255) / 256) * ((q->N + 255) / 256) * split_k, 256);
+        if (e > best) { best = e; choice = 1; }
+      }
+    } else if (variant == 3 && q->M >= 256 && q->N >= 256) choice = 4;
+    else if (variant == 4 && ring_ok<RCfgL>(a, combo)) choice = 1;
+    else if (variant == 5 && ring_ok<RCfgM>(a, combo)) choice = 2;
+    else if (variant == 6 && ring_ok<RCfgS>(a, combo)) choice = 3;
+    switch (choice) {
+      case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;
+      case 2: launch_ring<RCfgM>(a, combo, split_k, stream); break;
+      case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
+      case 4: launch_cfg<CfgL>(a, combo, split_k, stream); break;
+      default: launch_cfg<CfgS>(a, combo, split_k, stream); break;
+    }
   }
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
