@@ -37,68 +37,128 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // ---- fast transcendental helpers (epilogue-resident: they must cost a handful of VALU ops, not a libm call) ----
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }            // v_rcp_f32 (1 ulp)
 __device__ __forceinline__ float fast_exp(float x) { return fast_exp2(x * 1.4426950408889634f); }  // e^x
-// erf by Abramowitz-Stegun 7.1.26: |error| <= 1.5e-7 (three orders below bf16 resolution)
-__device__ __forceinline__ float fast_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = fast_rcp(fmaf(0.3275911f, ax, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float r = 1.0f - poly * t * fast_exp(-ax * ax);
-  return copysignf(r, x);
+// Activations.  The GEMM epilogue runs them on PAIRS (f32x2) so that the polynomial parts issue as packed fp32
+// (v_pk_fma_f32 / v_pk_mul_f32: two values per lane and instruction); the scalar forms wrap the pair forms.
+//   Phi(x) = 0.5 (1 + erf(x / sqrt 2)) by Abramowitz-Stegun 7.1.26 in its erfc form:
+//     z = |x| / sqrt 2, t = 1 / (1 + p z), q = (a1 t + ... + a5 t^5) e^{-z^2}  (= erfc z, |abs error| <= 1.5e-7)
+//     Phi(x) = x >= 0 ? 1 - q/2 : q/2          -- the negative tail keeps its RELATIVE accuracy (no 1 - (1 - q))
+//   gelu_erf(x) = x Phi(x);  gelu_erf'(x) = Phi(x) + x phi(x) with phi(x) = e^{-z^2} / sqrt(2 pi): one exp serves both.
+//   gelu_tanh(x) = 0.5 x (1 + tanh u) = x sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): one exp + one rcp.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 rcp2(f32x2 v) { return f32x2{fast_rcp(v.x), fast_rcp(v.y)}; }
+__device__ __forceinline__ f32x2 exp2_2(f32x2 v) { return f32x2{fast_exp2(v.x), fast_exp2(v.y)}; }
+__device__ __forceinline__ f32x2 sel_nonneg(f32x2 x, f32x2 a, f32x2 b) {   // x >= 0 ? a : b, per component
+  return f32x2{x.x >= 0.f ? a.x : b.x, x.y >= 0.f ? a.y : b.y};
 }
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float e = fast_exp(-2.0f * fabsf(x));
-  return copysignf((1.0f - e) * fast_rcp(1.0f + e), x);
+// q = erfc(|x| / sqrt 2) and e = exp(-x^2 / 2)
+__device__ __forceinline__ void erfc_parts(f32x2 x, f32x2& q, f32x2& e) {
+  const f32x2 z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+  const f32x2 t = rcp2(z * 0.3275911f + 1.0f);
+  f32x2 poly = t * 1.061405429f + (-1.453152027f);
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + (-0.284496736f);
+  poly = poly * t + 0.254829592f;
+  e = exp2_2(x * x * (-0.5f * 1.4426950408889634f));
+  q = poly * t * e;
 }
-__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x) { return rcp2(exp2_2(x * (-1.4426950408889634f)) + 1.0f); }
+__device__ __forceinline__ f32x2 tanh2(f32x2 x) { return sigmoid2(x + x) * 2.0f - 1.0f; }
 
-__device__ __forceinline__ float act_fwd(float x, int act) {
+__device__ __forceinline__ f32x2 act_fwd2(f32x2 x, int act) {
   switch (act) {
-    case ACT_GELU_ERF: return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
-    case ACT_GELU_TANH: {
-      const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-      return 0.5f * x * (1.0f + fast_tanh(u));
+    case ACT_GELU_ERF: {
+      f32x2 q, e;
+      erfc_parts(x, q, e);
+      const f32x2 h = x * 0.5f * q;
+      return sel_nonneg(x, x - h, h);
     }
-    case ACT_RELU: return x > 0.f ? x : 0.f;
-    case ACT_SILU: return x * fast_sigmoid(x);
-    case ACT_QUICK_GELU: return x * fast_sigmoid(1.702f * x);
-    case ACT_TANH: return fast_tanh(x);
-    case ACT_SIGMOID: return fast_sigmoid(x);
+    case ACT_GELU_TANH: {
+      const f32x2 u2 = x * (x * x * (2.0f * 0.7978845608028654f * 0.044715f) + 2.0f * 0.7978845608028654f);
+      return x * sigmoid2(u2);
+    }
+    case ACT_RELU: return f32x2{x.x > 0.f ? x.x : 0.f, x.y > 0.f ? x.y : 0.f};
+    case ACT_SILU: return x * sigmoid2(x);
+    case ACT_QUICK_GELU: return x * sigmoid2(x * 1.702f);
+    case ACT_TANH: return tanh2(x);
+    case ACT_SIGMOID: return sigmoid2(x);
     default: return x;
   }
 }
 
 // d act(x) / dx evaluated at the pre-activation x
-__device__ __forceinline__ float act_bwd(float x, int act) {
+__device__ __forceinline__ f32x2 act_bwd2(f32x2 x, int act) {
   switch (act) {
     case ACT_GELU_ERF: {
-      const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
-      const float pdf = 0.3989422804014327f * fast_exp(-0.5f * x * x);
-      return cdf + x * pdf;
+      f32x2 q, e;
+      erfc_parts(x, q, e);
+      const f32x2 hq = q * 0.5f;
+      return sel_nonneg(x, 1.0f - hq, hq) + x * e * 0.3989422804014327f;
     }
     case ACT_GELU_TANH: {
-      const float x2 = x * x;
-      const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
-      const float t = fast_tanh(u);
-      const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
-      return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+      const f32x2 x2 = x * x;
+      const f32x2 s = sigmoid2(x * (x2 * (2.0f * 0.7978845608028654f * 0.044715f) + 2.0f * 0.7978845608028654f));
+      const f32x2 du2 = x2 * (6.0f * 0.7978845608028654f * 0.044715f) + 2.0f * 0.7978845608028654f;   // d(2u)/dx
+      return s + x * s * (1.0f - s) * du2;
     }
-    case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case ACT_RELU: return f32x2{x.x > 0.f ? 1.f : 0.f, x.y > 0.f ? 1.f : 0.f};
     case ACT_SILU: {
-      const float s = fast_sigmoid(x);
-      return s * (1.0f + x * (1.0f - s));
+      const f32x2 s = sigmoid2(x);
+      return s * (x * (1.0f - s) + 1.0f);
     }
     case ACT_QUICK_GELU: {
-      const float s = fast_sigmoid(1.702f * x);
-      return s * (1.0f + 1.702f * x * (1.0f - s));
+      const f32x2 s = sigmoid2(x * 1.702f);
+      return s * (x * 1.702f * (1.0f - s) + 1.0f);
     }
-    case ACT_TANH: { const float t = fast_tanh(x); return 1.0f - t * t; }
-    case ACT_SIGMOID: { const float s = fast_sigmoid(x); return s * (1.0f - s); }
-    default: return 1.0f;
+    case ACT_TANH: { const f32x2 t = tanh2(x); return 1.0f - t * t; }
+    case ACT_SIGMOID: { const f32x2 s = sigmoid2(x); return s * (1.0f - s); }
+    default: return f32x2{1.0f, 1.0f};
   }
 }
+// Octet forms for the GEMM epilogue: ONE switch per eight values (the compiler does not hoist the switch of act_fwd2
+// out of an unrolled loop by itself: it then costs a chain of scalar compares and branches per pair).
+template <int ACT>
+__device__ __forceinline__ void act_fwd8_c(float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const f32x2 r = act_fwd2(f32x2{v[e], v[e + 1]}, ACT);
+    v[e] = r.x; v[e + 1] = r.y;
+  }
+}
+__device__ __forceinline__ void act_fwd8(float (&v)[8], int act) {
+  switch (act) {
+    case ACT_NONE: break;
+    case ACT_GELU_ERF: act_fwd8_c<ACT_GELU_ERF>(v); break;
+    case ACT_GELU_TANH: act_fwd8_c<ACT_GELU_TANH>(v); break;
+    case ACT_RELU: act_fwd8_c<ACT_RELU>(v); break;
+    case ACT_SILU: act_fwd8_c<ACT_SILU>(v); break;
+    case ACT_QUICK_GELU: act_fwd8_c<ACT_QUICK_GELU>(v); break;
+    case ACT_TANH: act_fwd8_c<ACT_TANH>(v); break;
+    default: act_fwd8_c<ACT_SIGMOID>(v); break;
+  }
+}
+template <int ACT>
+__device__ __forceinline__ void act_bwd8_mul_c(float (&v)[8], const float (&a)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const f32x2 r = act_bwd2(f32x2{a[e], a[e + 1]}, ACT);
+    v[e] *= r.x; v[e + 1] *= r.y;
+  }
+}
+// v *= act'(a)
+__device__ __forceinline__ void act_bwd8_mul(float (&v)[8], const float (&a)[8], int act) {
+  switch (act) {
+    case ACT_NONE: break;
+    case ACT_GELU_ERF: act_bwd8_mul_c<ACT_GELU_ERF>(v, a); break;
+    case ACT_GELU_TANH: act_bwd8_mul_c<ACT_GELU_TANH>(v, a); break;
+    case ACT_RELU: act_bwd8_mul_c<ACT_RELU>(v, a); break;
+    case ACT_SILU: act_bwd8_mul_c<ACT_SILU>(v, a); break;
+    case ACT_QUICK_GELU: act_bwd8_mul_c<ACT_QUICK_GELU>(v, a); break;
+    case ACT_TANH: act_bwd8_mul_c<ACT_TANH>(v, a); break;
+    default: act_bwd8_mul_c<ACT_SIGMOID>(v, a); break;
+  }
+}
+__device__ __forceinline__ float act_fwd(float x, int act) { return act_fwd2(f32x2{x, x}, act).x; }
+__device__ __forceinline__ float act_bwd(float x, int act) { return act_bwd2(f32x2{x, x}, act).x; }
 
 // ---- counter-based dropout RNG (stateless; forward and backward recompute the same mask) ----------
 // keep(element) <=> drop_hash(seed, idx_hi, idx_lo) >= thr,  thr = floor(p * 2^32)

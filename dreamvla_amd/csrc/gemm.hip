@@ -63,7 +63,6 @@ struct Cfg {
   static_assert(TN == 2, "epilogue patch is 64 columns wide");
 };
 using CfgS = Cfg<2, 2, 2, 2, true>;   // 128 x 128, 256 threads
-using CfgL = Cfg<2, 4, 4, 2, false>;  // 256 x 256, 512 threads (128 accumulator registers: one staging set only)
 
 struct GemmKArgs {
   const bf16_t* A; int64_t lda;
@@ -80,6 +79,9 @@ struct GemmKArgs {
   int split_k; int64_t k_per_split; float* workspace;
   int a_vec, b_vec, c_vec, aux_vec, epi_vec;
   int tiles_m, tiles_n;
+  int pingpong;  // 8-wave ring kernels: alternate the load / compute segments of the two waves of a SIMD
+  int ablate;    // timing experiments only (wrong results): 1 = no DMA after the prologue, 2 = no MFMA, 4 = no fragment reads
+  int stagger;   // ring kernels with 2 workgroups / CU: initial delay (units of s_sleep 127 = 8128 clocks) of the second residents
 };
 
 // Row-major image of a k-contiguous operand: row r = 128 B = 8 slots of 16 B; k-octet o of row r lives in slot
@@ -239,15 +241,11 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
   }
-  if (p.act != ACT_NONE) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], p.act);
-  }
+  act_fwd8(v, p.act);
   if (p.dact_aux) {
     float a[8];
     load8_aux(p.dact_aux + m * p.ld_dact + n, n, p.N, FULL, a);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= act_bwd(a[e], p.dact);
+    act_bwd8_mul(v, a, p.dact);
   }
   if (p.has_drop) {
     const uint32_t rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
@@ -279,6 +277,129 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
   } else {
     store8_bf16(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n, n, p.N, FULL, v);
   }
+}
+
+// Tile epilogue shared by all kernel families.  acc[i][j][r] holds (m = 32j + l31, n = 32i + 8*(r>>2) + 4*g + (r&3)) of
+// the wave's (TM*32) x 64 patch.  Each 32-row slab is transposed through a wave-private fp32 LDS patch [32][64+4] so
+// that a lane then owns 8 consecutive n of one row (16-byte aux loads / C stores).  A lane's column octet is the same
+// for all its rows, so its bias values are loaded once; the residual / act'-aux octets of a slab are all requested
+// BEFORE the slab is transposed so their latency overlaps the LDS traffic instead of serialising 4 loads per slab.
+template <int TM>
+__device__ __forceinline__ void tile_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], char* smem, int wave, int lane,
+                                              int64_t m_base, int64_t n_base, int split) {
+  const bool has_dact = p.dact_aux != nullptr;
+  constexpr int PATCH_LD = 68;  // floats per patch row (272 B: 16-B aligned, 4-bank skew per row)
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PATCH_LD);
+  const int l31 = lane & 31, g = lane >> 5;
+  const int cg = lane & 7, r8 = lane >> 3;            // this lane's column octet and row-in-group
+  const int64_t n = n_base + cg * 8;
+  // whole-tile fast path: every octet of this wave's columns is in range and all pointers are 16-B vectorisable
+  const bool tile_full = (n_base + 64 <= p.N) && p.c_vec && p.aux_vec && p.epi_vec;
+  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tile_full && p.bias && p.split_k <= 1) {
+    if (!p.bias_f32) {
+      unpack8f(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bias) + n), bias8);
+    } else {
+      const float4 b0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n);
+      const float4 b1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n + 4);
+      bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+      bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+  }
+  static_for<TM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int64_t mrow0 = m_base + j * 32 + r8;       // rows mrow0 + 8*it, it = 0..3
+    // one prefetch array: the residual octets if there is a residual, else the act' operand (a launch with both
+    // loads the act' operand late; none of the model's GEMMs has both)
+    uint4 pre[4];
+    if (tile_full && p.split_k <= 1) {                 // request the slab's aux octets now
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t m = mrow0 + 8 * it;
+        const int64_t mc = m < p.M ? m : p.M - 1;
+        if (p.residual) {
+          const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
+          pre[it] = *reinterpret_cast<const uint4*>(p.residual + rr * p.ld_res + n);
+        } else if (has_dact) {
+          pre[it] = *reinterpret_cast<const uint4*>(p.dact_aux + mc * p.ld_dact + n);
+        }
+      }
+    }
+    __syncthreads();  // operand buffers (j = 0) / previous slab (j > 0) no longer read
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        *reinterpret_cast<float4*>(patch + l31 * PATCH_LD + 32 * i + 8 * rq + 4 * g) =
+            make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
+    __syncthreads();
+    if (tile_full && p.split_k <= 1) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + r8;
+        const int64_t m = mrow0 + 8 * it;
+        const float4 lo = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (m < p.M) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+          if (p.preact) {
+            store8_bf16(p.preact + m * p.ld_preact + n, n, p.N, true, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));   // the activation sees the stored (bf16) value
+          }
+          act_fwd8(v, p.act);
+          if (has_dact) {
+            float a[8];
+            uint4 au = pre[it];
+            if (p.residual) au = *reinterpret_cast<const uint4*>(p.dact_aux + m * p.ld_dact + n);
+            unpack8f(au, a);
+            act_bwd8_mul(v, a, p.dact);
+          }
+          if (p.has_drop) {
+            const uint32_t rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const uint32_t h = drop_hash_rk(rowkey, (uint32_t)(n + e));
+              v[e] = (h >= p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+            }
+          }
+          if (p.residual) {
+            float a[8];
+            unpack8f(pre[it], a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a[e];
+          }
+          if (p.c_f32) {
+            float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+            if (p.accumulate) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) c[e] += v[e];
+            } else {
+              *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+              *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+          } else {
+            store8_bf16(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n, n, p.N, true, v);
+          }
+        }
+      }
+    } else {                                            // ragged / unaligned tiles and split-K slabs: guarded path
+#pragma unroll 2
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + r8;
+        const int64_t m = mrow0 + 8 * it;
+        if (m < p.M && n < p.N) {
+          const float4 lo = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8 + 4);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          if (tile_full) epilogue_oct<true>(p, m, n, v, split);
+          else epilogue_oct<false>(p, m, n, v, split);
+        }
+      }
+    }
+  });
 }
 
 template <class CF, bool A_T, bool B_T, int DBG = 0>
@@ -423,39 +544,7 @@ __global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
     }
   }
 
-  // ---- epilogue --------------------------------------------------------------------------------------
-  // acc[i][j][r] holds (m = 32j + l31, n = 32i + 8*(r>>2) + 4*g + (r&3)) of the wave's (TM*32) x 64 patch.  Each
-  // 32-row slab is transposed through a wave-private fp32 LDS patch [32][64+4] so that a lane then owns 8
-  // consecutive n of one row: 16-byte aux loads / C stores, and the (large) epilogue body is emitted once.
-  constexpr int PATCH_LD = 68;  // floats per patch row (272 B: 16-B aligned, 4-bank skew per row)
-  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PATCH_LD);
-  static_for<TM>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    __syncthreads();  // operand buffers (j = 0) / previous slab (j > 0) no longer read
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq)
-        *reinterpret_cast<float4*>(patch + l31 * PATCH_LD + 32 * i + 8 * rq + 4 * g) =
-            make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
-    __syncthreads();
-    // whole-tile fast path: every octet of this wave's columns is in range and all pointers are 16-B vectorisable
-    const bool tile_full = (n0 + wn * 64 + 64 <= p.N) && p.c_vec && p.aux_vec && p.epi_vec;
-#pragma unroll 2
-    for (int it = 0; it < 4; ++it) {
-      const int item = it * 64 + lane;
-      const int row = item >> 3, cg = item & 7;
-      const int64_t m = m0 + wm * (TM * 32) + j * 32 + row;
-      const int64_t n = n0 + wn * 64 + cg * 8;
-      if (m < p.M && n < p.N) {
-        const float4 lo = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8 + 4);
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (tile_full) epilogue_oct<true>(p, m, n, v, split);
-        else epilogue_oct<false>(p, m, n, v, split);
-      }
-    }
-  });
+  tile_epilogue<TM>(p, acc, smem, wave, lane, m0 + wm * (TM * 32), n0 + wn * 64, split);
 }
 
 // ====================================================================================================
@@ -475,11 +564,12 @@ __global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
 // Requirements (host falls back to the register-staged kernel otherwise): 16-B-vectorisable operands, K-range % 32 == 0,
 // r-contiguous operands with rows % tile == 0.
 // ====================================================================================================
-template <int WM_, int WN_, int TM_, int TN_>
+template <int WM_, int WN_, int TM_, int TN_, int NS_, int WPE_>
 struct RCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVES = WM * WN, NT = NWAVES * 64;
-  static constexpr int BKS = 32, NS = 4;
+  static constexpr int BKS = 32, NS = NS_;   // NS ring stages: NS - 1 stages are in flight ahead of the one computed
+  static constexpr int WPE = WPE_;           // waves per SIMD the register budget must allow (workgroups / CU * NWAVES / 4)
   static constexpr int A_BYTES = BM * BKS * 2, B_BYTES = BN * BKS * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int SMEM_BYTES = NS * STAGE_BYTES;
   static constexpr int A_CHUNKS = A_BYTES / 1024, B_CHUNKS = B_BYTES / 1024;
@@ -488,9 +578,11 @@ struct RCfg {
   static_assert(TN == 2, "epilogue patch is 64 columns wide");
   static_assert(NWAVES * 32 * 68 * 4 <= SMEM_BYTES, "epilogue patches must fit");
 };
-using RCfgL = RCfg<2, 4, 4, 2>;   // 256 x 256, 128 KiB ring
-using RCfgM = RCfg<4, 2, 2, 2>;   // 256 x 128,  96 KiB ring
-using RCfgS = RCfg<2, 2, 2, 2>;   // 128 x 128,  64 KiB ring, 4 waves, 2 workgroups / CU
+using RCfgL = RCfg<2, 4, 4, 2, 4, 2>;   // 256 x 256, 8 waves of 128 x 64, 128 KiB ring, 1 workgroup / CU
+using RCfgM = RCfg<4, 2, 2, 2, 4, 2>;   // 256 x 128, 8 waves of  64 x 64,  96 KiB ring, 1 workgroup / CU
+using RCfgS = RCfg<2, 2, 2, 2, 4, 2>;   // 128 x 128, 4 waves of  64 x 64,  64 KiB ring, 2 workgroups / CU
+using RCfgD = RCfg<2, 2, 4, 2, 3, 2>;   // 256 x 128, 4 waves of 128 x 64,  72 KiB ring (3 stages), 2 workgroups / CU: one
+                                        // workgroup's ring fill and epilogue overlap the other's MFMA stream
 
 // per-lane global source address of chunk c of an operand tile at k0 (the LDS destination of lane l is chunk base + 16 l)
 template <bool TRANS, int ROWS>
@@ -542,9 +634,13 @@ __device__ __forceinline__ bf16x8 ring_frag(const char* lds_oper, int rbase, int
   }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <class RC, bool A_T, bool B_T>
-__global__ __launch_bounds__(RC::NT) void gemm_ring_kernel(GemmKArgs p) {
-  constexpr int BM = RC::BM, BN = RC::BN, TM = RC::TM, TN = RC::TN, CPW = RC::CPW, NS = RC::NS;
+__global__ __launch_bounds__(RC::NT) __attribute__((amdgpu_waves_per_eu(RC::WPE, RC::WPE)))
+void gemm_ring_kernel(GemmKArgs p) {
+  constexpr int BM = RC::BM, BN = RC::BN, TM = RC::TM, TN = RC::TN, CPW = RC::CPW, NS = RC::NS, PD_ = RC::NS - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -573,6 +669,16 @@ __global__ __launch_bounds__(RC::NT) void gemm_ring_kernel(GemmKArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Two workgroups share a CU so that one's ring fill and epilogue (no MFMA) overlap the other's MFMA stream -- which
+  // only happens if they are OUT OF PHASE.  All workgroups of the first residency wave start together and every tile
+  // takes the same time, so the second residents (linear ids 256..511: the dispatcher places one workgroup per CU
+  // before it doubles up) are held back once; later workgroups inherit the slot's phase.
+  if (p.stagger > 0) {
+    const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+    if (lin >= 256 && lin < 512)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
   // per-wave DMA plan: CPW chunks per stage, fixed operand / chunk per slot i, per-lane source pointers that advance by
   // one stage (32 k) per issue; destinations are wave-uniform byte offsets inside a stage buffer.
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -593,6 +699,7 @@ __global__ __launch_bounds__(RC::NT) void gemm_ring_kernel(GemmKArgs p) {
     }
   }
   auto issue = [&](int s) {
+    if (s >= PD_ && (p.ablate & 1)) return;
     const uint32_t st = smem_base + (uint32_t)((s % NS) * RC::STAGE_BYTES);
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
@@ -600,67 +707,118 @@ __global__ __launch_bounds__(RC::NT) void gemm_ring_kernel(GemmKArgs p) {
       src[i] += step[i];
     }
   };
-  auto compute = [&](const char* st) {
+  // Fragment registers are double-buffered across the two k16-steps of a stage AND across stages: F[0] always holds
+  // k-step 0 of the stage being computed (loaded during the previous stage's second MFMA group), F[1] k-step 1 (loaded
+  // during the first MFMA group).  The stage barrier therefore sits between two MFMA groups whose operands are already
+  // in registers: the matrix pipe keeps 8 * TM * TN / 8 MFMAs queued while the waves synchronise.
+  bf16x8 fa[2][TM] = {}, fb[2][TN] = {};
+  auto load_frags = [&](int buf, const char* st, int ks) {
+    if (p.ablate & 4) return;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[TM], fb[TN];
+    for (int j = 0; j < TM; ++j) fa[buf][j] = ring_frag<A_T, BM>(st, wm * (TM * 32) + j * 32, ks, lane);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) fa[j] = ring_frag<A_T, BM>(st, wm * (TM * 32) + j * 32, ks, lane);
-#pragma unroll
-      for (int i = 0; i < TN; ++i) fb[i] = ring_frag<B_T, BN>(st + RC::A_BYTES, wn * (TN * 32) + i * 32, ks, lane);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
-    }
+    for (int i = 0; i < TN; ++i) fb[buf][i] = ring_frag<B_T, BN>(st + RC::A_BYTES, wn * (TN * 32) + i * 32, ks, lane);
   };
-
-  if (ns > 0) issue(0);
-  if (ns > 1) issue(1);
-  if (ns > 2) issue(2);
-  for (int s = 0; s < ns; ++s) {
-    // wait for this wave's pieces of stage s: the (up to two) younger stages stay in flight
-    if (s + 2 < ns) { if (CPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-    else if (s + 1 < ns) { if (CPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 3 < ns) issue(s + 3);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(smem + (s % NS) * RC::STAGE_BYTES);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  // ---- epilogue (same as the register-staged kernel) ----
-  constexpr int PATCH_LD = 68;
-  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PATCH_LD);
-  static_for<TM>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    __syncthreads();
+  auto mfma_group = [&](int buf) {
+    if (p.ablate & 2) return;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq)
-        *reinterpret_cast<float4*>(patch + l31 * PATCH_LD + 32 * i + 8 * rq + 4 * g) =
-            make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
-    __syncthreads();
-    const bool tile_full = (n0 + wn * 64 + 64 <= p.N) && p.c_vec && p.aux_vec && p.epi_vec;
-#pragma unroll 2
-    for (int it = 0; it < 4; ++it) {
-      const int item = it * 64 + lane;
-      const int row = item >> 3, cg = item & 7;
-      const int64_t m = m0 + wm * (TM * 32) + j * 32 + row;
-      const int64_t n = n0 + wn * 64 + cg * 8;
-      if (m < p.M && n < p.N) {
-        const float4 lo = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8 + 4);
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (tile_full) epilogue_oct<true>(p, m, n, v, split);
-        else epilogue_oct<false>(p, m, n, v, split);
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[buf][i], fa[buf][j], acc[i][j], 0, 0, 0);
+  };
+
+  constexpr int PD = NS - 1;   // DMA prefetch distance in stages
+  static_assert(PD == 2 || PD == 3, "wait ladders below cover 3- and 4-stage rings");
+  // own pieces of stage s landed, given that stages up to min(s + PD - 1, ns - 1) have been issued
+  auto wait_stage = [&](int s) {
+    if (PD == 3 && s + 2 < ns) wait_vmcnt<2 * CPW>();
+    else if (s + 1 < ns) wait_vmcnt<CPW>();
+    else wait_vmcnt<0>();
+  };
+#pragma unroll
+  for (int s = 0; s < PD; ++s)
+    if (s < ns) issue(s);
+
+  if (RC::NWAVES == 8 && p.pingpong) {
+    // Ping-pong: waves w and w+4 share a SIMD.  One LDS-DMA piece costs its wave 60..185 clocks of issue time
+    // (MI355X_MICROARCH.md latency table) and a stage needs CPW of them plus 2 (TM + TN) fragment reads -- about as long
+    // as the stage's 2 TM TN MFMAs run.  If all waves do that at the same time (right after the stage barrier) the
+    // matrix cores idle for it; so the two waves of a SIMD alternate: in every half-stage one is in its LOAD segment
+    // (fragment reads of stage s into registers + DMA issue of stage s+PD), the other in its COMPUTE segment (MFMAs on
+    // the fragments it loaded one half-stage earlier).  Two workgroup barriers per stage keep the halves aligned:
+    //   half 2s   : A loads stage s      | B computes stage s-1
+    //   half 2s+1 : A computes stage s   | B loads stage s
+    // Stage s is complete before half 2s (every wave waits for its own pieces before that barrier); its buffer is
+    // rewritten by the DMA of stage s+1+PD, issued in halves 2s+2 / 2s+3, after the last reads (B, half 2s+1) have
+    // drained (lgkmcnt(0) before the barrier).
+    const bool second = wave >= 4;
+    if (!second) {
+      for (int s = 0; s < ns; ++s) {
+        const char* st = smem + (s % NS) * RC::STAGE_BYTES;
+        wait_stage(s);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(0, st, 0);
+        load_frags(1, st, 1);
+        if (s + PD < ns) issue(s + PD);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0);
+        mfma_group(1);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    } else {
+      for (int s = 0; s < ns; ++s) {
+        const char* st = smem + (s % NS) * RC::STAGE_BYTES;
+        wait_stage(s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) { mfma_group(0); mfma_group(1); }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(0, st, 0);
+        load_frags(1, st, 1);
+        if (s + PD < ns) issue(s + PD);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ns > 0) { mfma_group(0); mfma_group(1); }
     }
-  });
+  } else {
+    if (ns > 0) {
+      wait_stage(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(0, smem, 0);
+    }
+    for (int s = 0; s < ns; ++s) {
+      const char* st = smem + (s % NS) * RC::STAGE_BYTES;
+      const char* st_next = smem + ((s + 1) % NS) * RC::STAGE_BYTES;
+      if (s + 1 < ns) {
+        // certify stage s+1; younger stages stay in flight.  The barrier also tells that every wave is done with
+        // stage s-1, whose buffer the next DMA issue overwrites.
+        if (PD == 3 && s + 2 < ns) wait_vmcnt<CPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + PD < ns) issue(s + PD);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(1, st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < ns) load_frags(0, st_next, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  tile_epilogue<TM>(p, acc, smem, wave, lane, m0 + wm * (TM * 32), n0 + wn * 64, split);
 }
 
 // split-K reduction: C[m,n] (+)= sum_s ws[s][m][n]
@@ -679,7 +837,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* C, int6
   }
 }
 
-int g_gemm_variant = -1;   // 0 auto; force: 2 S, 3 L (register-staged), 4 / 5 / 6 ring 256^2 / 256x128 / 128^2; 11..16 ablations
+int g_gemm_variant = -1;   // 0 auto; force: 2 register-staged S, 4 / 5 / 6 / 7 ring 256^2 / 256x128 / 128^2; 11..16 ablations
 inline int gemm_variant() {
   if (g_gemm_variant < 0) {
     const char* e = getenv("DVLA_GEMM_VARIANT");
@@ -769,6 +927,9 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       return DVLA_ERR_ARG;
   }
   GemmKArgs a;
+  a.stagger = 0;
+  a.pingpong = 1;
+  a.ablate = 0;
   a.A = reinterpret_cast<const bf16_t*>(q->A); a.lda = q->lda;
   a.B = reinterpret_cast<const bf16_t*>(q->B); a.ldb = q->ldb;
   a.C = q->C; a.ldc = q->ldc; a.c_f32 = (q->c_dtype == DVLA_DT_F32);
@@ -805,7 +966,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
 
   const int combo = (q->a_trans ? 2 : 0) | (q->b_trans ? 1 : 0);
   const int variant = gemm_variant();
-  if (variant >= 11 && combo == 0) {   // ablation builds of the S NT kernel (results are garbage by design)
+  if (variant >= 11 && variant <= 16 && combo == 0) {   // ablation builds of the S NT kernel (results are garbage by design)
     a.tiles_m = (int)((a.M + CfgS::BM - 1) / CfgS::BM);
     a.tiles_n = (int)((a.N + CfgS::BN - 1) / CfgS::BN);
     switch (variant - 10) {
@@ -816,13 +977,10 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       default: launch_one<CfgS, false, false, 6>(a, split_k, stream); break;
     }
   } else {
-    // tile choice.  Measured on MI355X (profiles/r01_gemm_variants.txt): the L (256^2, 1 workgroup / CU, one staging
-    // set, a few spilled address registers) kernel is 5-30 % SLOWER than S on every DreamVLA shape and on 8192^3
-    // (805 vs 880 TFLOP/s), so S is the default and L is kept selectable (variant 3) for the next tuning round.
     // Configuration choice (measured on MI355X, profiles/r01_gemm_variants.txt): the LDS-DMA ring kernels beat the
     // register-staged S kernel whenever they apply; among them pick max(relative tile speed x chip fill): the 256^2
     // ring is ~1.25x the 128^2 one per tile, the 256x128 one ~1.12x, but they run 256 workgroups at a time, not 512.
-    int choice = 0;   // 0 = register-staged S (always valid), 1 = ring L, 2 = ring M, 3 = ring S, 4 = register-staged L
+    int choice = 0;   // 0 = register-staged S (always valid), 1 = ring L, 2 = ring M, 3 = ring S
     if (variant == 0) {
       double best = 0.0;
       if (ring_ok<RCfgS>(a, combo)) { best = fill(((q->M + 127) / 128) * ((q->N + 127) / 128) * split_k, 512); choice = 3; }
@@ -834,15 +992,18 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
         const double e = 1.25 * fill(((q->M + 255) / 256) * ((q->N + 255) / 256) * split_k, 256);
         if (e > best) { best = e; choice = 1; }
       }
-    } else if (variant == 3 && q->M >= 256 && q->N >= 256) choice = 4;
-    else if (variant == 4 && ring_ok<RCfgL>(a, combo)) choice = 1;
+    } else if (variant == 4 && ring_ok<RCfgL>(a, combo)) choice = 1;
     else if (variant == 5 && ring_ok<RCfgM>(a, combo)) choice = 2;
     else if (variant == 6 && ring_ok<RCfgS>(a, combo)) choice = 3;
+    else if (variant >= 7 && variant <= 9 && ring_ok<RCfgD>(a, combo)) choice = 4;
+    if (variant >= 30 && variant < 40) { a.ablate = variant - 30; if (ring_ok<RCfgL>(a, combo)) choice = 1; }
+    if (variant >= 40 && variant < 50) { a.ablate = variant - 40; a.pingpong = 0; if (ring_ok<RCfgL>(a, combo)) choice = 1; }
+    a.stagger = (choice == 4) ? (variant == 8 ? 0 : variant == 9 ? 4 : 2) : 0;
     switch (choice) {
       case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;
       case 2: launch_ring<RCfgM>(a, combo, split_k, stream); break;
       case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
-      case 4: launch_cfg<CfgL>(a, combo, split_k, stream); break;
+      case 4: launch_ring<RCfgD>(a, combo, split_k, stream); break;
       default: launch_cfg<CfgS>(a, combo, split_k, stream); break;
     }
   }

@@ -63,8 +63,9 @@ typedef struct dvla_gemm_params {
   int32_t split_k; void* workspace;
 } dvla_gemm_params;
 int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
-/* kernel variant: 0 = register-staged operands (2-deep prefetch), 1 = LDS-DMA (global_load_lds) for k-contiguous
- * operands.  Same results bit for bit; default from env DVLA_GEMM_VARIANT (0). */
+/* tuning hook: 0 = automatic kernel choice (default; env DVLA_GEMM_VARIANT overrides at load), 2 = register-staged
+ * 128x128 kernel, 4 / 5 / 6 = LDS-DMA ring kernel 256x256 / 256x128 / 128x128 where it applies, 11..16 = ablation
+ * builds (wrong results by design, timing only).  Variants 0..6 differ only in fp32 summation order. */
 void dvla_set_gemm_variant(int variant);
 
 /* ---------------------------------------------------------------------------------------------------
