@@ -79,9 +79,6 @@ struct GemmKArgs {
   int split_k; int64_t k_per_split; float* workspace;
   int a_vec, b_vec, c_vec, aux_vec, epi_vec;
   int tiles_m, tiles_n;
-  int pingpong;  // 8-wave ring kernels: alternate the load / compute segments of the two waves of a SIMD
-  int ablate;    // timing experiments only (wrong results): 1 = no DMA after the prologue, 2 = no MFMA, 4 = no fragment reads
-  int stagger;   // ring kernels with 2 workgroups / CU: initial delay (units of s_sleep 127 = 8128 clocks) of the second residents
 };
 
 // Row-major image of a k-contiguous operand: row r = 128 B = 8 slots of 16 B; k-octet o of row r lives in slot
@@ -242,11 +239,6 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
     for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
   }
   act_fwd8(v, p.act);
-  if (p.dact_aux) {
-    float a[8];
-    load8_aux(p.dact_aux + m * p.ld_dact + n, n, p.N, FULL, a);
-    act_bwd8_mul(v, a, p.dact);
-  }
   if (p.has_drop) {
     const uint32_t rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
 #pragma unroll
@@ -254,6 +246,17 @@ __device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int6
       const uint32_t h = drop_hash_rk(rowkey, (uint32_t)(n + e));
       v[e] = (h >= p.drop_thr) ? v[e] * p.drop_scale : 0.f;
     }
+  }
+  // bf16 outputs: act' / residual are applied to the ROUNDED branch value -- the reference materialises
+  // `dropout(act(linear(x)))` and `dY @ W` as bf16 tensors first (same rule in the ring kernels' epilogue)
+  if (!p.c_f32 && (p.dact_aux || p.residual)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+  }
+  if (p.dact_aux) {
+    float a[8];
+    load8_aux(p.dact_aux + m * p.ld_dact + n, n, p.N, FULL, a);
+    act_bwd8_mul(v, a, p.dact);
   }
   if (p.residual) {
     float a[8];
@@ -350,13 +353,6 @@ __device__ __forceinline__ void tile_epilogue(const GemmKArgs& p, f32x16 (&acc)[
             for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));   // the activation sees the stored (bf16) value
           }
           act_fwd8(v, p.act);
-          if (has_dact) {
-            float a[8];
-            uint4 au = pre[it];
-            if (p.residual) au = *reinterpret_cast<const uint4*>(p.dact_aux + m * p.ld_dact + n);
-            unpack8f(au, a);
-            act_bwd8_mul(v, a, p.dact);
-          }
           if (p.has_drop) {
             const uint32_t rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
 #pragma unroll
@@ -364,6 +360,17 @@ __device__ __forceinline__ void tile_epilogue(const GemmKArgs& p, f32x16 (&acc)[
               const uint32_t h = drop_hash_rk(rowkey, (uint32_t)(n + e));
               v[e] = (h >= p.drop_thr) ? v[e] * p.drop_scale : 0.f;
             }
+          }
+          if (!p.c_f32 && (has_dact || p.residual)) {   // act' / residual see the rounded branch value (see epilogue_oct)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+          }
+          if (has_dact) {
+            float a[8];
+            uint4 au = pre[it];
+            if (p.residual) au = *reinterpret_cast<const uint4*>(p.dact_aux + m * p.ld_dact + n);
+            unpack8f(au, a);
+            act_bwd8_mul(v, a, p.dact);
           }
           if (p.residual) {
             float a[8];
@@ -548,12 +555,22 @@ __global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
 }
 
 // ====================================================================================================
-// Ring kernel: LDS-DMA operand staging (global_load_lds_dwordx4) through a 4-stage LDS ring, 8 waves, big tiles.
+// Ring kernel: PERSISTENT workgroups, LDS-DMA operand staging (global_load_lds_dwordx4) through a 4-stage LDS ring
+// that never drains between output tiles, and a barrier-free, wave-private epilogue.
 //
-//   stage = K-slice of 32: (BM + BN) x 32 bf16.  Three stages are always in flight while one is multiplied; a wave
-//   waits for ITS pieces of stage s with a counted s_waitcnt vmcnt(2 * chunks-per-wave), then ONE raw s_barrier makes
-//   every wave's pieces visible and proves everybody is done with stage s-1, whose buffer is immediately refilled
-//   with stage s+3.  No VGPR staging, no ds_write, no vmcnt(0) in the steady state.
+//   work item = (output tile, K split).  grid = min(items, workgroup slots of the chip); workgroup b runs items
+//   it * grid + perm(b), it = 0, 1, ...  (perm puts the workgroups of one XCD on consecutive items, and consecutive
+//   items form compact GH x (32 / GH) blocks of tiles: the 32 workgroups of an XCD share few operand panels in its L2).
+//
+//   stage = K-slice of 32: (BM + BN) x 32 bf16.  The DMA cursor runs PD = 3 stages ahead of the multiply THROUGH item
+//   boundaries: while the last stages of a tile are multiplied and while its epilogue runs, the first stages of the
+//   next tile are already in flight (measured: with one launch per tile the ring fill + C burst of every tile cost
+//   ~19 us per 256-tile round at 20832 x 4096 -- 40 % of a K = 1024 GEMM -- because all CUs do them at the same time).
+//   A wave waits for ITS pieces of a stage with a counted s_waitcnt vmcnt(stages ahead * pieces-per-wave), then ONE
+//   raw s_barrier makes every wave's pieces visible and proves everybody is done with the previous stage, whose
+//   buffer is immediately refilled.  No VGPR staging, no ds_write, no vmcnt(0) in the steady state.  (The counted
+//   waits ignore the epilogue's own loads / stores, which are YOUNGER than the pieces waited for: VMEM operations of
+//   a wave complete in order, so a smaller count only waits longer, never too little.)
 //   k-contiguous operand : LDS rows of 64 B (4 slots of 16 B), k-octet o of row r in slot o ^ ((r>>2)&3)
 //                          (the swizzle is applied on the per-lane GLOBAL address; the LDS image is lane-linear as
 //                          LDS-DMA requires), fragments by conflict-free ds_read_b128.
@@ -561,28 +578,35 @@ __global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
 //                          with the hardware transpose ds_read_b64_tr_b16 (lane i of a 16-lane group receives 4 consecutive k
 //                          of row i; semantics probed on hardware: tests/probes/tr_probe.hip) -- so Conv1D weights and
 //                          the weight-gradient GEMMs need no register transpose either.
-// Requirements (host falls back to the register-staged kernel otherwise): 16-B-vectorisable operands, K-range % 32 == 0,
-// r-contiguous operands with rows % tile == 0.
+//   epilogue             : bias / activation / dropout in the accumulator layout, then each 32 x 64 slab goes through a
+//                          4-KiB wave-private LDS patch OUTSIDE the ring (as bf16, or as two fp32 halves) so that a
+//                          lane stores 16 contiguous bytes; act'-multiply and residual are applied after the transpose
+//                          on the rounded value (which is what `dropout(linear(x))` then `x + y` do in the reference).
+//                          No workgroup barrier: the ring keeps streaming underneath.
+// Requirements (host falls back to the register-staged kernel otherwise): 16-B-vectorisable operands / outputs,
+// K-range % 32 == 0, r-contiguous operands with rows % tile == 0.
 // ====================================================================================================
-template <int WM_, int WN_, int TM_, int TN_, int NS_, int WPE_>
+template <int WM_, int WN_, int TM_, int TN_, int NS_, int WPE_, int GH_>
 struct RCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVES = WM * WN, NT = NWAVES * 64;
   static constexpr int BKS = 32, NS = NS_;   // NS ring stages: NS - 1 stages are in flight ahead of the one computed
-  static constexpr int WPE = WPE_;           // waves per SIMD the register budget must allow (workgroups / CU * NWAVES / 4)
+  static constexpr int WPE = WPE_;           // waves per SIMD the register budget must allow
+  static constexpr int GH = GH_;             // tile rows per raster group
   static constexpr int A_BYTES = BM * BKS * 2, B_BYTES = BN * BKS * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int SMEM_BYTES = NS * STAGE_BYTES;
+  static constexpr int RING_BYTES = NS * STAGE_BYTES, PATCH_BYTES = 4096;
+  static constexpr int SMEM_BYTES = RING_BYTES + NWAVES * PATCH_BYTES;
+  static constexpr int WG_PER_CU = (2 * SMEM_BYTES <= 160 * 1024) ? 2 : 1;
   static constexpr int A_CHUNKS = A_BYTES / 1024, B_CHUNKS = B_BYTES / 1024;
   static constexpr int CPW = (A_CHUNKS + B_CHUNKS) / NWAVES;   // DMA instructions per wave and stage
   static_assert((A_CHUNKS + B_CHUNKS) % NWAVES == 0, "chunks must divide evenly over the waves");
-  static_assert(TN == 2, "epilogue patch is 64 columns wide");
-  static_assert(NWAVES * 32 * 68 * 4 <= SMEM_BYTES, "epilogue patches must fit");
+  static_assert(TN == 2, "epilogue slabs are 64 columns wide");
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(NS == 4, "wait ladder assumes a prefetch distance of 3 stages");
 };
-using RCfgL = RCfg<2, 4, 4, 2, 4, 2>;   // 256 x 256, 8 waves of 128 x 64, 128 KiB ring, 1 workgroup / CU
-using RCfgM = RCfg<4, 2, 2, 2, 4, 2>;   // 256 x 128, 8 waves of  64 x 64,  96 KiB ring, 1 workgroup / CU
-using RCfgS = RCfg<2, 2, 2, 2, 4, 2>;   // 128 x 128, 4 waves of  64 x 64,  64 KiB ring, 2 workgroups / CU
-using RCfgD = RCfg<2, 2, 4, 2, 3, 2>;   // 256 x 128, 4 waves of 128 x 64,  72 KiB ring (3 stages), 2 workgroups / CU: one
-                                        // workgroup's ring fill and epilogue overlap the other's MFMA stream
+using RCfgL = RCfg<2, 4, 4, 2, 4, 2, 4>;   // 256 x 256, 8 waves of 128 x 64, 128 + 32 KiB, 1 workgroup / CU
+using RCfgM = RCfg<4, 2, 2, 2, 4, 2, 4>;   // 256 x 128, 8 waves of  64 x 64,  96 + 32 KiB, 1 workgroup / CU
+using RCfgS = RCfg<2, 2, 2, 2, 4, 2, 8>;   // 128 x 128, 4 waves of  64 x 64,  64 + 16 KiB, 2 workgroups / CU
 
 // per-lane global source address of chunk c of an operand tile at k0 (the LDS destination of lane l is chunk base + 16 l)
 template <bool TRANS, int ROWS>
@@ -636,51 +660,229 @@ __device__ __forceinline__ bf16x8 ring_frag(const char* lds_oper, int rbase, int
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// work item -> (tile origin, K range).  Consecutive ids sweep groups of GH tile rows column by column.
+struct RingItem { int64_t m0, n0, k_begin; int ns, split; };
+template <class RC>
+__device__ __forceinline__ RingItem ring_item(const GemmKArgs& p, int id) {
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int split = id / ntiles, tile = id - split * ntiles;
+  const int per_panel = RC::GH * p.tiles_n;
+  const int panel = tile / per_panel, r = tile - panel * per_panel;
+  const int left = p.tiles_m - panel * RC::GH;
+  const int gh = left < RC::GH ? left : RC::GH;
+  const int tn = r / gh, tm = panel * RC::GH + (r - tn * gh);
+  RingItem it;
+  it.m0 = (int64_t)tm * RC::BM; it.n0 = (int64_t)tn * RC::BN; it.split = split;
+  it.k_begin = (int64_t)split * p.k_per_split;
+  const int64_t k_end = (it.k_begin + p.k_per_split < p.K) ? (it.k_begin + p.k_per_split) : p.K;
+  it.ns = (int)((k_end - it.k_begin) / RC::BKS);
+  return it;
+}
+
+// patch addressing (wave-private 4 KiB): bf16 image = 32 rows x 16 units of 8 B, unit u of row r at u ^ (r & 15);
+// fp32 half-slab image = 32 rows x 8 units of 16 B, unit u of row r at u ^ (r & 7).
+__device__ __forceinline__ int patch_bf16(int row, int unit) { return row * 128 + ((unit ^ (row & 15)) << 3); }
+__device__ __forceinline__ int patch_f32(int row, int unit) { return row * 128 + ((unit ^ (row & 7)) << 4); }
+
+// Epilogue of one wave: (TM*32) x 64 block at (m_base, n_base).  acc[i][j][r] = element (m = 32j + l31,
+// n = 32i + 8*(r>>2) + 4*g + (r&3)).  Requires c_vec / aux_vec / epi_vec and N % 64 == 0 (ring_ok): only rows beyond M
+// need guards.
+template <int TM>
+__device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], char* patch, int lane,
+                                              int64_t m_base, int64_t n_base, int split) {
+  const int l31 = lane & 31, g = lane >> 5;
+  const int cg = lane & 7, r8 = lane >> 3;
+  const bool split_out = p.split_k > 1;
+  const bool has_dact = p.dact_aux != nullptr, has_res = p.residual != nullptr;
+  if (n_base >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
+
+  const bool f32_out = split_out || p.c_f32;
+  static_for<TM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int64_t m_acc = m_base + j * 32 + l31;           // this lane's row in the accumulator layout
+    const int64_t ms0 = m_base + j * 32 + r8;              // store layout: rows ms0 + 8*it
+    uint32_t rowkey = 0;
+    if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m_acc);
+
+    // ---- stage A (accumulator layout, fp32), evaluated per group of 4 columns right before it is written to the
+    // patch so that only four values are live: bias -> (round, if the pre-activation tensor is written) -> activation
+    // -> dropout ----
+    auto biased = [&](int i, int rq, float (&z)[4]) {
+      const int64_t n = n_base + 32 * i + 8 * rq + 4 * g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = acc[i][j][4 * rq + e];
+      if (!split_out && p.bias) {
+        if (p.bias_f32) {
+          const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n);
+          z[0] += b.x; z[1] += b.y; z[2] += b.z; z[3] += b.w;
+        } else {
+          const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.bias) + n);
+          z[0] += bf2f((bf16_t)(b.x & 0xffff)); z[1] += bf2f((bf16_t)(b.x >> 16));
+          z[2] += bf2f((bf16_t)(b.y & 0xffff)); z[3] += bf2f((bf16_t)(b.y >> 16));
+        }
+      }
+    };
+    auto finished = [&](int i, int rq, float (&z)[4]) {
+      biased(i, rq, z);
+      if (split_out) return;
+      if (p.preact) {   // the activation sees the stored (bf16) pre-activation
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = bf2f(f2bf(z[e]));
+      }
+      if (p.act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const f32x2 r = act_fwd2(f32x2{z[e], z[e + 1]}, p.act);
+          z[e] = r.x; z[e + 1] = r.y;
+        }
+      }
+      if (p.has_drop) {
+        const uint32_t n = (uint32_t)(n_base + 32 * i + 8 * rq + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t h = drop_hash_rk(rowkey, n + e);
+          z[e] = (h >= p.drop_thr) ? z[e] * p.drop_scale : 0.f;
+        }
+      }
+    };
+    if (!split_out && p.preact) {
+      // pre-activation tensor: same transpose as the bf16 output below
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float z[4];
+          biased(i, rq, z);
+          *reinterpret_cast<uint2*>(patch + patch_bf16(l31, 8 * i + 2 * rq + g)) =
+              make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+        }
+      wait_lds();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int R = it * 8 + r8;
+        const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
+        const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
+        const int64_t m = ms0 + 8 * it;
+        if (m < p.M) *reinterpret_cast<uint4*>(p.preact + m * p.ld_preact + n_base + 8 * cg) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+      wait_lds();
+    }
+
+    if (!f32_out) {
+      // ---- bf16 output: prefetch the store-layout operands, transpose the slab as bf16, finish, store 16 B / lane ----
+      uint4 pre[4];
+      if (has_res || has_dact) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int64_t m = ms0 + 8 * it;
+          const int64_t mc = m < p.M ? m : p.M - 1;
+          if (has_res) {
+            const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
+            pre[it] = *reinterpret_cast<const uint4*>(p.residual + rr * p.ld_res + n_base + 8 * cg);
+          } else {
+            pre[it] = *reinterpret_cast<const uint4*>(p.dact_aux + mc * p.ld_dact + n_base + 8 * cg);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float z[4];
+          finished(i, rq, z);
+          *reinterpret_cast<uint2*>(patch + patch_bf16(l31, 8 * i + 2 * rq + g)) =
+              make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+        }
+      wait_lds();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int R = it * 8 + r8;
+        const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
+        const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
+        uint4 out = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const int64_t m = ms0 + 8 * it;
+        if (has_res || has_dact) {
+          float o[8], a[8];
+          unpack8f(out, o);
+          if (has_dact) {
+            uint4 au = pre[it];
+            if (has_res) au = *reinterpret_cast<const uint4*>(p.dact_aux + (m < p.M ? m : p.M - 1) * p.ld_dact + n_base + 8 * cg);
+            unpack8f(au, a);
+            act_bwd8_mul(o, a, p.dact);
+          }
+          if (has_res) {
+            unpack8f(pre[it], a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += a[e];
+          }
+          out = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+        }
+        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n_base + 8 * cg) = out;
+      }
+      wait_lds();
+    } else {
+      // ---- fp32 output (fp32 C, accumulation, split-K partial sums): two 32-column halves through the patch ----
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float z[4];
+          finished(i, rq, z);
+          *reinterpret_cast<float4*>(patch + patch_f32(l31, 2 * rq + g)) = make_float4(z[0], z[1], z[2], z[3]);
+        }
+        wait_lds();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int R = it * 8 + r8;
+          float4 o = *reinterpret_cast<const float4*>(patch + patch_f32(R, cg));
+          const int64_t m = ms0 + 8 * it;
+          const int64_t n = n_base + 32 * i + 4 * cg;
+          if (m < p.M) {
+            if (split_out) {
+              *reinterpret_cast<float4*>(p.workspace + ((int64_t)split * p.M + m) * p.N + n) = o;
+            } else {
+              if (has_dact) {
+                const uint2 a = *reinterpret_cast<const uint2*>(p.dact_aux + m * p.ld_dact + n);
+                o.x *= act_bwd(bf2f((bf16_t)(a.x & 0xffff)), p.dact); o.y *= act_bwd(bf2f((bf16_t)(a.x >> 16)), p.dact);
+                o.z *= act_bwd(bf2f((bf16_t)(a.y & 0xffff)), p.dact); o.w *= act_bwd(bf2f((bf16_t)(a.y >> 16)), p.dact);
+              }
+              if (has_res) {
+                const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
+                const uint2 a = *reinterpret_cast<const uint2*>(p.residual + rr * p.ld_res + n);
+                o.x += bf2f((bf16_t)(a.x & 0xffff)); o.y += bf2f((bf16_t)(a.x >> 16));
+                o.z += bf2f((bf16_t)(a.y & 0xffff)); o.w += bf2f((bf16_t)(a.y >> 16));
+              }
+              float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n);
+              if (p.accumulate) { const float4 old = *c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+              *c = o;
+            }
+          }
+        }
+        wait_lds();
+      }
+    }
+  });
+}
 
 template <class RC, bool A_T, bool B_T>
 __global__ __launch_bounds__(RC::NT) __attribute__((amdgpu_waves_per_eu(RC::WPE, RC::WPE)))
 void gemm_ring_kernel(GemmKArgs p) {
-  constexpr int BM = RC::BM, BN = RC::BN, TM = RC::TM, TN = RC::TN, CPW = RC::CPW, NS = RC::NS, PD_ = RC::NS - 1;
+  constexpr int BM = RC::BM, BN = RC::BN, TM = RC::TM, TN = RC::TN, CPW = RC::CPW, NS = RC::NS, PD = RC::NS - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave % RC::WM, wn = wave / RC::WM;
-  const int l31 = lane & 31, g = lane >> 5;
 
-  const int ntiles = p.tiles_m * p.tiles_n;
-  int tile;
-  {
-    const int b = blockIdx.x, q = ntiles / 8, r = ntiles % 8, xcd = b % 8, idx = b / 8;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-  const int split = blockIdx.y;
-  const int64_t k_begin = (int64_t)split * p.k_per_split;
-  const int64_t k_end = (k_begin + p.k_per_split < p.K) ? (k_begin + p.k_per_split) : p.K;
-  const int ns = (int)((k_end - k_begin) / RC::BKS);
+  const int nitems = p.tiles_m * p.tiles_n * p.split_k;
+  const int grid = gridDim.x;
+  // workgroup b sits on XCD b % 8: give each XCD a run of consecutive items
+  const int perm = (grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // Two workgroups share a CU so that one's ring fill and epilogue (no MFMA) overlap the other's MFMA stream -- which
-  // only happens if they are OUT OF PHASE.  All workgroups of the first residency wave start together and every tile
-  // takes the same time, so the second residents (linear ids 256..511: the dispatcher places one workgroup per CU
-  // before it doubles up) are held back once; later workgroups inherit the slot's phase.
-  if (p.stagger > 0) {
-    const int lin = blockIdx.x + blockIdx.y * gridDim.x;
-    if (lin >= 256 && lin < 512)
-      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
-  // per-wave DMA plan: CPW chunks per stage, fixed operand / chunk per slot i, per-lane source pointers that advance by
-  // one stage (32 k) per issue; destinations are wave-uniform byte offsets inside a stage buffer.
+  // ---- DMA cursor: per-wave plan of CPW pieces per stage (fixed operand / chunk per slot i), per-lane source pointers
+  // that advance by one stage (32 k) per issue; destinations are wave-uniform byte offsets inside a stage buffer. ----
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const bf16_t* src[CPW];
   int64_t step[CPW];
@@ -689,136 +891,89 @@ void gemm_ring_kernel(GemmKArgs p) {
   for (int i = 0; i < CPW; ++i) {
     const int q = wave * CPW + i;   // wave-uniform
     if (q < RC::A_CHUNKS) {
-      src[i] = dma_src<A_T, BM>(p.A, p.lda, m0, p.M, k_begin, q, lane);
       step[i] = A_T ? (int64_t)RC::BKS * p.lda : (int64_t)RC::BKS;
       dst[i] = (uint32_t)(q * 1024);
     } else {
-      src[i] = dma_src<B_T, BN>(p.B, p.ldb, n0, p.N, k_begin, q - RC::A_CHUNKS, lane);
       step[i] = B_T ? (int64_t)RC::BKS * p.ldb : (int64_t)RC::BKS;
       dst[i] = (uint32_t)(RC::A_BYTES + (q - RC::A_CHUNKS) * 1024);
     }
   }
-  auto issue = [&](int s) {
-    if (s >= PD_ && (p.ablate & 1)) return;
-    const uint32_t st = smem_base + (uint32_t)((s % NS) * RC::STAGE_BYTES);
+  int cur_it = 0, cur_s = 0, cur_ns = 0;   // cursor: item iteration, stage inside it, stages of it
+  bool cur_live = false;
+  auto cursor_open = [&](int it) {
+    const int id = it * grid + perm;
+    cur_live = id < nitems;
+    if (!cur_live) return;
+    const RingItem w = ring_item<RC>(p, id);
+    cur_ns = w.ns; cur_s = 0;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int q = wave * CPW + i;
+      src[i] = (q < RC::A_CHUNKS) ? dma_src<A_T, BM>(p.A, p.lda, w.m0, p.M, w.k_begin, q, lane)
+                                  : dma_src<B_T, BN>(p.B, p.ldb, w.n0, p.N, w.k_begin, q - RC::A_CHUNKS, lane);
+    }
+  };
+  int islot = 0, inflight = 0;             // ring slot of the next issue; stages issued and not yet consumed
+  auto issue_next = [&]() {
+    if (!cur_live) return;
+    const uint32_t st = smem_base + (uint32_t)(islot * RC::STAGE_BYTES);
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       glds16(src[i], __builtin_amdgcn_readfirstlane(st + dst[i]));
       src[i] += step[i];
     }
+    islot = (islot + 1 == NS) ? 0 : islot + 1;
+    ++inflight;
+    if (++cur_s == cur_ns) cursor_open(++cur_it);
   };
-  // Fragment registers are double-buffered across the two k16-steps of a stage AND across stages: F[0] always holds
-  // k-step 0 of the stage being computed (loaded during the previous stage's second MFMA group), F[1] k-step 1 (loaded
-  // during the first MFMA group).  The stage barrier therefore sits between two MFMA groups whose operands are already
-  // in registers: the matrix pipe keeps 8 * TM * TN / 8 MFMAs queued while the waves synchronise.
-  bf16x8 fa[2][TM] = {}, fb[2][TN] = {};
-  auto load_frags = [&](int buf, const char* st, int ks) {
-    if (p.ablate & 4) return;
+  cursor_open(0);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) fa[buf][j] = ring_frag<A_T, BM>(st, wm * (TM * 32) + j * 32, ks, lane);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) fb[buf][i] = ring_frag<B_T, BN>(st + RC::A_BYTES, wn * (TN * 32) + i * 32, ks, lane);
-  };
-  auto mfma_group = [&](int buf) {
-    if (p.ablate & 2) return;
+  for (int d = 0; d < PD; ++d) issue_next();
+
+  char* patch = smem + RC::RING_BYTES + wave * RC::PATCH_BYTES;
+  int cslot = 0;
+  for (int it = 0;; ++it) {
+    const int id = it * grid + perm;
+    if (id >= nitems) break;
+    const RingItem w = ring_item<RC>(p, id);
+
+    f32x16 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[buf][i], fa[buf][j], acc[i][j], 0, 0, 0);
-  };
-
-  constexpr int PD = NS - 1;   // DMA prefetch distance in stages
-  static_assert(PD == 2 || PD == 3, "wait ladders below cover 3- and 4-stage rings");
-  // own pieces of stage s landed, given that stages up to min(s + PD - 1, ns - 1) have been issued
-  auto wait_stage = [&](int s) {
-    if (PD == 3 && s + 2 < ns) wait_vmcnt<2 * CPW>();
-    else if (s + 1 < ns) wait_vmcnt<CPW>();
-    else wait_vmcnt<0>();
-  };
 #pragma unroll
-  for (int s = 0; s < PD; ++s)
-    if (s < ns) issue(s);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (RC::NWAVES == 8 && p.pingpong) {
-    // Ping-pong: waves w and w+4 share a SIMD.  One LDS-DMA piece costs its wave 60..185 clocks of issue time
-    // (MI355X_MICROARCH.md latency table) and a stage needs CPW of them plus 2 (TM + TN) fragment reads -- about as long
-    // as the stage's 2 TM TN MFMAs run.  If all waves do that at the same time (right after the stage barrier) the
-    // matrix cores idle for it; so the two waves of a SIMD alternate: in every half-stage one is in its LOAD segment
-    // (fragment reads of stage s into registers + DMA issue of stage s+PD), the other in its COMPUTE segment (MFMAs on
-    // the fragments it loaded one half-stage earlier).  Two workgroup barriers per stage keep the halves aligned:
-    //   half 2s   : A loads stage s      | B computes stage s-1
-    //   half 2s+1 : A computes stage s   | B loads stage s
-    // Stage s is complete before half 2s (every wave waits for its own pieces before that barrier); its buffer is
-    // rewritten by the DMA of stage s+1+PD, issued in halves 2s+2 / 2s+3, after the last reads (B, half 2s+1) have
-    // drained (lgkmcnt(0) before the barrier).
-    const bool second = wave >= 4;
-    if (!second) {
-      for (int s = 0; s < ns; ++s) {
-        const char* st = smem + (s % NS) * RC::STAGE_BYTES;
-        wait_stage(s);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        load_frags(0, st, 0);
-        load_frags(1, st, 1);
-        if (s + PD < ns) issue(s + PD);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0);
-        mfma_group(1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      for (int s = 0; s < ns; ++s) {
-        const char* st = smem + (s % NS) * RC::STAGE_BYTES;
-        wait_stage(s);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (s > 0) { mfma_group(0); mfma_group(1); }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        load_frags(0, st, 0);
-        load_frags(1, st, 1);
-        if (s + PD < ns) issue(s + PD);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (ns > 0) { mfma_group(0); mfma_group(1); }
-    }
-  } else {
-    if (ns > 0) {
-      wait_stage(0);
-      __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < w.ns; ++s) {
+      // this wave's pieces of the oldest stage in flight have landed; the younger ones stay in flight
+      if (inflight >= 3) wait_vmcnt<2 * CPW>();
+      else if (inflight == 2) wait_vmcnt<CPW>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // everybody's pieces are visible; everybody is done with the previous stage
       __builtin_amdgcn_sched_barrier(0);
-      load_frags(0, smem, 0);
-    }
-    for (int s = 0; s < ns; ++s) {
-      const char* st = smem + (s % NS) * RC::STAGE_BYTES;
-      const char* st_next = smem + ((s + 1) % NS) * RC::STAGE_BYTES;
-      if (s + 1 < ns) {
-        // certify stage s+1; younger stages stay in flight.  The barrier also tells that every wave is done with
-        // stage s-1, whose buffer the next DMA issue overwrites.
-        if (PD == 3 && s + 2 < ns) wait_vmcnt<CPW>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+      --inflight;
+      issue_next();                    // refills the previous stage's buffer (possibly with the NEXT item's data)
+      __builtin_amdgcn_sched_barrier(0);
+      const char* st = smem + cslot * RC::STAGE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fa[j] = ring_frag<A_T, BM>(st, wm * (TM * 32) + j * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fb[i] = ring_frag<B_T, BN>(st + RC::A_BYTES, wn * (TN * 32) + i * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (s + PD < ns) issue(s + PD);
-      __builtin_amdgcn_sched_barrier(0);
-      load_frags(1, st, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_group(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < ns) load_frags(0, st_next, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_group(1);
-      __builtin_amdgcn_sched_barrier(0);
+      cslot = (cslot + 1 == NS) ? 0 : cslot + 1;
     }
+    ring_epilogue<TM>(p, acc, patch, lane, w.m0 + wm * (TM * 32), w.n0 + wn * 64, w.split);
   }
-
-  tile_epilogue<TM>(p, acc, smem, wave, lane, m0 + wm * (TM * 32), n0 + wn * 64, split);
 }
 
 // split-K reduction: C[m,n] (+)= sum_s ws[s][m][n]
@@ -837,13 +992,24 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* C, int6
   }
 }
 
-int g_gemm_variant = -1;   // 0 auto; force: 2 register-staged S, 4 / 5 / 6 / 7 ring 256^2 / 256x128 / 128^2; 11..16 ablations
+int g_gemm_variant = -1;   // 0 auto; force: 2 register-staged S, 4 / 5 / 6 ring 256^2 / 256x128 / 128^2; 11..16 ablations
 inline int gemm_variant() {
   if (g_gemm_variant < 0) {
     const char* e = getenv("DVLA_GEMM_VARIANT");
     g_gemm_variant = e ? atoi(e) : 0;
   }
   return g_gemm_variant;
+}
+
+inline int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
 }
 
 inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -880,7 +1046,9 @@ void launch_ring_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RC::SMEM_BYTES);
     attr_set = true;
   }
-  dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)split_k, 1), block(RC::NT, 1, 1);
+  const int64_t items = (int64_t)a.tiles_m * a.tiles_n * split_k;
+  const int64_t slots = (int64_t)num_cus() * RC::WG_PER_CU;
+  dim3 grid((unsigned)(items < slots ? items : slots), 1, 1), block(RC::NT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, RC::SMEM_BYTES, stream, a);
 }
 template <class RC>
@@ -896,8 +1064,9 @@ void launch_ring(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
 }
 template <class RC>
 bool ring_ok(const GemmKArgs& a, int combo) {
-  if (!a.a_vec || !a.b_vec) return false;
-  if (a.K % 32 != 0 || a.k_per_split % 32 != 0) return false;
+  if (!a.a_vec || !a.b_vec || !a.c_vec || !a.aux_vec || !a.epi_vec) return false;
+  if (a.K < 32 || a.K % 32 != 0 || a.k_per_split % 32 != 0 || (a.N & 63) != 0) return false;
+  if ((int64_t)((a.M + RC::BM - 1) / RC::BM) * ((a.N + RC::BN - 1) / RC::BN) * a.split_k >= (1ll << 30)) return false;
   if (a.M < RC::BM || a.N < RC::BN) return false;
   if ((combo & 2) && (a.M % RC::BM != 0)) return false;   // r-contiguous A: whole row panels only
   if ((combo & 1) && (a.N % RC::BN != 0)) return false;
@@ -927,9 +1096,6 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       return DVLA_ERR_ARG;
   }
   GemmKArgs a;
-  a.stagger = 0;
-  a.pingpong = 1;
-  a.ablate = 0;
   a.A = reinterpret_cast<const bf16_t*>(q->A); a.lda = q->lda;
   a.B = reinterpret_cast<const bf16_t*>(q->B); a.ldb = q->ldb;
   a.C = q->C; a.ldc = q->ldc; a.c_f32 = (q->c_dtype == DVLA_DT_F32);
@@ -977,33 +1143,33 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       default: launch_one<CfgS, false, false, 6>(a, split_k, stream); break;
     }
   } else {
-    // Configuration choice (measured on MI355X, profiles/r01_gemm_variants.txt): the LDS-DMA ring kernels beat the
-    // register-staged S kernel whenever they apply; among them pick max(relative tile speed x chip fill): the 256^2
-    // ring is ~1.25x the 128^2 one per tile, the 256x128 one ~1.12x, but they run 256 workgroups at a time, not 512.
+    // Configuration choice: cheapest by a two-constant model per ring configuration, T = rounds * (fixed + stage * ns),
+    // rounds = ceil(work items / workgroup slots), ns = 32-wide K stages per item.  Constants in microseconds per
+    // round, measured on MI355X with tests/gpu_gemm_variants.py / the K sweep in profiles/r01_gemm_variants.txt:
+    // the 256^2 tile has the fastest main loop per flop (0.88 us per stage for twice the area of the others' 0.58)
+    // but the most expensive epilogue (18.7 us vs 5.9 / 5.7 per round).  The register-staged kernel is the fallback
+    // for shapes the ring kernels do not take (ragged N, unaligned operands, tiny problems).
     int choice = 0;   // 0 = register-staged S (always valid), 1 = ring L, 2 = ring M, 3 = ring S
     if (variant == 0) {
-      double best = 0.0;
-      if (ring_ok<RCfgS>(a, combo)) { best = fill(((q->M + 127) / 128) * ((q->N + 127) / 128) * split_k, 512); choice = 3; }
-      if (ring_ok<RCfgM>(a, combo)) {
-        const double e = 1.12 * fill(((q->M + 255) / 256) * ((q->N + 127) / 128) * split_k, 256);
-        if (e > best) { best = e; choice = 2; }
-      }
-      if (ring_ok<RCfgL>(a, combo)) {
-        const double e = 1.25 * fill(((q->M + 255) / 256) * ((q->N + 255) / 256) * split_k, 256);
-        if (e > best) { best = e; choice = 1; }
-      }
+      const double ns = (double)(a.k_per_split < a.K ? a.k_per_split : a.K) / 32.0;
+      const int slots = num_cus();
+      double best = 1e30;
+      auto consider = [&](int c, int64_t bm, int64_t bn, int wg_per_cu, double fixed_us, double stage_us) {
+        const int64_t items = ((q->M + bm - 1) / bm) * ((q->N + bn - 1) / bn) * split_k;
+        const int64_t rounds = (items + (int64_t)slots * wg_per_cu - 1) / ((int64_t)slots * wg_per_cu);
+        const double t = (double)rounds * (fixed_us + stage_us * ns);
+        if (t < best) { best = t; choice = c; }
+      };
+      if (ring_ok<RCfgS>(a, combo)) consider(3, 128, 128, 2, 5.7, 0.58);
+      if (ring_ok<RCfgM>(a, combo)) consider(2, 256, 128, 1, 5.9, 0.58);
+      if (ring_ok<RCfgL>(a, combo)) consider(1, 256, 256, 1, 18.7, 0.88);
     } else if (variant == 4 && ring_ok<RCfgL>(a, combo)) choice = 1;
     else if (variant == 5 && ring_ok<RCfgM>(a, combo)) choice = 2;
     else if (variant == 6 && ring_ok<RCfgS>(a, combo)) choice = 3;
-    else if (variant >= 7 && variant <= 9 && ring_ok<RCfgD>(a, combo)) choice = 4;
-    if (variant >= 30 && variant < 40) { a.ablate = variant - 30; if (ring_ok<RCfgL>(a, combo)) choice = 1; }
-    if (variant >= 40 && variant < 50) { a.ablate = variant - 40; a.pingpong = 0; if (ring_ok<RCfgL>(a, combo)) choice = 1; }
-    a.stagger = (choice == 4) ? (variant == 8 ? 0 : variant == 9 ? 4 : 2) : 0;
     switch (choice) {
       case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;
       case 2: launch_ring<RCfgM>(a, combo, split_k, stream); break;
       case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
-      case 4: launch_ring<RCfgD>(a, combo, split_k, stream); break;
       default: launch_cfg<CfgS>(a, combo, split_k, stream); break;
     }
   }

@@ -80,12 +80,16 @@ def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", re
         out.append(metrics("preact", pre, ref, TOL_FWD))
         ref = R.bf16_round(ref)
     ref = R.act(ref, act)
+    if dropout_p > 0:
+        ref = R.dropout_elementwise(ref, dropout_p, sd)
+    # the reference materialises `dropout(act(linear(x)))` / `dY @ W` as a bf16 tensor BEFORE the residual add /
+    # the act' multiply (models/gpt2.py:329-339, autograd of gpt2.py:296-301): one rounding in between
+    if (dact or residual) and not out_f32:
+        ref = R.bf16_round(ref)
     if dact:
         x = aux_t.clone().requires_grad_(True)
         R.act(x, dact).sum().backward()
         ref = ref * x.grad
-    if dropout_p > 0:
-        ref = R.dropout_elementwise(ref, dropout_p, sd)
     if residual:
         ref = ref + res_t
     tag = f"gemm M{M} N{N} K{K} at{int(a_trans)} bt{int(b_trans)} bias{int(bias)} {act} res{int(residual)} f32{int(out_f32)} sk{split_k} p{dropout_p} dact{dact}"
@@ -220,6 +224,7 @@ def check_linear_fn(M, K, N, act="none", conv1d=False, residual=False, bias=True
     if dropout_p > 0:
         yr = R.dropout_elementwise(yr.reshape(-1, N), dropout_p, sd).view(yr.shape)
     if residual:
+        yr = yr + (R.bf16_round(yr.detach()) - yr.detach())  # the reference adds the residual to a bf16 tensor
         yr = yr + rr
     yr.backward(dy)
     tag = f"linear M{M} K{K} N{N} {act} conv1d{int(conv1d)} res{int(residual)} p{dropout_p}"
@@ -254,6 +259,7 @@ def check_mlp_fn(M, K, Hd, act="gelu_erf", conv1d=False, dropout_p=0.0, seed=0):
     z = R.linear(h, ref[3], ref[4], conv1d)
     if dropout_p > 0:
         z = R.dropout_elementwise(z, dropout_p, sd)
+    z = z + (R.bf16_round(z.detach()) - z.detach())  # `hidden + mlp(hidden)`: the branch output is a bf16 tensor
     yr = ref[0] + z
     yr.backward(dy)
     tag = f"mlp M{M} K{K} H{Hd} {act} conv1d{int(conv1d)} p{dropout_p}"
@@ -316,6 +322,16 @@ def all_checks(quick=False):
         (check_gemm, dict(M=256, N=128, K=64, dropout_p=0.1, residual=True)),
         (check_gemm, dict(M=256, N=128, K=64, dact="gelu_tanh")),
         (check_gemm, dict(M=1024, N=1024, K=1024, bias=True, act="relu")),
+        # persistent ring kernels: several work items per workgroup, ragged M / N edges, every epilogue flavour
+        (check_gemm, dict(M=4352, N=4096, K=96, bias=True)),
+        (check_gemm, dict(M=4224, N=2048, K=64, b_trans=True)),
+        (check_gemm, dict(M=4300, N=1152, K=128, bias=True, act="gelu_erf", residual=True)),
+        (check_gemm, dict(M=2100, N=1024, K=160, bias=True, act="gelu_tanh", want_preact=True)),
+        (check_gemm, dict(M=2048, N=1024, K=96, b_trans=True, dact="gelu_tanh")),
+        (check_gemm, dict(M=2049, N=1088, K=64, bias=True, dropout_p=0.1, residual=True)),
+        (check_gemm, dict(M=1024, N=768, K=4128, a_trans=True, b_trans=True, split_k=5, out_f32=True)),
+        (check_gemm, dict(M=1300, N=832, K=64, bias=True, out_f32=True, residual=True)),
+        (check_gemm, dict(M=768, N=3072, K=2048, a_trans=True, b_trans=True, split_k=3)),
     ]
     L += [
         (check_layernorm, dict(rows=37, cols=768, eps=1e-6)),
