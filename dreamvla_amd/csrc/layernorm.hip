@@ -28,6 +28,15 @@ __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
   f[4] = bf2f((bf16_t)(u.z & 0xffff)); f[5] = bf2f((bf16_t)(u.z >> 16));
   f[6] = bf2f((bf16_t)(u.w & 0xffff)); f[7] = bf2f((bf16_t)(u.w >> 16));
 }
+// eight consecutive parameters (vector index vi) as fp32; parameter tensors are 16-B aligned (checked by the host)
+__device__ __forceinline__ void load_param8(const void* p, int f32, int vi, float (&f)[8]) {
+  if (f32) {
+    const float4 a = reinterpret_cast<const float4*>(p)[2 * vi], b = reinterpret_cast<const float4*>(p)[2 * vi + 1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+    unpack8(reinterpret_cast<const uint4*>(p)[vi], f);
+  }
+}
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
 }
@@ -42,6 +51,18 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16_t* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols >> 3;
   const float inv_n = 1.0f / (float)cols;
+  // a lane's columns are the same for every row: gamma / beta live in registers for the whole kernel
+  float gam[VPL][8], bet[VPL][8];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gam[i][e] = 1.0f; bet[i][e] = 0.0f; }
+    if (vi < nvec) {
+      if (gamma) load_param8(gamma, pf32, vi, gam[i]);
+      if (beta) load_param8(beta, pf32, vi, bet[i]);
+    }
+  }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const uint4* xr = reinterpret_cast<const uint4*>(x + row * cols);
     float v[VPL][8];
@@ -80,12 +101,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16_t* __rest
       if (vi < nvec) {
         float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float h = (v[i][e] - mean) * rstd;
-          if (gamma) h *= param_at(gamma, pf32, vi * 8 + e);
-          if (beta) h += param_at(beta, pf32, vi * 8 + e);
-          o[e] = h;
-        }
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gam[i][e] + bet[i][e];
         yr[vi] = pack8(o);
       }
     }
@@ -107,10 +123,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
   for (int i = 0; i < VPL; ++i) {
     const int vi = lane + 64 * i;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      gam[i][e] = (gamma && vi < nvec) ? param_at(gamma, pf32, vi * 8 + e) : 1.0f;
-      dg[i][e] = 0.f; db[i][e] = 0.f;
-    }
+    for (int e = 0; e < 8; ++e) { gam[i][e] = 1.0f; dg[i][e] = 0.f; db[i][e] = 0.f; }
+    if (gamma && vi < nvec) load_param8(gamma, pf32, vi, gam[i]);
   }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const uint4* xr = reinterpret_cast<const uint4*>(x + row * cols);
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 
 int fwd_blocks(int64_t rows) {
   int64_t b = (rows + 3) / 4;
-  if (b > 8192) b = 8192;
+  if (b > 2048) b = 2048;   // 8 workgroups per CU; each wave keeps gamma / beta in registers over its ~rows/8192 rows
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -213,6 +227,7 @@ extern "C" int dvla_layernorm_fwd(const void* x, const void* gamma, const void* 
   if (!x || !y || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
   if (rows == 0) return DVLA_OK;
   if (cols % 8 != 0 || cols > 64 * 8 * LN_MAX_VPL) return DVLA_ERR_UNSUPPORTED;
+  if (((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) != 0) return DVLA_ERR_UNSUPPORTED;   // parameters are read as 16-B vectors
   const int vpl = (int)((cols / 8 + 63) / 64);
   const int pf32 = (param_dtype == DVLA_DT_F32);
   dim3 grid(fwd_blocks(rows)), block(LN_THREADS);
@@ -235,6 +250,7 @@ extern "C" int dvla_layernorm_bwd(const void* dy, const void* x, const void* gam
   if ((dgamma || dbeta) && !partial) return DVLA_ERR_ARG;
   if (rows == 0) return DVLA_OK;
   if (cols % 8 != 0 || cols > 64 * 8 * LN_MAX_VPL) return DVLA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(gamma) & 15) != 0) return DVLA_ERR_UNSUPPORTED;   // parameters are read as 16-B vectors
   const int vpl = (int)((cols / 8 + 63) / 64);
   const int pf32 = (param_dtype == DVLA_DT_F32);
   int64_t nb = (rows + 3) / 4;
