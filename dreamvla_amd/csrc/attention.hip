@@ -249,6 +249,206 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
 }
 
 // ====================================================================================================
+// forward, LDS-DMA ring version (the default; the kernel above is the fallback for masks / key lists too large for LDS)
+//
+//   K and V tiles (32 keys x 64 d, 4 KiB each, row-major as they lie in HBM) are copied global -> LDS by
+//   global_load_lds_dwordx4 through a 4-stage ring, three tiles ahead of the one being multiplied: no staging
+//   registers, no ds_write pass, and the HBM / L2 latency of a tile is hidden behind the two tiles before it (the
+//   register-staged kernel above looks ONE 32-key tile ahead -- ~300 MFMA clocks -- and stalls on every tile).
+//     K image : rows of 128 B, d-octet o of key r in slot o ^ ((r >> 1) & 7) (swizzle applied on the per-lane SOURCE
+//               address, LDS image lane-linear as LDS-DMA requires): conflict-free ds_read_b128 fragments.
+//     V image : the same rows with slot o ^ (4 * ((r >> 1) & 1)); V^T fragments come straight out of it with the
+//               hardware transpose ds_read_b64_tr_b16 (lane = d, 4 consecutive keys per instruction), conflict-free.
+//   The 2-bit tile flags of the workgroup's four query tiles, the key gather list and the per-query visibility words
+//   are copied to LDS once, so the tile loop contains no global load except the DMA (an ordinary load inside the loop
+//   would make hipcc drain the DMA ring with s_waitcnt vmcnt(0) at its first use).
+// ====================================================================================================
+constexpr int FA_NS = 4, FA_TILE = 4096, FA_STAGE = 2 * FA_TILE, FA_RING = FA_NS * FA_STAGE;
+
+__device__ __forceinline__ void fa_glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void fa_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef __attribute__((ext_vector_type(4))) short fa_s16x4;
+// K fragment: key row (lane & 31), d-slots 16 s + 8 g .. + 7
+__device__ __forceinline__ bf16x8 fa_frag_k(const char* kt, int row, int s, int g) {
+  return *reinterpret_cast<const bf16x8*>(kt + row * 128 + ((((2 * s + g) ^ ((row >> 1) & 7))) << 4));
+}
+// V^T fragment for output half db (d = 32 db + (lane & 31)) and key half mm: k-slot j of lane group g is key
+// 16 mm + 8 (j >> 2) + 4 g + (j & 3) -- the key of P register 8 mm + j (acc_row) -- fetched as two transposing reads.
+__device__ __forceinline__ bf16x8 fa_frag_vt(const char* vt, int db, int mm, int lane) {
+  const int gi = lane >> 4, c = lane & 15;
+  const int d = 32 * db + 16 * (gi & 1) + 4 * (c & 3);            // first of the 4 d values this lane FETCHES
+  union { fa_s16x4 h[2]; bf16x8 v; } u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int key = 16 * mm + 8 * h + 4 * (gi >> 1) + (c >> 2);   // key row this lane fetches from
+    const int byte = key * 128 + ((((d >> 3) ^ (4 * ((key >> 1) & 1)))) << 4) + (d & 7) * 2;
+    u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fa_s16x4*)(vt + byte));
+  }
+  return u.v;
+}
+
+__host__ __device__ inline int fa_pad16(int n) { return (n + 15) & ~15; }
+// dynamic LDS of the ring kernels: ring | tile flags [nkt] | key gather list [Lk] | visibility words [128][nkt]
+__host__ __device__ inline size_t fa_smem_bytes(int nkt, int Lk, bool has_index, bool has_bits) {
+  return (size_t)FA_RING + fa_pad16(nkt) + (has_index ? (size_t)fa_pad16(Lk * 4) : 0) + (has_bits ? (size_t)128 * nkt * 4 : 0);
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_ring_kernel(AttnKArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qt0 = blockIdx.x * 4;
+  const int qt = qt0 + wave;
+  const int q = qt * 32 + l31;
+  const bool q_ok = q < p.Lq;
+  const float scale_log2 = p.scale * LOG2E;
+  const bool has_bits = p.tile_map != nullptr && p.bits_q != nullptr;
+
+  uint8_t* flags = reinterpret_cast<uint8_t*>(smem + FA_RING);
+  int32_t* kidx = reinterpret_cast<int32_t*>(smem + FA_RING + fa_pad16(p.nkt));
+  uint32_t* bits = reinterpret_cast<uint32_t*>(smem + FA_RING + fa_pad16(p.nkt) + (p.key_index ? fa_pad16(p.Lk * 4) : 0));
+
+  const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
+  const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
+  const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
+
+  for (int kt = t; kt < p.nkt; kt += AT_THREADS) {
+    int f = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) f |= tile_flag(p, qt0 + w, kt) << (2 * w);
+    flags[kt] = (uint8_t)f;
+  }
+  if (p.key_index)
+    for (int i = t; i < p.Lk; i += AT_THREADS) kidx[i] = p.key_index[i];
+  if (has_bits)
+    for (int i = t; i < 128 * p.nkt; i += AT_THREADS) {
+      const int ql = i / p.nkt, kt = i - ql * p.nkt;
+      const int qq = qt0 * 32 + ql;
+      bits[i] = qq < p.Lq ? p.bits_q[(int64_t)qq * p.nkt + kt] : 0u;
+    }
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 u = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
+    qf[s] = *reinterpret_cast<const bf16x8*>(&u);
+  }
+  __syncthreads();
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 oacc[2] = {zero16(), zero16()};
+  const int rowid = (b * p.H + h) * p.Lq + q;
+  uint32_t rowkey = 0;
+  if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
+
+  auto next_needed = [&](int kt) -> int {
+    while (kt < p.nkt && __builtin_amdgcn_readfirstlane((int)flags[kt]) == 0) ++kt;
+    return kt < p.nkt ? kt : -1;
+  };
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // wave w copies rows 8w .. 8w+7 of the K tile and of the V tile: lane -> (row 8w + lane/8, LDS slot lane % 8)
+  const int rl = 8 * wave + (lane >> 3);
+  const int oct_k = (lane & 7) ^ ((rl >> 1) & 7);
+  const int oct_v = (lane & 7) ^ (4 * ((rl >> 1) & 1));
+  auto issue = [&](int kt, int slot) {
+    int row = kt * 32 + rl;
+    row = row < p.Lk ? row : p.Lk - 1;
+    const int64_t src = p.key_index ? (int64_t)kidx[row] : (int64_t)row;
+    const uint32_t dst = smem_base + (uint32_t)(slot * FA_STAGE + wave * 1024);
+    fa_glds16(kb + src * p.kst + oct_k * 8, __builtin_amdgcn_readfirstlane(dst));
+    fa_glds16(vb + src * p.vst + oct_v * 8, __builtin_amdgcn_readfirstlane(dst + FA_TILE));
+  };
+
+  int kt = next_needed(0);
+  int kti = kt, islot = 0, cslot = 0, inflight = 0;
+#pragma unroll
+  for (int d = 0; d < FA_NS - 1; ++d)
+    if (kti >= 0) {
+      issue(kti, islot);
+      islot = (islot + 1) & (FA_NS - 1); ++inflight;
+      kti = next_needed(kti + 1);
+    }
+  while (kt >= 0) {
+    if (inflight >= 3) fa_wait_vmcnt<4>();
+    else if (inflight == 2) fa_wait_vmcnt<2>();
+    else fa_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    --inflight;
+    if (kti >= 0) {
+      issue(kti, islot);
+      islot = (islot + 1) & (FA_NS - 1); ++inflight;
+      kti = next_needed(kti + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int flag = (__builtin_amdgcn_readfirstlane((int)flags[kt]) >> (2 * wave)) & 3;
+    if (flag != 0) {
+      const char* ks = smem + cslot * FA_STAGE;
+      const char* vs = ks + FA_TILE;
+      f32x16 sacc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_k(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
+      const int k0 = kt * 32;
+      uint32_t vis = 0xffffffffu;
+      if (flag == 2) vis = bits[(wave * 32 + l31) * p.nkt + kt];
+      if (k0 + 32 > p.Lk) vis &= low_mask(p.Lk - k0);
+      float sv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
+      if (__any(vis != 0xffffffffu)) {
+        const uint32_t vg = vis >> (4 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = vis_bit(vg, r) ? sv[r] : -INFINITY;
+      }
+      float mt = sv[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sv[r]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt * scale_log2);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2(m_run - m_safe);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sv[r] = fast_exp2(fmaf(sv[r], scale_log2, -m_safe)); rs += sv[r]; }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+      }
+      if (p.has_drop) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)(k0 + acc_row(r, g)));
+          sv[r] = (hsh >= p.drop_thr) ? sv[r] * p.inv_keep : 0.f;
+        }
+      }
+      const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_vt(vs, db, 0, lane), pf0, oacc[db], 0, 0, 0);
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_vt(vs, db, 1, lane), pf1, oacc[db], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cslot = (cslot + 1) & (FA_NS - 1);
+    kt = next_needed(kt + 1);
+  }
+  if (q_ok) {
+    const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
+    store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g);
+    if (p.lse && g == 0) p.lse[rowid] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
+  }
+}
+
+// ====================================================================================================
 // backward: delta[b,h,q] = sum_d dO * O   (8 lanes per row of 64)
 // ====================================================================================================
 __global__ void attn_delta_kernel(AttnKArgs p) {
@@ -560,13 +760,24 @@ int fill_args(const dvla_attn_params* q, AttnKArgs& a) {
 
 }  // namespace
 
+// DVLA_ATTN_STAGED=1 selects the register-staged kernels (A/B measurements, tests of the fallback path)
+static bool attn_force_staged() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DVLA_ATTN_STAGED"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   AttnKArgs a;
   int rc = fill_args(q, a);
   if (rc != DVLA_OK) return rc;
   dim3 grid((unsigned)((a.nqt + 3) / 4), (unsigned)a.H, (unsigned)a.B), block(AT_THREADS);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, a);
+  const size_t smem = fa_smem_bytes(a.nkt, a.Lk, a.key_index != nullptr, a.tile_map != nullptr && a.bits_q != nullptr);
+  if (smem <= 64 * 1024 && !attn_force_staged())
+    hipLaunchKernelGGL(attn_fwd_ring_kernel, grid, block, smem, stream, a);
+  else   // mask tables / key list too large for LDS
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, a);
   return dvla_check_launch();
 }
 
