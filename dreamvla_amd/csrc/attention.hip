@@ -760,6 +760,324 @@ int fill_args(const dvla_attn_params* q, AttnKArgs& a) {
 
 }  // namespace
 
+namespace {
+
+// ====================================================================================================
+// backward, LDS-DMA ring versions.  Same ring as the forward kernel; every 32 x 64 tile is stored ONCE, row-major with
+// 16-byte slot o of row r at o ^ fa_sw(r), fa_sw(r) = ((r>>1)&1)<<2 | (r>>2)&3.  That one image serves both fragment
+// kinds conflict-free: row fragments by ds_read_b128 (the 8 rows of equal parity in a 16-lane read group get 8
+// different slots) and transposed fragments by ds_read_b64_tr_b16 (keys k and k+2, which share the bank row, land in
+// different 64-byte halves) -- so the pair-interleaved second copies of the register-staged kernels are gone.
+// ====================================================================================================
+__device__ __forceinline__ int fa_sw(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ bf16x8 fa_frag_rm(const char* tile, int row, int s, int g) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((((2 * s + g) ^ fa_sw(row))) << 4));
+}
+// transposed fragment: lane = column d = 32 db + (lane & 31) of the tile, k-slot j of lane group g = tile row
+// 16 mm + 8 (j >> 2) + 4 g + (j & 3)  (= acc_row(8 mm + j, g), the row of P / dS register 8 mm + j)
+__device__ __forceinline__ bf16x8 fa_frag_tr(const char* tile, int db, int mm, int lane) {
+  const int gi = lane >> 4, c = lane & 15;
+  const int d = 32 * db + 16 * (gi & 1) + 4 * (c & 3);
+  union { fa_s16x4 h[2]; bf16x8 v; } u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 16 * mm + 8 * h + 4 * (gi >> 1) + (c >> 2);
+    const int byte = row * 128 + ((((d >> 3) ^ fa_sw(row))) << 4) + (d & 7) * 2;
+    u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fa_s16x4*)(tile + byte));
+  }
+  return u.v;
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_ring_kernel(AttnKArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qt0 = blockIdx.x * 4;
+  const int qt = qt0 + wave;
+  const int q = qt * 32 + l31;
+  const bool q_ok = q < p.Lq;
+  const float scale_log2 = p.scale * LOG2E;
+  const bool has_bits = p.tile_map != nullptr && p.bits_q != nullptr;
+
+  uint8_t* flags = reinterpret_cast<uint8_t*>(smem + FA_RING);
+  int32_t* kidx = reinterpret_cast<int32_t*>(smem + FA_RING + fa_pad16(p.nkt));
+  uint32_t* bits = reinterpret_cast<uint32_t*>(smem + FA_RING + fa_pad16(p.nkt) + (p.key_index ? fa_pad16(p.Lk * 4) : 0));
+
+  const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
+  const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
+  const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
+  const bf16_t* dob = p.dout + (int64_t)b * p.dsb + (int64_t)h * p.dsh;
+
+  for (int kt = t; kt < p.nkt; kt += AT_THREADS) {
+    int f = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) f |= tile_flag(p, qt0 + w, kt) << (2 * w);
+    flags[kt] = (uint8_t)f;
+  }
+  if (p.key_index)
+    for (int i = t; i < p.Lk; i += AT_THREADS) kidx[i] = p.key_index[i];
+  if (has_bits)
+    for (int i = t; i < 128 * p.nkt; i += AT_THREADS) {
+      const int ql = i / p.nkt, kt = i - ql * p.nkt;
+      const int qq = qt0 * 32 + ql;
+      bits[i] = qq < p.Lq ? p.bits_q[(int64_t)qq * p.nkt + kt] : 0u;
+    }
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 a = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
+    const uint4 c = load16(dob + (int64_t)q * p.dst + 16 * s + 8 * g, q_ok);
+    qf[s] = *reinterpret_cast<const bf16x8*>(&a);
+    dof[s] = *reinterpret_cast<const bf16x8*>(&c);
+  }
+  const int rowid = (b * p.H + h) * p.Lq + q;
+  const float lse2 = q_ok ? p.lse[rowid] * LOG2E : INFINITY;
+  const float dlt = q_ok ? p.delta[rowid] : 0.f;
+  uint32_t rowkey = 0;
+  if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
+  f32x16 dqacc[2] = {zero16(), zero16()};
+  __syncthreads();
+
+  auto next_needed = [&](int kt) -> int {
+    while (kt < p.nkt && __builtin_amdgcn_readfirstlane((int)flags[kt]) == 0) ++kt;
+    return kt < p.nkt ? kt : -1;
+  };
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int rl = 8 * wave + (lane >> 3);
+  const int oct = (lane & 7) ^ fa_sw(rl);
+  auto issue = [&](int kt, int slot) {
+    int row = kt * 32 + rl;
+    row = row < p.Lk ? row : p.Lk - 1;
+    const int64_t src = p.key_index ? (int64_t)kidx[row] : (int64_t)row;
+    const uint32_t dst = smem_base + (uint32_t)(slot * FA_STAGE + wave * 1024);
+    fa_glds16(kb + src * p.kst + oct * 8, __builtin_amdgcn_readfirstlane(dst));
+    fa_glds16(vb + src * p.vst + oct * 8, __builtin_amdgcn_readfirstlane(dst + FA_TILE));
+  };
+
+  int kt = next_needed(0);
+  int kti = kt, islot = 0, cslot = 0, inflight = 0;
+#pragma unroll
+  for (int d = 0; d < FA_NS - 1; ++d)
+    if (kti >= 0) {
+      issue(kti, islot);
+      islot = (islot + 1) & (FA_NS - 1); ++inflight;
+      kti = next_needed(kti + 1);
+    }
+  while (kt >= 0) {
+    if (inflight >= 3) fa_wait_vmcnt<4>();
+    else if (inflight == 2) fa_wait_vmcnt<2>();
+    else fa_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    --inflight;
+    if (kti >= 0) {
+      issue(kti, islot);
+      islot = (islot + 1) & (FA_NS - 1); ++inflight;
+      kti = next_needed(kti + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int flag = (__builtin_amdgcn_readfirstlane((int)flags[kt]) >> (2 * wave)) & 3;
+    if (flag != 0) {
+      const char* ks = smem + cslot * FA_STAGE;
+      const char* vs = ks + FA_TILE;
+      f32x16 sacc = zero16(), dpacc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(vs, l31, s, g), dof[s], dpacc, 0, 0, 0);
+      }
+      const int k0 = kt * 32;
+      uint32_t vis = 0xffffffffu;
+      if (flag == 2) vis = bits[(wave * 32 + l31) * p.nkt + kt];
+      if (k0 + 32 > p.Lk) vis &= low_mask(p.Lk - k0);
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(sacc[r], scale_log2, -lse2));
+      if (__any(vis != 0xffffffffu)) {
+        const uint32_t vg = vis >> (4 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[r] = vis_bit(vg, r) ? ds[r] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float dp = dpacc[r];
+        if (p.has_drop) {
+          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)(k0 + acc_row(r, g)));
+          dp = (hsh >= p.drop_thr) ? dp * p.inv_keep : 0.f;
+        }
+        ds[r] = ds[r] * (dp - dlt) * p.scale;
+      }
+      const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(ks, db, 0, lane), f0, dqacc[db], 0, 0, 0);
+        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(ks, db, 1, lane), f1, dqacc[db], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cslot = (cslot + 1) & (FA_NS - 1);
+    kt = next_needed(kt + 1);
+  }
+  if (q_ok) store_token(p.dq + (int64_t)b * p.dqsb + (int64_t)q * p.dqst + (int64_t)h * p.dqsh, dqacc, 1.0f, g);
+}
+
+// dynamic LDS of the dK/dV ring kernel: ring | tile flags [nqt] | visibility words [128 keys][nqt] | lse2 [32 nqt] | delta [32 nqt]
+__host__ __device__ inline size_t fa_dkv_smem_bytes(int nqt, bool has_bits) {
+  return (size_t)FA_RING + fa_pad16(nqt) + (has_bits ? (size_t)128 * nqt * 4 : 0) + (size_t)2 * 32 * nqt * 4;
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kt0 = blockIdx.x * 4;
+  const int ktw = kt0 + wave;
+  const int key = ktw * 32 + l31;
+  const bool key_ok = key < p.Lk;
+  const int key_row = (key_ok && p.key_index) ? p.key_index[key] : key;
+  const float scale_log2 = p.scale * LOG2E;
+  const bool has_bits = p.tile_map != nullptr && p.bits_k != nullptr;
+  const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
+  const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
+  const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
+  const bf16_t* dob = p.dout + (int64_t)b * p.dsb + (int64_t)h * p.dsh;
+  const int bh_row0 = (b * p.H + h) * p.Lq;
+
+  uint8_t* flags = reinterpret_cast<uint8_t*>(smem + FA_RING);
+  uint32_t* bits = reinterpret_cast<uint32_t*>(smem + FA_RING + fa_pad16(p.nqt));
+  float* lse2s = reinterpret_cast<float*>(smem + FA_RING + fa_pad16(p.nqt) + (has_bits ? (size_t)128 * p.nqt * 4 : 0));
+  float* dlts = lse2s + 32 * p.nqt;
+
+  for (int qt = t; qt < p.nqt; qt += AT_THREADS) {
+    int f = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) f |= tile_flag(p, qt, kt0 + w) << (2 * w);
+    flags[qt] = (uint8_t)f;
+  }
+  if (has_bits)
+    for (int i = t; i < 128 * p.nqt; i += AT_THREADS) {
+      const int kl = i / p.nqt, qt = i - kl * p.nqt;
+      const int kk = kt0 * 32 + kl;
+      bits[i] = kk < p.Lk ? p.bits_k[(int64_t)kk * p.nqt + qt] : 0u;
+    }
+  for (int i = t; i < 32 * p.nqt; i += AT_THREADS) {
+    lse2s[i] = i < p.Lq ? p.lse[bh_row0 + i] * LOG2E : INFINITY;   // q >= Lq: exp2(s - inf) = 0
+    dlts[i] = i < p.Lq ? p.delta[bh_row0 + i] : 0.f;
+  }
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 a = load16(kb + (int64_t)key_row * p.kst + 16 * s + 8 * g, key_ok);
+    const uint4 c = load16(vb + (int64_t)key_row * p.vst + 16 * s + 8 * g, key_ok);
+    kf[s] = *reinterpret_cast<const bf16x8*>(&a);
+    vf[s] = *reinterpret_cast<const bf16x8*>(&c);
+  }
+  f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
+  __syncthreads();
+
+  auto next_needed = [&](int qt) -> int {
+    while (qt < p.nqt && __builtin_amdgcn_readfirstlane((int)flags[qt]) == 0) ++qt;
+    return qt < p.nqt ? qt : -1;
+  };
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int rl = 8 * wave + (lane >> 3);
+  const int oct = (lane & 7) ^ fa_sw(rl);
+  auto issue = [&](int qt, int slot) {
+    int row = qt * 32 + rl;
+    row = row < p.Lq ? row : p.Lq - 1;
+    const uint32_t dst = smem_base + (uint32_t)(slot * FA_STAGE + wave * 1024);
+    fa_glds16(qb + (int64_t)row * p.qst + oct * 8, __builtin_amdgcn_readfirstlane(dst));
+    fa_glds16(dob + (int64_t)row * p.dst + oct * 8, __builtin_amdgcn_readfirstlane(dst + FA_TILE));
+  };
+
+  int qt = next_needed(0);
+  int qti = qt, islot = 0, cslot = 0, inflight = 0;
+#pragma unroll
+  for (int d = 0; d < FA_NS - 1; ++d)
+    if (qti >= 0) {
+      issue(qti, islot);
+      islot = (islot + 1) & (FA_NS - 1); ++inflight;
+      qti = next_needed(qti + 1);
+    }
+  while (qt >= 0) {
+    if (inflight >= 3) fa_wait_vmcnt<4>();
+    else if (inflight == 2) fa_wait_vmcnt<2>();
+    else fa_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    --inflight;
+    if (qti >= 0) {
+      issue(qti, islot);
+      islot = (islot + 1) & (FA_NS - 1); ++inflight;
+      qti = next_needed(qti + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int flag = (__builtin_amdgcn_readfirstlane((int)flags[qt]) >> (2 * wave)) & 3;
+    if (flag != 0) {
+      const char* qs = smem + cslot * FA_STAGE;
+      const char* dos = qs + FA_TILE;
+      f32x16 sacc = zero16(), dpacc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(qs, l31, s, g), kf[s], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(dos, l31, s, g), vf[s], dpacc, 0, 0, 0);
+      }
+      const int q0 = qt * 32;
+      float lse2[16], dlt[16];
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 a = *reinterpret_cast<const float4*>(lse2s + q0 + 8 * rq + 4 * g);
+        const float4 c = *reinterpret_cast<const float4*>(dlts + q0 + 8 * rq + 4 * g);
+        lse2[4 * rq] = a.x; lse2[4 * rq + 1] = a.y; lse2[4 * rq + 2] = a.z; lse2[4 * rq + 3] = a.w;
+        dlt[4 * rq] = c.x; dlt[4 * rq + 1] = c.y; dlt[4 * rq + 2] = c.z; dlt[4 * rq + 3] = c.w;
+      }
+      uint32_t vis = key_ok ? 0xffffffffu : 0u;  // bit i: query q0+i sees this lane's key
+      if (flag == 2) vis = bits[(wave * 32 + l31) * p.nqt + qt];
+      float pr[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[r] = fast_exp2(fmaf(sacc[r], scale_log2, -lse2[r]));
+      if (__any(vis != 0xffffffffu)) {
+        const uint32_t vg = vis >> (4 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = vis_bit(vg, r) ? pr[r] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float dp = dpacc[r];
+        float pdrop = pr[r];
+        if (p.has_drop) {
+          const uint32_t rk = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + q0 + acc_row(r, g)));
+          const bool keep = drop_hash_rk(rk, (uint32_t)key) >= p.drop_thr;
+          dp = keep ? dp * p.inv_keep : 0.f;
+          pdrop = keep ? pdrop * p.inv_keep : 0.f;
+        }
+        ds[r] = pr[r] * (dp - dlt[r]) * p.scale;
+        pr[r] = pdrop;
+      }
+      const bf16x8 pf0 = pack_frag(pr), pf1 = pack_frag(pr + 8);
+      const bf16x8 sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(dos, db, 0, lane), pf0, dvacc[db], 0, 0, 0);
+        dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(dos, db, 1, lane), pf1, dvacc[db], 0, 0, 0);
+        dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(qs, db, 0, lane), sf0, dkacc[db], 0, 0, 0);
+        dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(qs, db, 1, lane), sf1, dkacc[db], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cslot = (cslot + 1) & (FA_NS - 1);
+    qt = next_needed(qt + 1);
+  }
+  if (key_ok) {
+    store_token(p.dk + (int64_t)b * p.dksb + (int64_t)key_row * p.dkst + (int64_t)h * p.dksh, dkacc, 1.0f, g);
+    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, 1.0f, g);
+  }
+}
+
+}  // namespace
+
 // DVLA_ATTN_STAGED=1 selects the register-staged kernels (A/B measurements, tests of the fallback path)
 static bool attn_force_staged() {
   static int v = -1;
@@ -800,9 +1118,19 @@ extern "C" int dvla_attn_bwd(const dvla_attn_params* q, void* stream_) {
   rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
   dim3 block(AT_THREADS);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)((a.nqt + 3) / 4), (unsigned)a.H, (unsigned)a.B), block, 0, stream, a);
+  const size_t smem_dq = fa_smem_bytes(a.nkt, a.Lk, a.key_index != nullptr, a.tile_map != nullptr && a.bits_q != nullptr);
+  const size_t smem_dkv = fa_dkv_smem_bytes(a.nqt, a.tile_map != nullptr && a.bits_k != nullptr);
+  const dim3 grid_dq((unsigned)((a.nqt + 3) / 4), (unsigned)a.H, (unsigned)a.B);
+  const dim3 grid_dkv((unsigned)((a.nkt + 3) / 4), (unsigned)a.H, (unsigned)a.B);
+  if (smem_dq <= 64 * 1024 && !attn_force_staged())
+    hipLaunchKernelGGL(attn_bwd_dq_ring_kernel, grid_dq, block, smem_dq, stream, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid_dq, block, 0, stream, a);
   rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((a.nkt + 3) / 4), (unsigned)a.H, (unsigned)a.B), block, 0, stream, a);
+  if (smem_dkv <= 64 * 1024 && !attn_force_staged())
+    hipLaunchKernelGGL(attn_bwd_dkv_ring_kernel, grid_dkv, block, smem_dkv, stream, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid_dkv, block, 0, stream, a);
   return dvla_check_launch();
 }
