@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--seq", type=int, default=7)
     ap.add_argument("--heads", default="C", choices=sorted(HEAD_SETS))
     ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--tune-steps", type=int, default=3,
+                    help="untimed steps BEFORE the warm-up in which dreamvla_amd.ops.GemmTuner tries each GEMM kernel "
+                         "configuration once per problem shape and locks the fastest (setup, like building the extension)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--torch-ddp", action="store_true", help="use torch DDP instead of dreamvla_amd.ddp.GradBucketReducer")
@@ -174,6 +177,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from dreamvla_amd.ops import GemmTuner
+    if GemmTuner.enabled:
+        for _ in range(args.tune_steps):
+            step()
+        sync()
     for _ in range(args.warmup):
         step()
     sync()

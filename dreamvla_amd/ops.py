@@ -6,6 +6,7 @@ streams and autograd bookkeeping.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -127,6 +128,50 @@ class GemmProfiler:
                 "gflop_per_launch": flops / n / 1e9, "tflops": (flops / (total_ms * 1e-3) / 1e12) if total_ms > 0 else 0.0}
 
 
+class GemmTuner:
+    """Online choice of the GEMM kernel configuration per problem key (like a convolution autotuner).
+
+    include/dvla.h exposes the configurations through `dvla_set_gemm_variant` (0 = the library's cost model, 2 =
+    register-staged 128x128, 4 / 5 / 6 = LDS-DMA ring 256x256 / 256x128 / 128x128; they differ only in fp32 summation
+    order).  Which one is fastest depends on more than (M, N, K): the epilogue, what the neighbouring kernels left in
+    L2 / Infinity Cache, the clocks.  So the first calls of every key run the candidates IN TURN -- each real call is
+    executed exactly once, with one candidate, bracketed by two events that are read back later without a host sync --
+    and once every candidate has `ROUNDS` finished timing(s) the key is locked to the best one.  A forced variant that
+    does not apply to a shape falls back to the register-staged kernel inside the library, so every trial is valid.
+    Disable with DVLA_GEMM_AUTOTUNE=0 (the library's cost model is then used for every call)."""
+    CANDIDATES = (0, 4, 5, 6, 2)
+    ROUNDS = 1
+    enabled = os.environ.get("DVLA_GEMM_AUTOTUNE", "1") != "0" and os.environ.get("DVLA_GEMM_VARIANT") is None
+    table = {}      # key -> locked variant
+    trials = {}     # key -> {"pending": [(variant, e0, e1)], "times": {variant: [ms]}, "next": int}
+
+    @classmethod
+    def pick(cls, key):
+        v = cls.table.get(key)
+        if v is not None:
+            return v, None
+        st = cls.trials.setdefault(key, {"pending": [], "times": {c: [] for c in cls.CANDIDATES}, "next": 0})
+        still = []
+        for (var, e0, e1) in st["pending"]:
+            if e1.query():
+                st["times"][var].append(e0.elapsed_time(e1))
+            else:
+                still.append((var, e0, e1))
+        st["pending"] = still
+        if all(len(t) >= cls.ROUNDS for t in st["times"].values()):
+            best = min(cls.CANDIDATES, key=lambda c: sorted(st["times"][c])[len(st["times"][c]) // 2])
+            cls.table[key] = best
+            del cls.trials[key]
+            return best, None
+        var = cls.CANDIDATES[st["next"] % len(cls.CANDIDATES)]
+        st["next"] += 1
+        return var, st
+
+    @classmethod
+    def reset(cls):
+        cls.table.clear(); cls.trials.clear()
+
+
 def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=False, dact_aux=None, dact=0,
          dropout_p=0.0, seed=(0, 0), residual=None, res_rows=0, out_dtype=BF16, out=None, accumulate=False, split_k=1):
     """C[M,N] = epilogue(A . B^T); see include/dvla.h.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
@@ -186,12 +231,26 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     else:
         p.split_k = 1
     prof = GemmProfiler.active
-    if prof is not None:
+    variant, trial = 0, None
+    if GemmTuner.enabled:
+        variant, trial = GemmTuner.pick((M, N, K, int(a_trans), int(b_trans), int(p.split_k), int(act), int(dact),
+                                         bias is not None, want_preact, dact_aux is not None, residual is not None,
+                                         dropout_p > 0.0, out.dtype == torch.float32))
+    if prof is not None or trial is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.dvla_gemm_bf16(C.byref(p), _stream()), "dvla_gemm_bf16")
-    if prof is not None:
+    if variant:
+        lib.dvla_set_gemm_variant(variant)
+    try:
+        check(lib.dvla_gemm_bf16(C.byref(p), _stream()), "dvla_gemm_bf16")
+    finally:
+        if variant:
+            lib.dvla_set_gemm_variant(0)
+    if prof is not None or trial is not None:
         e1.record()
+    if trial is not None:
+        trial["pending"].append((variant, e0, e1))
+    if prof is not None:
         prof.records.append((e0, e1, 2.0 * M * N * K))
         prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k)))
     return (out, preact) if want_preact else out
