@@ -5,7 +5,7 @@
 
 namespace {
 
-constexpr int CS_BLOCKS = 128;  // row slabs (stage-1 partial rows)
+constexpr int CS_BLOCKS = 512;  // row slabs (stage-1 partial rows): >= 4 workgroups per CU even for 512-column inputs
 
 // stage 1: block = 4 waves over one 512-column strip of one row slab.  Wave w takes rows r_begin + w, + 4, ...; a lane
 // owns 8 consecutive columns (16-B loads, a wave reads 1 KiB contiguous per row).  The 4 waves are combined through LDS.
@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c0 < cols) {
     if (vec_ok && c0 + 8 <= cols) {
-      for (int64_t r = r_begin + wave; r < r_end; r += 4) {
+#pragma unroll 8
+      for (int64_t r = r_begin + wave; r < r_end; r += 4) {   // unrolled: eight independent 16-B loads in flight per lane
         const uint4 u = *reinterpret_cast<const uint4*>(x + r * ld + c0);
         s[0] += bf2f((bf16_t)(u.x & 0xffff)); s[1] += bf2f((bf16_t)(u.x >> 16));
         s[2] += bf2f((bf16_t)(u.y & 0xffff)); s[3] += bf2f((bf16_t)(u.y >> 16));
@@ -45,15 +46,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
 // interleaved slab subsets, combined through LDS (fixed order -> deterministic).
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab,
                                                             int64_t cols, int64_t stride) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  // 16 columns x 16 row-parts per workgroup: a thread adds nslab / 16 partial rows, then a 16-way LDS reduction
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int64_t c = (int64_t)blockIdx.x * 16 + cl;
   float s = 0.f;
   if (c < cols)
-    for (int k = part; k < nslab; k += 4) s += partial[(int64_t)k * stride + c];
+#pragma unroll 4
+    for (int k = part; k < nslab; k += 16) s += partial[(int64_t)k * stride + c];
   red[part][cl] = s;
   __syncthreads();
-  if (part == 0 && c < cols) out[c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+  if (part == 0 && c < cols) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][cl];
+    out[c] = tot;
+  }
 }
 
 __global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int64_t cols,
@@ -135,7 +143,7 @@ extern "C" int dvla_colsum(const void* x, int64_t ld, int64_t rows, int64_t cols
                      reinterpret_cast<const bf16_t*>(x), ld, rows, cols, partial, vec_ok);
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream, partial, out,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, stream, partial, out,
                      (int)nslab, cols, cols);
   return dvla_check_launch();
 }

@@ -586,15 +586,18 @@ __global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
 // Requirements (host falls back to the register-staged kernel otherwise): 16-B-vectorisable operands / outputs,
 // K-range % 32 == 0, r-contiguous operands with rows % tile == 0.
 // ====================================================================================================
-template <int WM_, int WN_, int TM_, int TN_, int NS_, int WPE_, int GH_>
+template <int WM_, int WN_, int TM_, int TN_, int NS_, int WPE_, int GH_, int BKS_, int PROWS_>
 struct RCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVES = WM * WN, NT = NWAVES * 64;
-  static constexpr int BKS = 32, NS = NS_;   // NS ring stages: NS - 1 stages are in flight ahead of the one computed
+  static constexpr int BKS = BKS_;           // K-slice per ring stage: 32 (64-B LDS rows) or 64 (128-B rows = whole cache lines
+                                             // of a k-contiguous operand per DMA request)
+  static constexpr int NS = NS_;             // NS ring stages: NS - 1 stages are in flight ahead of the one computed
   static constexpr int WPE = WPE_;           // waves per SIMD the register budget must allow
   static constexpr int GH = GH_;             // tile rows per raster group
+  static constexpr int PROWS = PROWS_;       // rows of the epilogue patch: 32 (4 KiB per wave) or 16 (2 KiB, two passes per slab)
   static constexpr int A_BYTES = BM * BKS * 2, B_BYTES = BN * BKS * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int RING_BYTES = NS * STAGE_BYTES, PATCH_BYTES = 4096;
+  static constexpr int RING_BYTES = NS * STAGE_BYTES, PATCH_BYTES = PROWS * 128;
   static constexpr int SMEM_BYTES = RING_BYTES + NWAVES * PATCH_BYTES;
   static constexpr int WG_PER_CU = (2 * SMEM_BYTES <= 160 * 1024) ? 2 : 1;
   static constexpr int A_CHUNKS = A_BYTES / 1024, B_CHUNKS = B_BYTES / 1024;
@@ -602,19 +605,23 @@ struct RCfg {
   static_assert((A_CHUNKS + B_CHUNKS) % NWAVES == 0, "chunks must divide evenly over the waves");
   static_assert(TN == 2, "epilogue slabs are 64 columns wide");
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
-  static_assert(NS == 4, "wait ladder assumes a prefetch distance of 3 stages");
+  static_assert(NS >= 2 && NS <= 4 && (BKS == 32 || BKS == 64) && (PROWS == 32 || PROWS == 16), "supported shapes");
+  static_assert((NS - 1) * CPW <= 63, "vmcnt is a 6-bit counter");
 };
-using RCfgL = RCfg<2, 4, 4, 2, 4, 2, 4>;   // 256 x 256, 8 waves of 128 x 64, 128 + 32 KiB, 1 workgroup / CU
-using RCfgM = RCfg<4, 2, 2, 2, 4, 2, 4>;   // 256 x 128, 8 waves of  64 x 64,  96 + 32 KiB, 1 workgroup / CU
-using RCfgS = RCfg<2, 2, 2, 2, 4, 2, 8>;   // 128 x 128, 4 waves of  64 x 64,  64 + 16 KiB, 2 workgroups / CU
+using RCfgL = RCfg<2, 4, 4, 2, 4, 2, 4, 32, 32>;    // 256 x 256, BK 32, 8 waves of 128 x 64, 128 + 32 KiB, 1 workgroup / CU
+using RCfgM = RCfg<4, 2, 2, 2, 4, 2, 4, 32, 32>;    // 256 x 128, BK 32, 8 waves of  64 x 64,  96 + 32 KiB, 1 workgroup / CU
+using RCfgS = RCfg<2, 2, 2, 2, 4, 2, 8, 32, 32>;    // 128 x 128, BK 32, 4 waves of  64 x 64,  64 + 16 KiB, 2 workgroups / CU
+using RCfgM64 = RCfg<4, 2, 2, 2, 3, 2, 4, 64, 16>;  // 256 x 128, BK 64, 8 waves of  64 x 64, 144 + 16 KiB, 1 workgroup / CU
 
 // per-lane global source address of chunk c of an operand tile at k0 (the LDS destination of lane l is chunk base + 16 l)
-template <bool TRANS, int ROWS>
+template <bool TRANS, int ROWS, int BKS>
 __device__ __forceinline__ const bf16_t* dma_src(const bf16_t* __restrict__ P, int64_t ld, int64_t row0, int64_t rows,
                                                  int64_t k0, int c, int lane) {
-  if (!TRANS) {   // chunk c = rows 16c .. 16c+15, four 16-B slots per row
-    const int rl = c * 16 + (lane >> 2);
-    const int o = (lane & 3) ^ ((rl >> 2) & 3);
+  if (!TRANS) {   // k-contiguous: LDS rows of 2 BKS bytes; chunk c = 1 KiB = 16 (BK 32) or 8 (BK 64) consecutive rows
+    constexpr int LPR = BKS / 8;             // 16-B slots (= lanes) per row
+    const int rl = c * (64 / LPR) + lane / LPR;
+    const int sl = lane % LPR;
+    const int o = (BKS == 32) ? (sl ^ ((rl >> 2) & 3)) : (sl ^ ((rl >> 1) & 7));
     int64_t row = row0 + rl;
     row = row < rows ? row : rows - 1;
     return P + row * ld + k0 + o * 8;
@@ -638,12 +645,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-// fragment of the 32-row sub-tile starting at tile row `rbase`, k16-step ks (0..1) of the stage
-template <bool TRANS, int ROWS>
+// fragment of the 32-row sub-tile starting at tile row `rbase`, k16-step ks (0 .. BKS/16 - 1) of the stage
+template <bool TRANS, int ROWS, int BKS>
 __device__ __forceinline__ bf16x8 ring_frag(const char* lds_oper, int rbase, int ks, int lane) {
   if (!TRANS) {
     const int row = rbase + (lane & 31), o = 2 * ks + (lane >> 5);
-    return *reinterpret_cast<const bf16x8*>(lds_oper + row * 64 + ((o ^ ((row >> 2) & 3)) << 4));
+    if (BKS == 32) return *reinterpret_cast<const bf16x8*>(lds_oper + row * 64 + ((o ^ ((row >> 2) & 3)) << 4));
+    return *reinterpret_cast<const bf16x8*>(lds_oper + row * 128 + ((o ^ ((row >> 1) & 7)) << 4));
   } else {
     const int gi = lane >> 4, c = lane & 15;
     const int r = rbase + 16 * (gi & 1) + 4 * (c & 3);                 // first of the 4 rows this lane FETCHES
@@ -677,7 +685,7 @@ __device__ __forceinline__ RingItem ring_item(const GemmKArgs& p, int id) {
   it.m0 = (int64_t)tm * RC::BM; it.n0 = (int64_t)tn * RC::BN; it.split = split;
   it.k_begin = (int64_t)split * p.k_per_split;
   const int64_t k_end = (it.k_begin + p.k_per_split < p.K) ? (it.k_begin + p.k_per_split) : p.K;
-  it.ns = (int)((k_end - it.k_begin) / RC::BKS);
+  it.ns = (int)((k_end - it.k_begin) / RC::BKS);   // K range % BKS == 0 (ring_ok)
   return it;
 }
 
@@ -689,11 +697,13 @@ __device__ __forceinline__ int patch_f32(int row, int unit) { return row * 128 +
 // Epilogue of one wave: (TM*32) x 64 block at (m_base, n_base).  acc[i][j][r] = element (m = 32j + l31,
 // n = 32i + 8*(r>>2) + 4*g + (r&3)).  Requires c_vec / aux_vec / epi_vec and N % 64 == 0 (ring_ok): only rows beyond M
 // need guards.
-template <int TM>
+template <int TM, int PROWS>
 __device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], char* patch, int lane,
                                               int64_t m_base, int64_t n_base, int split) {
+  constexpr int NH = 32 / PROWS, NIT = PROWS / 8;   // patch passes per 32-row slab, 8-row store groups per pass
   const int l31 = lane & 31, g = lane >> 5;
   const int cg = lane & 7, r8 = lane >> 3;
+  const int lrow = l31 & (PROWS - 1);               // this lane's row inside the patch
   const bool split_out = p.split_k > 1;
   const bool has_dact = p.dact_aux != nullptr, has_res = p.residual != nullptr;
   if (n_base >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
@@ -702,7 +712,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[
   static_for<TM>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const int64_t m_acc = m_base + j * 32 + l31;           // this lane's row in the accumulator layout
-    const int64_t ms0 = m_base + j * 32 + r8;              // store layout: rows ms0 + 8*it
+    const int64_t ms0 = m_base + j * 32 + r8;              // store layout: rows ms0 + PROWS*hh + 8*it
     uint32_t rowkey = 0;
     if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m_acc);
 
@@ -748,26 +758,31 @@ __device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[
       }
     };
     if (!split_out && p.preact) {
-      // pre-activation tensor: same transpose as the bf16 output below
+      // pre-activation tensor: same transposition as the bf16 output below
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int hh = 0; hh < NH; ++hh) {
+        if (PROWS == 32 || (l31 >> 4) == hh) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          float z[4];
-          biased(i, rq, z);
-          *reinterpret_cast<uint2*>(patch + patch_bf16(l31, 8 * i + 2 * rq + g)) =
-              make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              float z[4];
+              biased(i, rq, z);
+              *reinterpret_cast<uint2*>(patch + patch_bf16(lrow, 8 * i + 2 * rq + g)) =
+                  make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+            }
         }
-      wait_lds();
+        wait_lds();
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int R = it * 8 + r8;
-        const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
-        const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
-        const int64_t m = ms0 + 8 * it;
-        if (m < p.M) *reinterpret_cast<uint4*>(p.preact + m * p.ld_preact + n_base + 8 * cg) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        for (int it = 0; it < NIT; ++it) {
+          const int R = it * 8 + r8;
+          const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
+          const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
+          const int64_t m = ms0 + hh * PROWS + 8 * it;
+          if (m < p.M) *reinterpret_cast<uint4*>(p.preact + m * p.ld_preact + n_base + 8 * cg) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        wait_lds();
       }
-      wait_lds();
     }
 
     if (!f32_out) {
@@ -775,92 +790,102 @@ __device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[
       uint4 pre[4];
       if (has_res || has_dact) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int64_t m = ms0 + 8 * it;
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int64_t m = ms0 + (q4 / NIT) * PROWS + (q4 % NIT) * 8;
           const int64_t mc = m < p.M ? m : p.M - 1;
           if (has_res) {
             const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
-            pre[it] = *reinterpret_cast<const uint4*>(p.residual + rr * p.ld_res + n_base + 8 * cg);
+            pre[q4] = *reinterpret_cast<const uint4*>(p.residual + rr * p.ld_res + n_base + 8 * cg);
           } else {
-            pre[it] = *reinterpret_cast<const uint4*>(p.dact_aux + mc * p.ld_dact + n_base + 8 * cg);
+            pre[q4] = *reinterpret_cast<const uint4*>(p.dact_aux + mc * p.ld_dact + n_base + 8 * cg);
           }
         }
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int hh = 0; hh < NH; ++hh) {
+        if (PROWS == 32 || (l31 >> 4) == hh) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          float z[4];
-          finished(i, rq, z);
-          *reinterpret_cast<uint2*>(patch + patch_bf16(l31, 8 * i + 2 * rq + g)) =
-              make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              float z[4];
+              finished(i, rq, z);
+              *reinterpret_cast<uint2*>(patch + patch_bf16(lrow, 8 * i + 2 * rq + g)) =
+                  make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+            }
         }
-      wait_lds();
+        wait_lds();
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int R = it * 8 + r8;
-        const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
-        const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
-        uint4 out = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        const int64_t m = ms0 + 8 * it;
-        if (has_res || has_dact) {
-          float o[8], a[8];
-          unpack8f(out, o);
-          if (has_dact) {
-            uint4 au = pre[it];
-            if (has_res) au = *reinterpret_cast<const uint4*>(p.dact_aux + (m < p.M ? m : p.M - 1) * p.ld_dact + n_base + 8 * cg);
-            unpack8f(au, a);
-            act_bwd8_mul(o, a, p.dact);
-          }
-          if (has_res) {
-            unpack8f(pre[it], a);
+        for (int it = 0; it < NIT; ++it) {
+          const int R = it * 8 + r8;
+          const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
+          const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
+          uint4 out = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          const int64_t m = ms0 + hh * PROWS + 8 * it;
+          if (has_res || has_dact) {
+            float o[8], a[8];
+            unpack8f(out, o);
+            if (has_dact) {
+              uint4 au = pre[hh * NIT + it];
+              if (has_res) au = *reinterpret_cast<const uint4*>(p.dact_aux + (m < p.M ? m : p.M - 1) * p.ld_dact + n_base + 8 * cg);
+              unpack8f(au, a);
+              act_bwd8_mul(o, a, p.dact);
+            }
+            if (has_res) {
+              unpack8f(pre[hh * NIT + it], a);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += a[e];
+              for (int e = 0; e < 8; ++e) o[e] += a[e];
+            }
+            out = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
           }
-          out = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+          if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n_base + 8 * cg) = out;
         }
-        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n_base + 8 * cg) = out;
+        wait_lds();
       }
-      wait_lds();
     } else {
-      // ---- fp32 output (fp32 C, accumulation, split-K partial sums): two 32-column halves through the patch ----
+      // ---- fp32 output (fp32 C, accumulation, split-K partial sums): 32-column halves through the patch ----
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          float z[4];
-          finished(i, rq, z);
-          *reinterpret_cast<float4*>(patch + patch_f32(l31, 2 * rq + g)) = make_float4(z[0], z[1], z[2], z[3]);
-        }
-        wait_lds();
+        for (int hh = 0; hh < NH; ++hh) {
+          if (PROWS == 32 || (l31 >> 4) == hh) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int R = it * 8 + r8;
-          float4 o = *reinterpret_cast<const float4*>(patch + patch_f32(R, cg));
-          const int64_t m = ms0 + 8 * it;
-          const int64_t n = n_base + 32 * i + 4 * cg;
-          if (m < p.M) {
-            if (split_out) {
-              *reinterpret_cast<float4*>(p.workspace + ((int64_t)split * p.M + m) * p.N + n) = o;
-            } else {
-              if (has_dact) {
-                const uint2 a = *reinterpret_cast<const uint2*>(p.dact_aux + m * p.ld_dact + n);
-                o.x *= act_bwd(bf2f((bf16_t)(a.x & 0xffff)), p.dact); o.y *= act_bwd(bf2f((bf16_t)(a.x >> 16)), p.dact);
-                o.z *= act_bwd(bf2f((bf16_t)(a.y & 0xffff)), p.dact); o.w *= act_bwd(bf2f((bf16_t)(a.y >> 16)), p.dact);
-              }
-              if (has_res) {
-                const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
-                const uint2 a = *reinterpret_cast<const uint2*>(p.residual + rr * p.ld_res + n);
-                o.x += bf2f((bf16_t)(a.x & 0xffff)); o.y += bf2f((bf16_t)(a.x >> 16));
-                o.z += bf2f((bf16_t)(a.y & 0xffff)); o.w += bf2f((bf16_t)(a.y >> 16));
-              }
-              float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n);
-              if (p.accumulate) { const float4 old = *c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-              *c = o;
+            for (int rq = 0; rq < 4; ++rq) {
+              float z[4];
+              finished(i, rq, z);
+              *reinterpret_cast<float4*>(patch + patch_f32(lrow, 2 * rq + g)) = make_float4(z[0], z[1], z[2], z[3]);
             }
           }
+          wait_lds();
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int R = it * 8 + r8;
+            float4 o = *reinterpret_cast<const float4*>(patch + patch_f32(R, cg));
+            const int64_t m = m_base + j * 32 + hh * PROWS + R;
+            const int64_t n = n_base + 32 * i + 4 * cg;
+            if (m < p.M) {
+              if (split_out) {
+                *reinterpret_cast<float4*>(p.workspace + ((int64_t)split * p.M + m) * p.N + n) = o;
+              } else {
+                if (has_dact) {
+                  const uint2 a = *reinterpret_cast<const uint2*>(p.dact_aux + m * p.ld_dact + n);
+                  o.x *= act_bwd(bf2f((bf16_t)(a.x & 0xffff)), p.dact); o.y *= act_bwd(bf2f((bf16_t)(a.x >> 16)), p.dact);
+                  o.z *= act_bwd(bf2f((bf16_t)(a.y & 0xffff)), p.dact); o.w *= act_bwd(bf2f((bf16_t)(a.y >> 16)), p.dact);
+                }
+                if (has_res) {
+                  const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
+                  const uint2 a = *reinterpret_cast<const uint2*>(p.residual + rr * p.ld_res + n);
+                  o.x += bf2f((bf16_t)(a.x & 0xffff)); o.y += bf2f((bf16_t)(a.x >> 16));
+                  o.z += bf2f((bf16_t)(a.y & 0xffff)); o.w += bf2f((bf16_t)(a.y >> 16));
+                }
+                float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n);
+                if (p.accumulate) { const float4 old = *c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                *c = o;
+              }
+            }
+          }
+          wait_lds();
         }
-        wait_lds();
       }
     }
   });
@@ -909,8 +934,8 @@ void gemm_ring_kernel(GemmKArgs p) {
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int q = wave * CPW + i;
-      src[i] = (q < RC::A_CHUNKS) ? dma_src<A_T, BM>(p.A, p.lda, w.m0, p.M, w.k_begin, q, lane)
-                                  : dma_src<B_T, BN>(p.B, p.ldb, w.n0, p.N, w.k_begin, q - RC::A_CHUNKS, lane);
+      src[i] = (q < RC::A_CHUNKS) ? dma_src<A_T, BM, RC::BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, q, lane)
+                                  : dma_src<B_T, BN, RC::BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, q - RC::A_CHUNKS, lane);
     }
   };
   int islot = 0, inflight = 0;             // ring slot of the next issue; stages issued and not yet consumed
@@ -947,8 +972,8 @@ void gemm_ring_kernel(GemmKArgs p) {
 
     for (int s = 0; s < w.ns; ++s) {
       // this wave's pieces of the oldest stage in flight have landed; the younger ones stay in flight
-      if (inflight >= 3) wait_vmcnt<2 * CPW>();
-      else if (inflight == 2) wait_vmcnt<CPW>();
+      if (PD >= 3 && inflight >= 3) wait_vmcnt<(PD >= 3 ? 2 : 0) * CPW>();
+      else if (PD >= 2 && inflight == 2) wait_vmcnt<(PD >= 2 ? 1 : 0) * CPW>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();   // everybody's pieces are visible; everybody is done with the previous stage
       __builtin_amdgcn_sched_barrier(0);
@@ -957,12 +982,12 @@ void gemm_ring_kernel(GemmKArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       const char* st = smem + cslot * RC::STAGE_BYTES;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < RC::BKS / 16; ++ks) {
         bf16x8 fa[TM], fb[TN];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) fa[j] = ring_frag<A_T, BM>(st, wm * (TM * 32) + j * 32, ks, lane);
+        for (int j = 0; j < TM; ++j) fa[j] = ring_frag<A_T, BM, RC::BKS>(st, wm * (TM * 32) + j * 32, ks, lane);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) fb[i] = ring_frag<B_T, BN>(st + RC::A_BYTES, wn * (TN * 32) + i * 32, ks, lane);
+        for (int i = 0; i < TN; ++i) fb[i] = ring_frag<B_T, BN, RC::BKS>(st + RC::A_BYTES, wn * (TN * 32) + i * 32, ks, lane);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -972,7 +997,7 @@ void gemm_ring_kernel(GemmKArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       cslot = (cslot + 1 == NS) ? 0 : cslot + 1;
     }
-    ring_epilogue<TM>(p, acc, patch, lane, w.m0 + wm * (TM * 32), w.n0 + wn * 64, w.split);
+    ring_epilogue<TM, RC::PROWS>(p, acc, patch, lane, w.m0 + wm * (TM * 32), w.n0 + wn * 64, w.split);
   }
 }
 
@@ -992,7 +1017,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* C, int6
   }
 }
 
-int g_gemm_variant = -1;   // 0 auto; force: 2 register-staged S, 4 / 5 / 6 ring 256^2 / 256x128 / 128^2; 11..16 ablations
+int g_gemm_variant = -1;   // 0 auto; force: 2 register-staged S, 4 / 5 / 6 / 7 ring 256^2 / 256x128 / 128^2 / 256x128 BK 64; 11..16 ablations
 inline int gemm_variant() {
   if (g_gemm_variant < 0) {
     const char* e = getenv("DVLA_GEMM_VARIANT");
@@ -1065,7 +1090,7 @@ void launch_ring(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
 template <class RC>
 bool ring_ok(const GemmKArgs& a, int combo) {
   if (!a.a_vec || !a.b_vec || !a.c_vec || !a.aux_vec || !a.epi_vec) return false;
-  if (a.K < 32 || a.K % 32 != 0 || a.k_per_split % 32 != 0 || (a.N & 63) != 0) return false;
+  if (a.K < RC::BKS || a.K % RC::BKS != 0 || a.k_per_split % RC::BKS != 0 || (a.N & 63) != 0) return false;
   if ((int64_t)((a.M + RC::BM - 1) / RC::BM) * ((a.N + RC::BN - 1) / RC::BN) * a.split_k >= (1ll << 30)) return false;
   if (a.M < RC::BM || a.N < RC::BN) return false;
   if ((combo & 2) && (a.M % RC::BM != 0)) return false;   // r-contiguous A: whole row panels only
@@ -1166,10 +1191,12 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     } else if (variant == 4 && ring_ok<RCfgL>(a, combo)) choice = 1;
     else if (variant == 5 && ring_ok<RCfgM>(a, combo)) choice = 2;
     else if (variant == 6 && ring_ok<RCfgS>(a, combo)) choice = 3;
+    else if (variant == 7 && ring_ok<RCfgM64>(a, combo)) choice = 4;
     switch (choice) {
       case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;
       case 2: launch_ring<RCfgM>(a, combo, split_k, stream); break;
       case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
+      case 4: launch_ring<RCfgM64>(a, combo, split_k, stream); break;
       default: launch_cfg<CfgS>(a, combo, split_k, stream); break;
     }
   }
