@@ -11,7 +11,7 @@ heads, DiT diffusion head) -> reference loss block -> backward -> gradient all-r
 (obs + depth + sam dream heads, DiT head; L = 651).  rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     : the dominant kernel (gemm_kernel, bf16 MFMA).  achieved = algorithmic FLOPs of every GEMM launch of one
+  roofline     : the dominant kernels (gemm_ring_kernel / gemm_kernel, bf16 MFMA).  achieved = algorithmic FLOPs of every GEMM launch of one
                  instrumented step / summed launch durations (HIP events on the launch stream), peak = 2500 TFLOP/s dense.
   cpu_baseline : the oracle (oracle/model_ref.py, "port") timed on this box's host cores on a bounded sample.
 """
@@ -74,16 +74,23 @@ def cpu_baseline(heads, S):
     g = torch.Generator().manual_seed(3)
     noise = torch.randn(8 * B * S, 3, 7, generator=g)
     tstep = torch.randint(0, 100, (8 * B * S,), generator=g)
+    nsteps = 3
     t0 = time.time()
-    out = M.dreamvla_forward(sd, cfg, b["image_primary"][:, :S], b["image_wrist"][:, :S], b["state"][:, :S],
-                             b["text_token"][:, :S], action_label=lab, mode="train", dit_noise=noise, dit_timestep=tstep)
-    t_fwd = time.time() - t0
-    total, _ = losses.calvin_losses(out, b, sequence_length=S, use_dit_head=cfg["use_dit_head"], label_action=lab)
-    total.backward()
+    t_fwd = 0.0
+    for _ in range(nsteps):
+        for v in leaves.values():
+            v.grad = None
+        t1 = time.time()
+        out = M.dreamvla_forward(sd, cfg, b["image_primary"][:, :S], b["image_wrist"][:, :S], b["state"][:, :S],
+                                 b["text_token"][:, :S], action_label=lab, mode="train", dit_noise=noise, dit_timestep=tstep)
+        t_fwd += time.time() - t1
+        total, _ = losses.calvin_losses(out, b, sequence_length=S, use_dit_head=cfg["use_dit_head"], label_action=lab)
+        total.backward()
     dt = time.time() - t0
-    return {"value": B / dt, "unit": "samples/s", "cores": nthreads, "kind": "port",
-            "sample": f"1 un-warmed step of oracle/model_ref.py forward+loss+backward, fp32, B={B}, S={S}, head set {heads}, "
-                      f"full 1024/24/16 model, {nthreads} threads of {os.cpu_count()}; fwd {t_fwd:.1f}s of {dt:.1f}s"}
+    return {"value": B * nsteps / dt, "unit": "samples/s", "cores": nthreads, "kind": "port",
+            "sample": f"{nsteps} steps (first one un-warmed) of oracle/model_ref.py forward+loss+backward, fp32, B={B}, S={S}, "
+                      f"head set {heads}, full 1024/24/16 model, {nthreads} threads of {os.cpu_count()}; "
+                      f"fwd {t_fwd:.1f}s of {dt:.1f}s"}
 
 
 def main():
@@ -220,9 +227,16 @@ def main():
         if os.environ.get("DVLA_GEMM_BREAKDOWN"):
             with open(os.environ["DVLA_GEMM_BREAKDOWN"], "w") as f:
                 json.dump(prof.breakdown(), f, indent=1)
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA 32x32x16, all launches of one training step)",
+        traffic, traffic_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (cannot be collected from inside)
+            with open(pmc) as f:
+                t = json.load(f)
+            traffic, traffic_src = t["gemm_bytes_per_launch"], t["source"]
+        roofline = {"bound": "mfma",
+                    "kernel": "gemm_ring_kernel + gemm_kernel (bf16 MFMA 32x32x16; every GEMM launch of one training step)",
                     "achieved": r["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["tflops"] / BF16_PEAK_TFLOPS,
-                    "traffic": None, "launches": r["launches"], "avg_launch_us": r["avg_us"],
+                    "traffic": traffic, "traffic_source": traffic_src, "launches": r["launches"], "avg_launch_us": r["avg_us"],
                     "gflop_per_launch": r["gflop_per_launch"], "gemm_ms_per_step": r["total_ms"],
                     "whole_step_frac_of_bf16_peak": TRAIN_GFLOP_PER_SAMPLE[args.heads] * (B * 1e3 / ms_per_step) / 1e3 / BF16_PEAK_TFLOPS}
 

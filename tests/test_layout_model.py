@@ -281,3 +281,119 @@ def test_attention_backward_tile_dataflow():
             for r in range(16):
                 assert dv[db][l, r] == dV[l & 31, 32 * db + acc_row(r, l >> 5)]
                 assert dk[db][l, r] == dK[l & 31, 32 * db + acc_row(r, l >> 5)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention ring kernels (attention.hip, attn_*_ring_kernel): ONE swizzled row-major LDS-DMA image per 32 x 64 tile
+# serves row fragments (ds_read_b128) and transposed fragments (ds_read_b64_tr_b16)
+# ---------------------------------------------------------------------------------------------------
+def fa_sw(r):
+    return (((r >> 1) & 1) << 2) | ((r >> 2) & 3)
+
+
+def fa_dma_image(tile):
+    """tile[32][64] -> LDS byte image as written by the 4 DMA pieces (wave w: rows 8w..8w+7, lane -> row 8w + lane/8,
+    LDS slot lane % 8 holding global d-octet (lane % 8) ^ fa_sw(row)); modelled as elements (2 B each)."""
+    lds = np.zeros(32 * 64)
+    for w in range(4):
+        for lane in range(64):
+            rl = 8 * w + (lane >> 3)
+            octet = (lane & 7) ^ fa_sw(rl)
+            dst = (w * 1024 + lane * 16) // 2
+            lds[dst:dst + 8] = tile[rl, octet * 8: octet * 8 + 8]
+    return lds
+
+
+def fa_frag_rm(lds, s):
+    f = np.zeros((64, 8))
+    for l in range(64):
+        row, g = l & 31, l >> 5
+        off = (row * 128 + (((2 * s + g) ^ fa_sw(row)) << 4)) // 2
+        f[l] = lds[off:off + 8]
+    return f
+
+
+def tr_read_b64(lds, byte_addr):
+    """ds_read_b64_tr_b16 as probed on hardware (tests/probes/tr_probe.hip): inside each 16-lane group lane i receives
+    element (i & 3) of the four 8-byte chunks FETCHED by lanes 4 j + (i >> 2), j = 0..3."""
+    out = np.zeros((64, 4))
+    for l in range(64):
+        base, i = l & ~15, l & 15
+        for j in range(4):
+            src = base + 4 * j + (i >> 2)
+            out[l, j] = lds[byte_addr[src] // 2 + (i & 3)]
+    return out
+
+
+def fa_frag_tr(lds, db, mm):
+    f = np.zeros((64, 8))
+    for h in range(2):
+        addr = np.zeros(64, dtype=np.int64)
+        for l in range(64):
+            gi, c = l >> 4, l & 15
+            d = 32 * db + 16 * (gi & 1) + 4 * (c & 3)
+            row = 16 * mm + 8 * h + 4 * (gi >> 1) + (c >> 2)
+            addr[l] = row * 128 + (((d >> 3) ^ fa_sw(row)) << 4) + (d & 7) * 2
+        f[:, 4 * h: 4 * h + 4] = tr_read_b64(lds, addr)
+    return f
+
+
+def test_attention_ring_tile_dataflow():
+    rng = np.random.default_rng(11)
+    Q = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    K = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    V = rng.integers(-2, 3, (32, 64)).astype(np.float64)
+    k_img, v_img = fa_dma_image(K), fa_dma_image(V)
+    sacc = np.zeros((64, 16))
+    for s in range(4):
+        sacc = mfma_32x32x16(fa_frag_rm(k_img, s), direct_frag(Q, s), sacc)
+    S = Q @ K.T
+    for l in range(64):
+        for r in range(16):
+            assert sacc[l, r] == S[l & 31, acc_row(r, l >> 5)]
+    oacc = [np.zeros((64, 16)), np.zeros((64, 16))]
+    for db in range(2):
+        oacc[db] = mfma_32x32x16(fa_frag_tr(v_img, db, 0), sacc[:, 0:8], oacc[db])
+        oacc[db] = mfma_32x32x16(fa_frag_tr(v_img, db, 1), sacc[:, 8:16], oacc[db])
+    O = S @ V
+    for l in range(64):
+        for db in range(2):
+            for r in range(16):
+                assert oacc[db][l, r] == O[l & 31, 32 * db + acc_row(r, l >> 5)]
+    # dQ^T = K^T . dS^T uses the transposed fragments of the SAME K image
+    dq = [np.zeros((64, 16)), np.zeros((64, 16))]
+    for db in range(2):
+        dq[db] = mfma_32x32x16(fa_frag_tr(k_img, db, 0), sacc[:, 0:8], dq[db])
+        dq[db] = mfma_32x32x16(fa_frag_tr(k_img, db, 1), sacc[:, 8:16], dq[db])
+    DQ = S @ K
+    for l in range(64):
+        for db in range(2):
+            for r in range(16):
+                assert dq[db][l, r] == DQ[l & 31, 32 * db + acc_row(r, l >> 5)]
+
+
+def test_attention_ring_image_bank_conflict_free():
+    # row fragments: ds_read_b128, 4 groups of 16 lanes, 64 banks of 4 B
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for s in range(4):
+        for g in range(2):
+            for grp in groups:
+                banks = set()
+                for row in grp:
+                    dw = (row * 128 + (((2 * s + g) ^ fa_sw(row)) << 4)) // 4
+                    banks.update((dw + d) % 64 for d in range(4))
+                assert len(banks) == 64
+    # transposed fragments: ds_read_b64_tr_b16, 2 groups of 32 lanes, 8 B per lane
+    for db in range(2):
+        for mm in range(2):
+            for h in range(2):
+                for half in range(2):
+                    banks = set()
+                    for l in range(32 * half, 32 * half + 32):
+                        gi, c = l >> 4, l & 15
+                        d = 32 * db + 16 * (gi & 1) + 4 * (c & 3)
+                        row = 16 * mm + 8 * h + 4 * (gi >> 1) + (c >> 2)
+                        dw = (row * 128 + (((d >> 3) ^ fa_sw(row)) << 4) + (d & 7) * 2) // 4
+                        banks.update((dw + x) % 64 for x in range(2))
+                    assert len(banks) == 64
