@@ -136,6 +136,27 @@ __device__ __forceinline__ void act_fwd8(float (&v)[8], int act) {
     default: act_fwd8_c<ACT_SIGMOID>(v); break;
   }
 }
+// four values (one accumulator column group of the ring kernels' epilogue), one switch
+template <int ACT>
+__device__ __forceinline__ void act_fwd4_c(float (&v)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; e += 2) {
+    const f32x2 r = act_fwd2(f32x2{v[e], v[e + 1]}, ACT);
+    v[e] = r.x; v[e + 1] = r.y;
+  }
+}
+__device__ __forceinline__ void act_fwd4(float (&v)[4], int act) {
+  switch (act) {
+    case ACT_NONE: break;
+    case ACT_GELU_ERF: act_fwd4_c<ACT_GELU_ERF>(v); break;
+    case ACT_GELU_TANH: act_fwd4_c<ACT_GELU_TANH>(v); break;
+    case ACT_RELU: act_fwd4_c<ACT_RELU>(v); break;
+    case ACT_SILU: act_fwd4_c<ACT_SILU>(v); break;
+    case ACT_QUICK_GELU: act_fwd4_c<ACT_QUICK_GELU>(v); break;
+    case ACT_TANH: act_fwd4_c<ACT_TANH>(v); break;
+    default: act_fwd4_c<ACT_SIGMOID>(v); break;
+  }
+}
 template <int ACT>
 __device__ __forceinline__ void act_bwd8_mul_c(float (&v)[8], const float (&a)[8]) {
 #pragma unroll

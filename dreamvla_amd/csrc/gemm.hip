@@ -79,6 +79,8 @@ struct GemmKArgs {
   int split_k; int64_t k_per_split; float* workspace;
   int a_vec, b_vec, c_vec, aux_vec, epi_vec;
   int tiles_m, tiles_n;
+  int direct_store;  // plain bf16 epilogues store from the accumulator layout: 0 never, 1 always, 2 (default) 256x256 tile only; env DVLA_GEMM_DIRECT
+  int sweep;     // ring kernels: 1 = each XCD walks its own contiguous run of items (temporal L2 reuse), 0 = XCDs interleave
 };
 
 // Row-major image of a k-contiguous operand: row r = 128 B = 8 slots of 16 B; k-octet o of row r lives in slot
@@ -741,13 +743,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = bf2f(f2bf(z[e]));
       }
-      if (p.act != ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          const f32x2 r = act_fwd2(f32x2{z[e], z[e + 1]}, p.act);
-          z[e] = r.x; z[e + 1] = r.y;
-        }
-      }
+      act_fwd4(z, p.act);
       if (p.has_drop) {
         const uint32_t n = (uint32_t)(n_base + 32 * i + 8 * rq + 4 * g);
 #pragma unroll
@@ -785,7 +781,23 @@ __device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[
       }
     }
 
-    if (!f32_out) {
+    if (!f32_out && !has_res && !has_dact && (p.direct_store == 1 || (p.direct_store == 2 && TM == 4))) {
+      // ---- plain bf16 output of the 256x256 tile: 8-byte stores straight from the accumulator layout (32 rows x 16 B per
+      // instruction; the L2 merges the partial lines).  Measured on MI355X at 20832x4096: K = 64 launch 105.6 -> 75.3 us,
+      // K = 1024 265.5 -> 223.0 us for the 256x256 tile (whose 4 slabs per wave at 256 VGPRs make the patch path slow),
+      // but 60 -> 80 us for the 256x128 / 128x128 tiles, which therefore keep the transposition. ----
+      if (m_acc < p.M) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            float z[4];
+            finished(i, rq, z);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + m_acc * p.ldc + n_base + 32 * i + 8 * rq + 4 * g) =
+                make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+          }
+      }
+    } else if (!f32_out) {
       // ---- bf16 output: prefetch the store-layout operands, transpose the slab as bf16, finish, store 16 B / lane ----
       uint4 pre[4];
       if (has_res || has_dact) {
@@ -905,6 +917,19 @@ void gemm_ring_kernel(GemmKArgs p) {
   const int grid = gridDim.x;
   // workgroup b sits on XCD b % 8: give each XCD a run of consecutive items
   const int perm = (grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // item of iteration `it` (or -1): sweep = 0: round `it` covers items [it*grid, (it+1)*grid), XCD x takes the x-th
+  // eighth of the round; sweep = 1: XCD x owns items [x*per, (x+1)*per) and walks them in order
+  const int per_xcd = (nitems + 7) >> 3;
+  auto item_of = [&](int it) -> int {
+    if (p.sweep && (grid & 7) == 0) {
+      const int base = (int)(blockIdx.x & 7) * per_xcd;
+      const int id = base + it * (grid >> 3) + (int)(blockIdx.x >> 3);
+      const int lim = base + per_xcd < nitems ? base + per_xcd : nitems;
+      return id < lim ? id : -1;
+    }
+    const int id = it * grid + perm;
+    return id < nitems ? id : -1;
+  };
 
   // ---- DMA cursor: per-wave plan of CPW pieces per stage (fixed operand / chunk per slot i), per-lane source pointers
   // that advance by one stage (32 k) per issue; destinations are wave-uniform byte offsets inside a stage buffer. ----
@@ -926,8 +951,8 @@ void gemm_ring_kernel(GemmKArgs p) {
   int cur_it = 0, cur_s = 0, cur_ns = 0;   // cursor: item iteration, stage inside it, stages of it
   bool cur_live = false;
   auto cursor_open = [&](int it) {
-    const int id = it * grid + perm;
-    cur_live = id < nitems;
+    const int id = item_of(it);
+    cur_live = id >= 0;
     if (!cur_live) return;
     const RingItem w = ring_item<RC>(p, id);
     cur_ns = w.ns; cur_s = 0;
@@ -958,8 +983,8 @@ void gemm_ring_kernel(GemmKArgs p) {
   char* patch = smem + RC::RING_BYTES + wave * RC::PATCH_BYTES;
   int cslot = 0;
   for (int it = 0;; ++it) {
-    const int id = it * grid + perm;
-    if (id >= nitems) break;
+    const int id = item_of(it);
+    if (id < 0) break;
     const RingItem w = ring_item<RC>(p, id);
 
     f32x16 acc[TN][TM];
@@ -1024,6 +1049,12 @@ inline int gemm_variant() {
     g_gemm_variant = e ? atoi(e) : 0;
   }
   return g_gemm_variant;
+}
+
+inline int gemm_sweep() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DVLA_GEMM_SWEEP"); v = e ? atoi(e) : 0; }
+  return v;
 }
 
 inline int num_cus() {
@@ -1121,6 +1152,8 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       return DVLA_ERR_ARG;
   }
   GemmKArgs a;
+  a.sweep = gemm_sweep();
+  { static int ds = -1; if (ds < 0) { const char* e = getenv("DVLA_GEMM_DIRECT"); ds = e ? atoi(e) : 2; } a.direct_store = ds; }
   a.A = reinterpret_cast<const bf16_t*>(q->A); a.lda = q->lda;
   a.B = reinterpret_cast<const bf16_t*>(q->B); a.ldb = q->ldb;
   a.C = q->C; a.ldc = q->ldc; a.c_f32 = (q->c_dtype == DVLA_DT_F32);
@@ -1156,7 +1189,11 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   if (split_k > 1 && ((q->N & 3) != 0 || !aligned(q->workspace, 16))) a.epi_vec = 0;
 
   const int combo = (q->a_trans ? 2 : 0) | (q->b_trans ? 1 : 0);
-  const int variant = gemm_variant();
+  int variant = gemm_variant();
+  if (variant >= 100) {   // A/B knob for measurements: 1xx = direct stores on, 2xx = off, xx = configuration
+    a.direct_store = (variant / 100 == 1) ? 1 : 0;
+    variant %= 100;
+  }
   if (variant >= 11 && variant <= 16 && combo == 0) {   // ablation builds of the S NT kernel (results are garbage by design)
     a.tiles_m = (int)((a.M + CfgS::BM - 1) / CfgS::BM);
     a.tiles_n = (int)((a.N + CfgS::BN - 1) / CfgS::BN);
