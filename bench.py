@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--torch-ddp", action="store_true", help="use torch DDP instead of dreamvla_amd.ddp.GradBucketReducer")
+    ap.add_argument("--torch-adamw", action="store_true",
+                    help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of dreamvla_amd.optim.FlatAdamW (HIP, flat buffers)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -152,7 +154,13 @@ def main():
                                                               gradient_as_bucket_view=True)
     else:
         reducer = GradBucketReducer(params)
-    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4, fused=True)   # finetune.sh:23,26
+    flat_opt = None
+    if reducer is not None and not args.torch_adamw:
+        from dreamvla_amd.optim import FlatAdamW
+        flat_opt = FlatAdamW(reducer, lr=1e-3, weight_decay=1e-4, max_grad_norm=0.1)   # finetune.sh:23,26 + clip 0.1
+        opt = None
+    else:
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4, fused=True)   # finetune.sh:23,26
 
     b = synthetic_batch(B, S, window=S + 3, seed=1234 + rank, heads=label_heads(args.heads))
     b["actions"][..., 6:] = (b["actions"][..., 6:] > 0.5).float()
@@ -175,8 +183,11 @@ def main():
         total.backward()
         if reducer is not None:
             reducer.finish()
-        torch.nn.utils.clip_grad_norm_(params, 0.1)
-        opt.step()
+        if flat_opt is not None:
+            flat_opt.step()          # gradient norm + clip + AdamW, two HIP kernels per bucket
+        else:
+            torch.nn.utils.clip_grad_norm_(params, 0.1)
+            opt.step()
         return total
 
     def sync():
@@ -259,7 +270,9 @@ def main():
                                    f"{args.layers} layers / 16 heads, dropout 0.1 on, AdamW + clip 0.1",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "trainable_params_M": n_train / 1e6, "loss": loss_val,
-                       "grad_exchange": "torch DDP" if reducer is None else "GradBucketReducer (flat bf16 buckets, async all-reduce)"},
+                       "grad_exchange": "torch DDP" if reducer is None else "GradBucketReducer (flat bf16 buckets, async all-reduce)",
+                       "optimizer": "FlatAdamW (HIP: dvla_sumsq_bf16 + dvla_adamw_bf16 on flat buffers)" if flat_opt is not None
+                                    else "clip_grad_norm_ + torch.optim.AdamW(fused)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

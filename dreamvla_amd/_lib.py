@@ -78,6 +78,10 @@ SYMBOLS = {
     "dvla_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_cast_bf16_to_f32": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
+    "dvla_sumsq_partial_len": (C.c_int64, []),
+    "dvla_sumsq_bf16": (C.c_int, [_P, _I64, _P, _P, C.c_int32, _P]),
+    "dvla_adamw_bf16": (C.c_int, [_P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P,
+                                  C.c_float, _P]),
 }
 
 _lib = None

@@ -43,14 +43,17 @@ class GradBucketReducer:
             for p in b["params"]:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
+    ALIGN = 128   # elements: every view starts on a 256-byte boundary (the kernels read parameters / gradients as 16-B vectors)
+
     def _make_bucket(self, plist):
-        total = sum(p.numel() for p in plist)
-        flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
-        off = 0
+        offsets, off = [], 0
         for p in plist:
-            p.grad = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        self.buckets.append({"flat": flat, "params": plist, "pending": len(plist), "launched": False})
+            offsets.append(off)
+            off += -(-p.numel() // self.ALIGN) * self.ALIGN
+        flat = torch.zeros(off, dtype=plist[0].dtype, device=plist[0].device)
+        for p, o in zip(plist, offsets):
+            p.grad = flat[o:o + p.numel()].view_as(p)
+        self.buckets.append({"flat": flat, "params": plist, "offsets": offsets, "pending": len(plist), "launched": False})
 
     def _make_hook(self, bi):
         def hook(param):

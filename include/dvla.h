@@ -152,6 +152,20 @@ int dvla_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* out = a + b (bf16, n elements); b_period > 0 broadcasts b with period b_period elements */
 int dvla_add(const void* a, const void* b, void* out, int64_t n, int64_t b_period, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Optimizer step over flat bf16 buffers (the caller's `clip_grad_norm_` + `torch.optim.AdamW.step`, reference
+ * train.py:253-262 / utils/train_utils.py:600-608).
+ * dvla_sumsq_bf16: out[0] (+)= sum x[i]^2 in fp32; `partial` holds dvla_sumsq_partial_len() floats.
+ * dvla_adamw_bf16: one AdamW step on n elements; math in fp32, parameters and both moments stored in bf16 (torch's
+ *   fused AdamW with bf16 parameters).  If grad_sumsq != NULL the gradient is first scaled by
+ *   min(1, max_norm / (sqrt(*grad_sumsq) + 1e-6)) and rounded to bf16 (clip_grad_norm_ semantics; the scalar stays on
+ *   the device, no host synchronisation).  `step` is the 1-based step count (bias corrections). */
+int64_t dvla_sumsq_partial_len(void);
+int dvla_sumsq_bf16(const void* x, int64_t n, float* partial, float* out, int32_t accumulate, void* stream);
+int dvla_adamw_bf16(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, const float* grad_sumsq, float max_norm,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

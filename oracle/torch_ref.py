@@ -126,3 +126,27 @@ def merge_heads(o):
 
 def bf16_round(x):
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+def clip_adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, max_norm=None):
+    """One `clip_grad_norm_(max_norm)` + AdamW step on lists of bf16 tensors (updated in place), restating torch's
+    semantics with bf16 parameters (train.py optimizer step of the reference; torch/optim/adamw.py fused path:
+    fp32 math per element, parameters and both moments stored in bf16; clip_grad_norm_: total L2 norm in fp32,
+    coef = min(1, max_norm / (norm + 1e-6)), gradients scaled in place i.e. rounded to bf16).  Returns the norm."""
+    norm = None
+    coef = 1.0
+    if max_norm is not None:
+        norm = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
+        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+    b1, b2 = betas
+    bc1 = 1.0 - b1 ** step
+    bc2_sqrt = (1.0 - b2 ** step) ** 0.5
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        gf = (g.float() * coef).to(torch.bfloat16).float()
+        pf = p.float() * (1.0 - lr * weight_decay)
+        mf = m.float() + (gf - m.float()) * (1.0 - b1)
+        vf = b2 * v.float() + (1.0 - b2) * gf * gf
+        denom = vf.sqrt() / bc2_sqrt + eps
+        pf = pf - (lr / bc1) * (mf / denom)
+        p.copy_(pf.to(torch.bfloat16)); m.copy_(mf.to(torch.bfloat16)); v.copy_(vf.to(torch.bfloat16))
+    return norm

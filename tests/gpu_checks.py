@@ -333,6 +333,7 @@ def all_checks(quick=False):
         (check_gemm, dict(M=1300, N=832, K=64, bias=True, out_f32=True, residual=True)),
         (check_gemm, dict(M=768, N=3072, K=2048, a_trans=True, b_trans=True, split_k=3)),
     ]
+    L += [(check_flat_adamw, dict())]
     L += [
         (check_layernorm, dict(rows=37, cols=768, eps=1e-6)),
         (check_layernorm, dict(rows=1000, cols=1024)),
@@ -365,3 +366,31 @@ def all_checks(quick=False):
         (check_misc, dict()),
     ]
     return L
+
+
+def check_flat_adamw(seed=0):
+    """dreamvla_amd.optim.FlatAdamW (dvla_sumsq_bf16 + dvla_adamw_bf16) vs the oracle's clip + AdamW restatement."""
+    from dreamvla_amd.ddp import GradBucketReducer
+    from dreamvla_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(77 + seed)
+    shapes = [(1024, 1024), (1024,), (333, 77), (5,), (4096, 256)]
+    host = [(torch.randn(s, generator=g) * 0.2).to(BF) for s in shapes]
+    params = [torch.nn.Parameter(h.clone().to(DEV)) for h in host]
+    red = GradBucketReducer(params, bucket_bytes=3 << 20)      # several buckets
+    opt = FlatAdamW(red, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05, max_grad_norm=0.1)
+    mine = [h.clone() for h in host]
+    m = [torch.zeros_like(h) for h in host]
+    v = [torch.zeros_like(h) for h in host]
+    out = []
+    for step in range(1, 4):
+        grads = [(torch.randn(s, generator=g) * (2.0 if step != 2 else 1e-3)).to(BF) for s in shapes]
+        red.zero_grad()
+        for p, gr in zip(params, grads):
+            p.grad.copy_(gr.to(DEV))
+        opt.step()
+        norm_o = R.clip_adamw_step(mine, grads, m, v, step, 1e-2, (0.9, 0.95), 1e-8, 0.05, max_norm=0.1)
+        out.append(metrics(f"flat_adamw step{step} grad_norm", opt.grad_norm().cpu(), norm_o.reshape(1), 1e-5, round_ref=False))
+        got = torch.cat([p.detach().float().cpu().reshape(-1) for p in params])
+        ref = torch.cat([q.float().reshape(-1) for q in mine])
+        out.append(metrics(f"flat_adamw step{step} params", got, ref, 1e-3 if step > 1 else 1e-6, round_ref=False))
+    return out
