@@ -80,7 +80,6 @@ struct GemmKArgs {
   int a_vec, b_vec, c_vec, aux_vec, epi_vec;
   int tiles_m, tiles_n;
   int direct_store;  // plain bf16 epilogues store from the accumulator layout: 0 never, 1 always, 2 (default) 256x256 tile only; env DVLA_GEMM_DIRECT
-  int sweep;     // ring kernels: 1 = each XCD walks its own contiguous run of items (temporal L2 reuse), 0 = XCDs interleave
 };
 
 // Row-major image of a k-contiguous operand: row r = 128 B = 8 slots of 16 B; k-octet o of row r lives in slot
@@ -917,16 +916,7 @@ void gemm_ring_kernel(GemmKArgs p) {
   const int grid = gridDim.x;
   // workgroup b sits on XCD b % 8: give each XCD a run of consecutive items
   const int perm = (grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  // item of iteration `it` (or -1): sweep = 0: round `it` covers items [it*grid, (it+1)*grid), XCD x takes the x-th
-  // eighth of the round; sweep = 1: XCD x owns items [x*per, (x+1)*per) and walks them in order
-  const int per_xcd = (nitems + 7) >> 3;
-  auto item_of = [&](int it) -> int {
-    if (p.sweep && (grid & 7) == 0) {
-      const int base = (int)(blockIdx.x & 7) * per_xcd;
-      const int id = base + it * (grid >> 3) + (int)(blockIdx.x >> 3);
-      const int lim = base + per_xcd < nitems ? base + per_xcd : nitems;
-      return id < lim ? id : -1;
-    }
+  auto item_of = [&](int it) -> int {   // item of iteration `it`, or -1
     const int id = it * grid + perm;
     return id < nitems ? id : -1;
   };
@@ -1051,12 +1041,6 @@ inline int gemm_variant() {
   return g_gemm_variant;
 }
 
-inline int gemm_sweep() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DVLA_GEMM_SWEEP"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
 inline int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1152,7 +1136,6 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       return DVLA_ERR_ARG;
   }
   GemmKArgs a;
-  a.sweep = gemm_sweep();
   { static int ds = -1; if (ds < 0) { const char* e = getenv("DVLA_GEMM_DIRECT"); ds = e ? atoi(e) : 2; } a.direct_store = ds; }
   a.A = reinterpret_cast<const bf16_t*>(q->A); a.lda = q->lda;
   a.B = reinterpret_cast<const bf16_t*>(q->B); a.ldb = q->ldb;

@@ -189,15 +189,17 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
   }
 }
 
-// out[c] = sum over blocks of partial[b][which][c]; 64 columns x 4 interleaved block subsets per workgroup (deterministic)
+// out[c] = sum over blocks of partial[b][which][c]; 16 columns x 16 interleaved block subsets per workgroup
+// (deterministic; a thread adds nblocks / 16 partial rows with 4 loads in flight, then a 16-way LDS reduction)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int nblocks, int cols) {
-  __shared__ float red[2][4][64];
-  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ float red[2][16][16];
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float sg = 0.f, sb = 0.f;
   if (c < cols)
-    for (int b = part; b < nblocks; b += 4) {
+#pragma unroll 4
+    for (int b = part; b < nblocks; b += 16) {
       sg += partial[(int64_t)b * 2 * cols + c];
       sb += partial[(int64_t)b * 2 * cols + cols + c];
     }
@@ -205,8 +207,11 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   red[1][part][cl] = sb;
   __syncthreads();
   if (part == 0 && c < cols) {
-    if (dgamma) dgamma[c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-    if (dbeta) dbeta[c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { tg += red[0][q][cl]; tb += red[1][q][cl]; }
+    if (dgamma) dgamma[c] = tg;
+    if (dbeta) dbeta[c] = tb;
   }
 }
 
@@ -269,7 +274,7 @@ extern "C" int dvla_layernorm_bwd(const void* dy, const void* x, const void* gam
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
   if (part) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream, part, dgamma,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, stream, part, dgamma,
                        dbeta, (int)nb, (int)cols);
     rc = dvla_check_launch();
   }
