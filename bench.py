@@ -234,7 +234,8 @@ def main():
         with prof:
             step()
         torch.cuda.synchronize()
-        r = prof.summary()
+        r_all, r_lib = prof.summary(), prof.summary("library")
+        r = prof.summary("hip")     # the roofline is quoted on the hand-written kernels only
         if os.environ.get("DVLA_GEMM_BREAKDOWN"):
             with open(os.environ["DVLA_GEMM_BREAKDOWN"], "w") as f:
                 json.dump(prof.breakdown(), f, indent=1)
@@ -249,7 +250,12 @@ def main():
                     "achieved": r["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["tflops"] / BF16_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "launches": r["launches"], "avg_launch_us": r["avg_us"],
                     "gflop_per_launch": r["gflop_per_launch"], "gemm_ms_per_step": r["total_ms"],
-                    "whole_step_frac_of_bf16_peak": TRAIN_GFLOP_PER_SAMPLE[args.heads] * (B * 1e3 / ms_per_step) / 1e3 / BF16_PEAK_TFLOPS}
+                    "whole_step_frac_of_bf16_peak": TRAIN_GFLOP_PER_SAMPLE[args.heads] * (B * 1e3 / ms_per_step) / 1e3 / BF16_PEAK_TFLOPS,
+                    # epilogue-free GEMMs on which the tuner measured hipBLASLt faster than every hand-written
+                    # configuration (the per-shape gap list: DVLA_GEMM_BREAKDOWN=<file>); DVLA_GEMM_LIBRARY=0 removes the candidate
+                    "library_gemm": {"launches": r_lib["launches"], "ms_per_step": r_lib["total_ms"], "tflops": r_lib["tflops"]},
+                    "all_gemm": {"launches": r_all["launches"], "ms_per_step": r_all["total_ms"], "tflops": r_all["tflops"]},
+                    "tuner_wins_by_problem_key": GemmTuner.summary()}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -107,8 +107,8 @@ class GemmProfiler:
         for (e0, e1, f), sh in zip(self.records, self.shapes):
             a = agg.setdefault(sh, [0, 0.0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
-        rows = [{"M": k[0], "N": k[1], "K": k[2], "a_trans": k[3], "b_trans": k[4], "split_k": k[5], "launches": v[0],
-                 "ms": v[1], "tflops": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for k, v in agg.items()]
+        rows = [{"M": k[0], "N": k[1], "K": k[2], "a_trans": k[3], "b_trans": k[4], "split_k": k[5], "kernel": k[6],
+                 "launches": v[0], "ms": v[1], "tflops": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for k, v in agg.items()]
         return sorted(rows, key=lambda r: -r["ms"])
 
     def __enter__(self):
@@ -119,12 +119,14 @@ class GemmProfiler:
         GemmProfiler.active = None
         return False
 
-    def summary(self):
+    def summary(self, kernel=None):
+        """all launches, or only the ones run by `kernel` ("hip": the hand-written kernels, "library": hipBLASLt)"""
         torch.cuda.synchronize()
-        total_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        flops = sum(f for _, _, f in self.records)
-        n = max(len(self.records), 1)
-        return {"launches": len(self.records), "total_ms": total_ms, "avg_us": total_ms * 1e3 / n,
+        recs = [r for r, sh in zip(self.records, self.shapes) if kernel is None or sh[6] == kernel]
+        total_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+        flops = sum(f for _, _, f in recs)
+        n = max(len(recs), 1)
+        return {"launches": len(recs), "total_ms": total_ms, "avg_us": total_ms * 1e3 / n,
                 "gflop_per_launch": flops / n / 1e9, "tflops": (flops / (total_ms * 1e-3) / 1e12) if total_ms > 0 else 0.0}
 
 
@@ -140,41 +142,87 @@ class GemmTuner:
     does not apply to a shape falls back to the register-staged kernel inside the library, so every trial is valid.
     Disable with DVLA_GEMM_AUTOTUNE=0 (the library's cost model is then used for every call)."""
     CANDIDATES = (0, 4, 5, 6, 2)
+    LIBRARY = 8     # hipBLASLt through dvla_gemm_library_bf16: offered for epilogue-free GEMMs only (plain=True)
     ROUNDS = 1
     enabled = os.environ.get("DVLA_GEMM_AUTOTUNE", "1") != "0" and os.environ.get("DVLA_GEMM_VARIANT") is None
+    library = os.environ.get("DVLA_GEMM_LIBRARY", "1") != "0"
     table = {}      # key -> locked variant
     trials = {}     # key -> {"pending": [(variant, e0, e1)], "times": {variant: [ms]}, "next": int}
+    banned = set()  # keys on which the library candidate failed (no kernel / no workspace): never offered again
 
     @classmethod
-    def pick(cls, key):
+    def candidates(cls, key, plain):
+        if plain and cls.library and key not in cls.banned:
+            return cls.CANDIDATES + (cls.LIBRARY,)
+        return cls.CANDIDATES
+
+    @classmethod
+    def pick(cls, key, plain=False):
         v = cls.table.get(key)
         if v is not None:
             return v, None
-        st = cls.trials.setdefault(key, {"pending": [], "times": {c: [] for c in cls.CANDIDATES}, "next": 0})
+        st = cls.trials.get(key)
+        if st is None:
+            st = cls.trials[key] = {"pending": [], "times": {c: [] for c in cls.candidates(key, plain)}, "next": 0}
         still = []
         for (var, e0, e1) in st["pending"]:
             if e1.query():
-                st["times"][var].append(e0.elapsed_time(e1))
+                if var in st["times"]:
+                    st["times"][var].append(e0.elapsed_time(e1))
             else:
                 still.append((var, e0, e1))
         st["pending"] = still
+        cands = tuple(st["times"])
         if all(len(t) >= cls.ROUNDS for t in st["times"].values()):
-            best = min(cls.CANDIDATES, key=lambda c: sorted(st["times"][c])[len(st["times"][c]) // 2])
+            best = min(cands, key=lambda c: sorted(st["times"][c])[len(st["times"][c]) // 2])
             cls.table[key] = best
             del cls.trials[key]
             return best, None
-        var = cls.CANDIDATES[st["next"] % len(cls.CANDIDATES)]
+        var = cands[st["next"] % len(cands)]
         st["next"] += 1
         return var, st
 
     @classmethod
+    def ban_library(cls, key):
+        """the library candidate could not run this problem: drop it from the key's trial (or its lock)"""
+        cls.banned.add(key)
+        st = cls.trials.get(key)
+        if st is not None:
+            st["times"].pop(cls.LIBRARY, None)
+        if cls.table.get(key) == cls.LIBRARY:
+            del cls.table[key]
+
+    @classmethod
     def reset(cls):
-        cls.table.clear(); cls.trials.clear()
+        cls.table.clear(); cls.trials.clear(); cls.banned.clear()
+
+    @classmethod
+    def summary(cls):
+        """how many problem keys each configuration won (bench.py reports it next to the roofline)"""
+        out = {}
+        for v in cls.table.values():
+            name = "library" if v == cls.LIBRARY else f"hip:{v}"
+            out[name] = out.get(name, 0) + 1
+        return out
+
+
+_LIB_WS = {}
+
+
+def _library_workspace(device):
+    """one 64-MiB scratch buffer per (device, stream) for hipBLASLt's own split-K; kernels of a stream run in order"""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _LIB_WS.get(key)
+    if ws is None:
+        ws = _LIB_WS[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    return ws
 
 
 def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=False, dact_aux=None, dact=0,
-         dropout_p=0.0, seed=(0, 0), residual=None, res_rows=0, out_dtype=BF16, out=None, accumulate=False, split_k=1):
-    """C[M,N] = epilogue(A . B^T); see include/dvla.h.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
+         dropout_p=0.0, seed=(0, 0), residual=None, res_rows=0, out_dtype=BF16, out=None, accumulate=False, split_k=1,
+         variant=None):
+    """C[M,N] = epilogue(A . B^T); see include/dvla.h.  `variant` forces a kernel configuration (tests / sweeps;
+    GemmTuner.LIBRARY = hipBLASLt, epilogue-free problems only) instead of asking the tuner.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
     Returns C (and the pre-activation tensor if want_preact)."""
     lib = _lib.load()
     _req(a, "gemm.a"); _req(b, "gemm.b")
@@ -224,35 +272,53 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
             residual = residual.contiguous()
         p.residual, p.ld_res, p.res_rows = residual.data_ptr(), residual.stride(0), int(res_rows)
     p.accumulate = int(accumulate)
-    ws = None
-    if split_k > 1:
-        ws = torch.empty((split_k, M, N), dtype=torch.float32, device=a.device)
-        p.split_k, p.workspace = int(split_k), ws.data_ptr()
-    else:
-        p.split_k = 1
+    p.split_k = max(1, int(split_k))
     prof = GemmProfiler.active
-    variant, trial = 0, None
-    if GemmTuner.enabled:
-        variant, trial = GemmTuner.pick((M, N, K, int(a_trans), int(b_trans), int(p.split_k), int(act), int(dact),
-                                         bias is not None, want_preact, dact_aux is not None, residual is not None,
-                                         dropout_p > 0.0, out.dtype == torch.float32))
+    plain = (bias is None and act == 0 and not want_preact and dact_aux is None and residual is None
+             and dropout_p == 0.0)
+    trial, key = None, None
+    forced = variant is not None
+    variant = int(variant) if forced else 0
+    if GemmTuner.enabled and not forced:
+        key = (M, N, K, int(a_trans), int(b_trans), int(p.split_k), int(act), int(dact),
+               bias is not None, want_preact, dact_aux is not None, residual is not None,
+               dropout_p > 0.0, out.dtype == torch.float32, bool(accumulate))
+        variant, trial = GemmTuner.pick(key, plain)
     if prof is not None or trial is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if variant:
-        lib.dvla_set_gemm_variant(variant)
-    try:
-        check(lib.dvla_gemm_bf16(C.byref(p), _stream()), "dvla_gemm_bf16")
-    finally:
+    ran_library = False
+    if variant == GemmTuner.LIBRARY:
+        lws = _library_workspace(a.device)
+        p.split_k = 1                      # the library splits K itself, inside its workspace
+        rc = lib.dvla_gemm_library_bf16(C.byref(p), lws.data_ptr(), lws.numel(), _stream())
+        if rc == 0:
+            ran_library = True
+        elif forced:
+            check(rc, "dvla_gemm_library_bf16")
+        else:                              # no library kernel for this problem: never offer it again, run ours now
+            GemmTuner.ban_library(key)
+            variant, trial = 0, None
+            p.split_k = max(1, int(split_k))
+    if not ran_library:
+        ws = None
+        if p.split_k > 1:
+            ws = torch.empty((p.split_k, M, N), dtype=torch.float32, device=a.device)
+            p.workspace = ws.data_ptr()
         if variant:
-            lib.dvla_set_gemm_variant(0)
+            lib.dvla_set_gemm_variant(variant)
+        try:
+            check(lib.dvla_gemm_bf16(C.byref(p), _stream()), "dvla_gemm_bf16")
+        finally:
+            if variant:
+                lib.dvla_set_gemm_variant(0)
     if prof is not None or trial is not None:
         e1.record()
     if trial is not None:
         trial["pending"].append((variant, e0, e1))
     if prof is not None:
         prof.records.append((e0, e1, 2.0 * M * N * K))
-        prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k)))
+        prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k), "library" if ran_library else "hip"))
     return (out, preact) if want_preact else out
 
 

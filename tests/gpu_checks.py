@@ -54,7 +54,7 @@ def rnd(shape, gen, scale=1.0):
 
 # ---------------------------------------------------------------------------------------------------
 def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", residual=False, out_f32=False,
-               split_k=1, dropout_p=0.0, dact=None, want_preact=False, seed=0):
+               split_k=1, dropout_p=0.0, dact=None, want_preact=False, seed=0, variant=None):
     from dreamvla_amd import ops
     from dreamvla_amd._lib import ACT
     g = torch.Generator().manual_seed(1234 + seed)
@@ -70,7 +70,7 @@ def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", re
                  bias=None if bias_t is None else bias_t.to(DEV, BF), act=ACT[act], want_preact=want_preact,
                  dact_aux=None if aux_t is None else aux_t.to(DEV, BF), dact=ACT[dact] if dact else 0,
                  dropout_p=dropout_p, seed=sd, residual=None if res_t is None else res_t.to(DEV, BF),
-                 out_dtype=torch.float32 if out_f32 else BF, split_k=split_k)
+                 out_dtype=torch.float32 if out_f32 else BF, split_k=split_k, variant=variant)
     got, pre = r if want_preact else (r, None)
     ref = A @ B.t()
     if bias:
@@ -92,7 +92,7 @@ def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", re
         ref = ref * x.grad
     if residual:
         ref = ref + res_t
-    tag = f"gemm M{M} N{N} K{K} at{int(a_trans)} bt{int(b_trans)} bias{int(bias)} {act} res{int(residual)} f32{int(out_f32)} sk{split_k} p{dropout_p} dact{dact}"
+    tag = f"gemm{'' if variant is None else ' v%d' % variant} M{M} N{N} K{K} at{int(a_trans)} bt{int(b_trans)} bias{int(bias)} {act} res{int(residual)} f32{int(out_f32)} sk{split_k} p{dropout_p} dact{dact}"
     out.insert(0, metrics(tag, got, ref, TOL_F32 if out_f32 else TOL_FWD, round_ref=not out_f32))
     return out
 
@@ -332,6 +332,14 @@ def all_checks(quick=False):
         (check_gemm, dict(M=1024, N=768, K=4128, a_trans=True, b_trans=True, split_k=5, out_f32=True)),
         (check_gemm, dict(M=1300, N=832, K=64, bias=True, out_f32=True, residual=True)),
         (check_gemm, dict(M=768, N=3072, K=2048, a_trans=True, b_trans=True, split_k=3)),
+    ]
+    # the epilogue-free library comparator (dvla_gemm_library_bf16 -> hipBLASLt), forced: all four layouts, both C dtypes
+    for at in (False, True):
+        for bt in (False, True):
+            L.append((check_gemm, dict(M=512, N=384, K=256, a_trans=at, b_trans=bt, variant=8)))
+    L += [
+        (check_gemm, dict(M=1024, N=768, K=4128, a_trans=True, b_trans=True, out_f32=True, variant=8)),
+        (check_gemm, dict(M=2048, N=1024, K=96, b_trans=True, variant=8)),
     ]
     L += [(check_flat_adamw, dict())]
     L += [

@@ -58,3 +58,44 @@ def test_tuner_keys_are_independent():
     assert (a, b) == (0, 2)
     GemmTuner.reset()
     assert GemmTuner.table == {} and GemmTuner.trials == {}
+
+
+def drive_plain(key, cost):
+    calls = []
+    for _ in range(64):
+        v, trial = GemmTuner.pick(key, plain=True)
+        calls.append(v)
+        if trial is None:
+            return v, calls
+        trial["pending"].append((v, FakeEvent(0.0), FakeEvent(cost[v])))
+    raise AssertionError("tuner did not converge")
+
+
+def test_library_candidate_only_for_plain_keys():
+    GemmTuner.reset()
+    assert GemmTuner.LIBRARY not in GemmTuner.candidates(("fused",), plain=False)
+    assert GemmTuner.LIBRARY in GemmTuner.candidates(("plain",), plain=True)
+    cost = {0: 3.0, 4: 2.5, 5: 2.0, 6: 2.0, 2: 4.0, GemmTuner.LIBRARY: 1.0}
+    best, calls = drive_plain(("plain",), cost)
+    assert best == GemmTuner.LIBRARY and calls.count(GemmTuner.LIBRARY) == 2   # one trial + the locked call
+    assert GemmTuner.summary() == {"library": 1}
+    best, calls = drive(("fused",), cost)
+    assert best in (5, 6) and GemmTuner.LIBRARY not in calls
+
+
+def test_library_ban_removes_the_candidate():
+    GemmTuner.reset()
+    key = ("plain2",)
+    seen = []
+    for _ in range(32):
+        v, trial = GemmTuner.pick(key, plain=True)
+        if trial is None:
+            break
+        if v == GemmTuner.LIBRARY:
+            GemmTuner.ban_library(key)       # what ops.gemm does when dvla_gemm_library_bf16 returns an error
+            continue
+        seen.append(v)
+        trial["pending"].append((v, FakeEvent(0.0), FakeEvent(float(v + 1))))
+    assert GemmTuner.table[key] == 0 and GemmTuner.LIBRARY not in seen
+    assert GemmTuner.LIBRARY not in GemmTuner.candidates(key, plain=True)
+    GemmTuner.reset()
