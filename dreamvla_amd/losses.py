@@ -49,11 +49,13 @@ def label_actions(actions, sequence_length, action_pred_steps, atten_goal=0):
 
 def calvin_losses(outputs, batch, *, sequence_length, future_steps=3, atten_goal=0, pred_num=1, patch_size=16,
                   use_dit_head=True, loss_arm_action_ratio=1.0, loss_gripper_action_ratio=0.01, label_action=None,
-                  compute_dtype=torch.float32):
+                  flow_as_mask=False, compute_dtype=torch.float32):
     """outputs: the 10-tuple of DreamVLA.forward(mode='train'); batch: dict with window-length tensors
     (image_primary/image_wrist (B,W,3,224,224), optional depth_*/dino_*/sam_*/tracks*).  Returns (total, parts).
     The reference computes these in the model dtype; `compute_dtype=float32` (default) evaluates the reductions in
-    fp32, which is at least as accurate."""
+    fp32, which is at least as accurate.  `flow_as_mask` (LIBERO scripts, train_utils.py:283-333): the image loss is
+    taken on the patches whose 2x2-pooled track flow exceeds 1 px (primary mask dilated 3x3, wrist mask not).
+    Pinned against the real training loop's values and gradients: tests/test_losses_golden.py."""
     (arm, grip, image_pred, _, _, _, depth_pred, traj_pred, dino_pred, sam_pred) = outputs
     S, T = sequence_length, sequence_length - atten_goal
     lo, hi = future_steps, future_steps + T + pred_num - 1
@@ -74,7 +76,20 @@ def calvin_losses(outputs, batch, *, sequence_length, future_steps=3, atten_goal
             x = x.view(bs, T + pred_num - 1, *x.shape[1:])
             return x.unfold(1, pred_num, 1).permute(0, 1, 4, 2, 3).flatten(0, 1)
         ip = image_pred.reshape(bs, S, *image_pred.shape[1:])[:, :T].reshape(-1, *image_pred.shape[1:]).to(compute_dtype)
-        parts["image"] = 0.5 * (F.mse_loss(ip[:, 0], lab("image_primary")) + F.mse_loss(ip[:, 1], lab("image_wrist")))
+        lp, lw = lab("image_primary"), lab("image_wrist")
+        if flow_as_mask and "tracks" in batch:
+            def fmask(key, dilate):
+                t = batch[key][:, :T + pred_num - 1].to(compute_dtype)
+                hw = int(t.shape[2] ** 0.5)
+                tp = t.reshape(-1, hw, hw, t.shape[3]).permute(0, 3, 1, 2)                 # (B*P, 2, H, W)
+                m = (torch.norm(F.avg_pool2d(tp, kernel_size=2, stride=2), dim=1) > 1.0).unsqueeze(1).to(compute_dtype)
+                if dilate:
+                    m = F.max_pool2d(m, kernel_size=3, stride=1, padding=1)
+                return m.reshape(m.shape[0], 1, -1, 1)
+            mp, mw = fmask("tracks", True), fmask("tracks_gripper", False)
+            parts["image"] = 0.5 * (F.mse_loss(ip[:, 0] * mp, lp * mp) + F.mse_loss(ip[:, 1] * mw, lw * mw))
+        else:
+            parts["image"] = 0.5 * (F.mse_loss(ip[:, 0], lp) + F.mse_loss(ip[:, 1], lw))
     parts["depth"] = zero
     if depth_pred is not None:
         def dlab(key):
