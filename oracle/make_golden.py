@@ -114,6 +114,12 @@ FULL_CFGS = {
     "B": dict(finetune_type="calvin", sequence_length=2, num_resampler_query=16, num_obs_token_per_image=9,
               action_pred_steps=3, transformer_layers=2, hidden_dim=1024, transformer_heads=16, phase="finetune",
               obs_pred=True, use_dit_head=True, attn_implementation="sdpa"),
+    # BASELINE configs[3]: LIBERO flags (scripts/LIBERO/DreamVLA/finetune_long.sh: libero_finetune, --gripper_width, DiT head)
+    # with the DINO / SAM / CoTracker-trajectory dream heads switched on
+    "E": dict(finetune_type="libero_finetune", sequence_length=2, num_resampler_query=16, num_obs_token_per_image=9,
+              action_pred_steps=3, transformer_layers=2, hidden_dim=1024, transformer_heads=16, phase="finetune",
+              gripper_width=True, obs_pred=True, dino_feat_pred=True, sam_feat_pred=True, trajectory_pred=True,
+              use_dit_head=True, attn_implementation="sdpa"),
 }
 
 
@@ -146,6 +152,10 @@ def full_fixture(name):
     for k in ("image_primary", "image_wrist", "state", "text_token"):
         b[k] = b[k][:, :S]
     fx = dict(cfg=cfg, B=B, S=S, window=S + 3, seed=4321, action_label=label)
+    if cfg.get("gripper_width"):   # 6 arm values + the two finger widths (train_utils.py:128-129); stored, it is tiny
+        gw = torch.Generator().manual_seed(4322)
+        b["state"] = torch.cat([b["state"][..., :6], (torch.rand(B, S, 2, generator=gw) * 0.08).to(BF).float()], dim=-1)
+        fx["state"] = b["state"].clone()
     torch.manual_seed(0)
     real = {k: getattr(torch, k) for k in ("randn_like", "randint", "randn")}
     if cfg["use_dit_head"]:
@@ -182,10 +192,18 @@ def full_fixture(name):
     return fx
 
 
-def main():
+def main(only=()):
+    """`python -m oracle.make_golden E` regenerates only the named full-model fixture(s)"""
     assert ref_loader.available(), "needs /root/reference"
     os.makedirs(GOLD, exist_ok=True)
     src = "generated by oracle/make_golden.py from the REAL reference modules under /root/reference"
+    if only:
+        for name in only:
+            fx = full_fixture(name)
+            fx["source"] = src
+            torch.save(fx, os.path.join(GOLD, f"dreamvla_{name}.pt"))
+            print(name, os.path.getsize(os.path.join(GOLD, f"dreamvla_{name}.pt")))
+        return
     # masks
     from tests.test_mask import COMBOS
     ref = ref_loader.ref_module("models.dreamvla_model").generate_attention_mask
@@ -209,6 +227,8 @@ def main():
                    "entries": {k: list(v.shape) for k, v in mC.state_dict().items()}}, f)
     del mC
     for name in FULL_CFGS:
+        if only and name not in only:
+            continue
         fx = full_fixture(name)
         fx["source"] = src
         torch.save(fx, os.path.join(GOLD, f"dreamvla_{name}.pt"))
@@ -217,4 +237,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(tuple(sys.argv[1:]))

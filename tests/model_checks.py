@@ -65,7 +65,10 @@ def compare_outputs(got, want_list, tol, tag):
 def golden_inputs(fx):
     b = weights.synthetic_batch(fx["B"], fx["S"], window=fx["window"], seed=fx["seed"])
     S = fx["S"]
-    return {k: b[k][:, :S] for k in ("image_primary", "image_wrist", "state", "text_token")}
+    inp = {k: b[k][:, :S] for k in ("image_primary", "image_wrist", "state", "text_token")}
+    if "state" in fx:      # gripper_width configurations: 8-wide state stored in the fixture
+        inp["state"] = fx["state"]
+    return inp
 
 
 def build_hip_model(cfg, device="cuda", dtype=BF):

@@ -33,7 +33,7 @@ def test_diffusion_tables_vs_golden():
     assert np.allclose(full.sqrt_alphas_cumprod, d["sqrt_acp"].numpy(), rtol=0, atol=1e-15)
 
 
-@pytest.mark.parametrize("name", ["A", "B"])
+@pytest.mark.parametrize("name", ["A", "B", "E"])
 def test_oracle_full_model_vs_golden(name):
     fx = C.load(f"dreamvla_{name}.pt")
     cfg = fx["cfg"]

@@ -16,7 +16,7 @@ def test_hip_modules_vs_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["A", "B"])
+@pytest.mark.parametrize("name", ["A", "B", "E"])
 def test_hip_full_model_vs_golden(name):
     _assert_all(C.hip_full_model_checks(name))
 
