@@ -64,8 +64,22 @@ def space_timesteps(num_timesteps, section_counts):
     return set(all_steps)
 
 
+_DEV_TABLES = {}
+
+
+def _device_table(arr, device):
+    """float64 copy of a schedule table on `device`, made once: the per-call host->device copy of the reference
+    (gaussian_diffusion.py:870-882) is a pageable-memory copy, i.e. a host synchronisation per extract (50 per DDIM-10
+    sample) and illegal inside a hipGraph capture.  Same values, same float64 -> float32 gather."""
+    key = (arr.ctypes.data, arr.shape[0], str(device))
+    t = _DEV_TABLES.get(key)
+    if t is None:
+        t = _DEV_TABLES[key] = th.from_numpy(arr).to(device=device)
+    return t
+
+
 def _extract_into_tensor(arr, timesteps, broadcast_shape):
-    res = th.from_numpy(arr).to(device=timesteps.device)[timesteps].float()
+    res = _device_table(arr, timesteps.device)[timesteps].float()
     while len(res.shape) < len(broadcast_shape):
         res = res[..., None]
     return res + th.zeros(broadcast_shape, device=timesteps.device)
@@ -111,7 +125,7 @@ class GaussianDiffusion:
         assert eta == 0.0 and not clip_denoised, "only the eta=0, unclipped DDIM path of the reference is restated"
         img = noise if noise is not None else th.randn(*shape, device=device)
         for i in list(range(self.num_timesteps))[::-1]:
-            t = th.tensor([i] * shape[0], device=img.device)
+            t = th.full((shape[0],), i, device=img.device, dtype=th.long)   # a fill kernel, not a host->device copy
             with th.no_grad():
                 img = self.ddim_sample(model, img, t, model_kwargs=model_kwargs)["sample"]
         return img
@@ -135,7 +149,11 @@ class SpacedDiffusion(GaussianDiffusion):
         super().__init__(betas=np.array(new_betas))
 
     def _model_timesteps(self, t):
-        map_tensor = th.tensor(self.timestep_map, device=t.device, dtype=t.dtype)
+        key = (str(t.device), t.dtype)
+        cache = self.__dict__.setdefault("_map_tensors", {})
+        map_tensor = cache.get(key)
+        if map_tensor is None:
+            map_tensor = cache[key] = th.tensor(self.timestep_map, device=t.device, dtype=t.dtype)
         return map_tensor[t]
 
 

@@ -16,10 +16,16 @@ class TimestepEmbedder(nn.Module):
                                  Linear(hidden_size, hidden_size, bias=True))
         self.frequency_embedding_size = frequency_embedding_size
 
+    _FREQS = {}
+
     @staticmethod
     def timestep_embedding(t, dim, max_period=10000):
         half = dim // 2
-        freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(device=t.device)
+        key = (half, max_period, str(t.device))
+        freqs = TimestepEmbedder._FREQS.get(key)
+        if freqs is None:   # computed on the host exactly as the reference does (models.py:44-49), copied to the device once
+            freqs = TimestepEmbedder._FREQS[key] = torch.exp(
+                -math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(device=t.device)
         args = t[:, None].float() * freqs[None]
         embedding = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
         if dim % 2:

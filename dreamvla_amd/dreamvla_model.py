@@ -359,14 +359,18 @@ class DreamVLA(nn.Module):
                 mode='train'):
         if self.training and self.phase == "pretrain":
             self.attention_mask = nn.Parameter(self._make_mask().to(self.attention_mask.device), requires_grad=False)
+        parts = self.encode_frames(image_primary, image_wrist, state, text_token)
+        return self.decode_tokens(parts, action_label=action_label, mode=mode)
+
+    def encode_frames(self, image_primary, image_wrist, state, text_token):
+        """Conditioning tokens of every frame, as the list [text (B,S,1,H), state (B,S,1,H), primary image (B,S,nq,H),
+        wrist image (B,S,nq,H), cls primary (B,S,1,H), cls wrist (B,S,1,H)]  (dreamvla_model.py:643-737).  Each frame
+        is encoded independently of every other frame and of its position in the window (the window position embedding
+        is added in `decode_tokens`), which is what lets dreamvla_amd.rollout.RolloutEngine keep the tokens of the
+        frames it has already seen and encode only the newest one per control step."""
         B, S, _ = state.shape
-        device = image_primary.device
         H = self.hidden_dim
         wdt = self.text_projector.weight.dtype
-        image_pred = depth_pred = traj_pred = dino_pred = sam_pred = None
-        arm_pred_action = gripper_pred_action = None
-        arm_pred_state = gripper_pred_state = None
-        loss_arm_action = None
 
         # text: frozen CLIP text tower -> Linear(512, H)                                  (643-653)
         with torch.no_grad():
@@ -403,8 +407,25 @@ class DreamVLA(nn.Module):
         cls_primary = self.cls_token_primary_projector(cls2[0]).view(B, S, -1, H)
         cls_wrist = self.cls_token_wrist_projector(cls2[1]).view(B, S, -1, H)
 
+        return [text_embedding, state_embedding, image_primary_embedding, image_wrist_embedding, cls_primary, cls_wrist]
+
+    def decode_tokens(self, parts, action_label=None, mode='train'):
+        """Token assembly with the prediction queries, trunk, dream heads (train) and action head
+        (dreamvla_model.py:739-991).  `parts`: the list from `encode_frames`, or one (B, S, 36, H) tensor of them."""
+        if torch.is_tensor(parts):
+            parts = [parts]
+        else:
+            parts = list(parts)
+        B, S = parts[0].shape[:2]
+        n = B * S
+        H = self.hidden_dim
+        wdt = self.text_projector.weight.dtype
+        image_pred = depth_pred = traj_pred = dino_pred = sam_pred = None
+        arm_pred_action = gripper_pred_action = None
+        arm_pred_state = gripper_pred_state = None
+        loss_arm_action = None
+
         # token assembly                                                                     (739-759)
-        parts = [text_embedding, state_embedding, image_primary_embedding, image_wrist_embedding, cls_primary, cls_wrist]
         pred_token_start_idx = sum(p.shape[2] for p in parts)
         if self.obs_pred:
             parts.append(self.obs_tokens.to(wdt).expand(B, S, -1, -1))

@@ -149,6 +149,7 @@ class GemmTuner:
     table = {}      # key -> locked variant
     trials = {}     # key -> {"pending": [(variant, e0, e1)], "times": {variant: [ms]}, "next": int}
     banned = set()  # keys on which the library candidate failed (no kernel / no workspace): never offered again
+    frozen = False  # True (hipGraph capture / replay-critical sections): no trials, no events -- locked choice or the cost model
 
     @classmethod
     def candidates(cls, key, plain):
@@ -161,6 +162,8 @@ class GemmTuner:
         v = cls.table.get(key)
         if v is not None:
             return v, None
+        if cls.frozen:
+            return 0, None
         st = cls.trials.get(key)
         if st is None:
             st = cls.trials[key] = {"pending": [], "times": {c: [] for c in cls.candidates(key, plain)}, "next": 0}

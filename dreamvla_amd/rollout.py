@@ -1,0 +1,139 @@
+"""Closed-loop rollout engine: the evaluation-time use of the hot path (BASELINE.json
+configs[4]).
+
+The reference evaluates with `ModelWrapper.step` (utils/eval_utils_calvin.py:82-147, same in eval_utils_libero.py):
+per control step it appends the newest camera frames / robot state to `history_len`-deep queues, pads a short history
+by repeating the last frame, calls `model(..., mode="test")` on the WHOLE window -- re-encoding all `history_len`
+frames through the ViT and the resampler although only one of them is new -- and picks the action of the newest real
+frame.  This engine keeps that contract (same queue / padding / selection semantics, same DreamVLA weights, batched
+over independent episodes) and removes the redundant work:
+
+  * per-frame token cache: `DreamVLA.encode_frames` output (text | state | 2 x 16 resampled image tokens | 2 cls tokens
+    = 36 x H per frame) of every frame seen so far lives in a (B, S, 36, H) ring in HBM; a control step encodes ONLY
+    the newest frame (1/S of the ViT + resampler + CLIP work), shifts the ring and decodes;
+  * the decode (token assembly, 24-layer trunk under the block mask, action head incl. the 10-step DDIM sampler with
+    classifier-free guidance) has static shapes, so it is captured once into a hipGraph (`torch.cuda.CUDAGraph`; the
+    ctypes kernel launches go to torch's current stream, which is the capture stream) and replayed per step -- ~1 400
+    kernel launches of a few microseconds each at B = 1 are launch-bound otherwise.
+
+Episodes of one batch advance in lock-step (one `step` = one control step of every episode); `reset(mask)` restarts
+the episodes selected by a boolean mask (their history is cleared, the others keep theirs).
+"""
+import torch
+
+from .ops import GemmTuner
+
+
+class RolloutEngine:
+    def __init__(self, model, batch_size, history_len=None, use_graph=True, warmup_decodes=3):
+        self.model = model.module if hasattr(model, "module") else model
+        m = self.model
+        if m.training:
+            raise ValueError("RolloutEngine drives an eval() model (dropout off), like the reference's evaluation")
+        self.B = int(batch_size)
+        self.S = int(history_len or m.sequence_length)
+        if self.S != m.sequence_length:
+            raise ValueError("history_len must equal the model's sequence_length (the attention mask is built for it)")
+        p = next(m.transformer_backbone.parameters())
+        self.device, self.dtype = p.device, p.dtype
+        self.H = m.hidden_dim
+        self.tokens = None                      # (B, S, 36, H) ring, oldest frame first
+        self.count = torch.zeros(self.B, dtype=torch.long)          # host: frames seen per episode (capped at S)
+        self.use_graph = bool(use_graph)
+        self.warmup_decodes = int(warmup_decodes)
+        self._graph = None
+        self._static_in = None
+        self._static_out = None
+        self._decodes = 0
+
+    # ------------------------------------------------------------------------------------------------------------
+    def reset(self, mask=None):
+        """forget the history of the selected episodes (all when mask is None)"""
+        if mask is None:
+            self.count.zero_()
+        else:
+            self.count[torch.as_tensor(mask, dtype=torch.bool).cpu()] = 0
+
+    @torch.no_grad()
+    def encode_newest(self, image_primary, image_wrist, state, text_token):
+        """(B,3,224,224) x 2, (B,7|8), (B,77) int64 -> (B, 36, H) tokens of the newest frame"""
+        m = self.model
+        parts = m.encode_frames(image_primary.unsqueeze(1), image_wrist.unsqueeze(1), state.unsqueeze(1),
+                                text_token.unsqueeze(1))
+        return torch.cat(parts, dim=2)[:, 0]
+
+    def _push(self, new_tok):
+        """queue semantics of ModelWrapper.step: append; while an episode has seen k < S frames its window is
+        [f1 .. fk, fk, ..., fk] (eval_utils_calvin.py:118-126); afterwards the window slides."""
+        B, S = self.B, self.S
+        if self.tokens is None:
+            self.tokens = new_tok.unsqueeze(1).expand(B, S, *new_tok.shape[1:]).contiguous()
+            self.count.fill_(1)
+            return
+        k = self.count                                    # frames seen BEFORE this one
+        full = (k >= S)
+        if bool(full.all()):
+            self.tokens = torch.cat((self.tokens[:, 1:], new_tok.unsqueeze(1)), dim=1)
+        else:
+            idx = torch.arange(S).unsqueeze(0).expand(B, S)
+            kk = k.unsqueeze(1)
+            # source slot for window position j: sliding episodes take j+1 (last <- new); filling episodes keep j < k
+            # and take the new frame for every j >= k
+            src = torch.where(full.unsqueeze(1), (idx + 1).clamp(max=S), torch.where(idx < kk, idx, torch.full_like(idx, S)))
+            ext = torch.cat((self.tokens, new_tok.unsqueeze(1)), dim=1)                  # slot S = the new frame
+            gather = src.to(self.device).view(B, S, 1, 1).expand(B, S, *new_tok.shape[1:])
+            self.tokens = torch.gather(ext, 1, gather)
+        self.count = torch.clamp(k + 1, max=S)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _decode_eager(self, tokens):
+        out = self.model.decode_tokens(tokens, mode="test")
+        return out[0], out[1]
+
+    @torch.no_grad()
+    def _decode(self, tokens):
+        if not self.use_graph:
+            return self._decode_eager(tokens)
+        if self._graph is None:
+            if self._decodes < self.warmup_decodes:     # eager steps first: the GEMM tuner locks, lazy tables get built
+                self._decodes += 1
+                return self._decode_eager(tokens)
+            self._static_in = tokens.clone()
+            torch.cuda.synchronize()
+            was = GemmTuner.frozen
+            GemmTuner.frozen = True                      # no timing events / trials inside the capture
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._decode_eager(self._static_in)  # once on the capture-side stream (per-stream workspaces)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._static_out = self._decode_eager(self._static_in)
+                self._graph = g
+            finally:
+                GemmTuner.frozen = was
+        self._static_in.copy_(tokens)
+        self._graph.replay()
+        return self._static_out[0].clone(), self._static_out[1].clone()
+
+    @torch.no_grad()
+    def step(self, image_primary, image_wrist, state, text_token):
+        """One control step of every episode.  Returns (action (B, 7) float32 on the device: 6 arm values and the
+        gripper command in {-1, +1} as ModelWrapper.step builds it (eval_utils_calvin.py:136-146), arm (B,S,steps,6),
+        gripper (B,S,steps,1))."""
+        dt = self.dtype
+        new_tok = self.encode_newest(image_primary.to(self.device, dt), image_wrist.to(self.device, dt),
+                                     state.to(self.device, dt), text_token.to(self.device))
+        self._push(new_tok)
+        arm, grip = self._decode(self.tokens)
+        B, S = self.B, self.S
+        if arm.dim() == 4 and arm.shape[0] == 1 and B * S == arm.shape[1]:   # DiT test head returns (1, B*S, steps, .)
+            arm, grip = arm.view(B, S, *arm.shape[2:]), grip.view(B, S, *grip.shape[2:])
+        sel = (self.count - 1).to(self.device)                               # newest real frame of each episode
+        bi = torch.arange(B, device=self.device)
+        a = arm[bi, sel, 0, :].float()
+        g = (grip[bi, sel, 0, :].float() > 0.5).float()
+        action = torch.cat((a, (g - 0.5) * 2), dim=-1)
+        return action, arm, grip

@@ -1,0 +1,72 @@
+"""BASELINE.json configs[4] (rollout inference): control steps per second of
+  naive  : the reference wrapper's way -- model(full S-frame window, mode="test") every step (eval_utils_calvin.py:127-134)
+  engine : dreamvla_amd.rollout.RolloutEngine, per-frame token cache, eager decode
+  graph  : the same with the decode captured in a hipGraph
+on one MI355X, full-size model (1024/24/16, S = 10 as scripts/CALVIN_ABC_D/DreamVLA/eval.sh, DiT head + DDIM-10),
+B episodes in lock-step.  Writes gpurun_out/rollout_bench.json.   python tests/gpu_rollout_bench.py [B ...]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from dreamvla_amd.dreamvla_model import DreamVLA
+    from dreamvla_amd.rollout import RolloutEngine
+    Bs = [int(a) for a in sys.argv[1:]] or [1, 64]
+    S, BF, dev = 10, torch.bfloat16, "cuda"
+    cfg = dict(finetune_type="calvin", sequence_length=S, num_resampler_query=16, num_obs_token_per_image=9,
+               action_pred_steps=3, transformer_layers=24, hidden_dim=1024, transformer_heads=16, phase="finetune",
+               obs_pred=True, depth_pred=True, sam_feat_pred=True, use_dit_head=True, attn_implementation="sdpa")
+    torch.manual_seed(0)
+    m = DreamVLA(clip_device="cpu", vit_checkpoint_path=None, **cfg).bfloat16().to(dev)
+    m._init_model_type()
+    m.eval()
+    out = {"config": "eval step, S=10, DiT head DDIM-10 + CFG, head set C weights, bf16, 1x MI355X", "rows": []}
+    for B in Bs:
+        g = torch.Generator().manual_seed(B)
+        frames = [(torch.randn(B, 3, 224, 224, generator=g).to(dev, BF), torch.randn(B, 3, 224, 224, generator=g).to(dev, BF),
+                   torch.cat([torch.rand(B, 6, generator=g), torch.ones(B, 1)], -1).to(dev, BF)) for _ in range(4)]
+        text = torch.randint(1, 49000, (B, 77), generator=g).to(dev)
+        row = {"B": B}
+        # naive: full window every step
+        win = [torch.stack([frames[i % 4][k] for i in range(S)], dim=1) for k in range(3)]
+        tt = text.unsqueeze(1).repeat(1, S, 1)
+        with torch.no_grad():
+            for _ in range(6):            # GEMM tuner settles
+                m(win[0], win[1], win[2], tt, mode="test")
+            torch.cuda.synchronize()
+            n = 5
+            t0 = time.perf_counter()
+            for _ in range(n):
+                m(win[0], win[1], win[2], tt, mode="test")
+            torch.cuda.synchronize()
+            row["naive_ms_per_step"] = (time.perf_counter() - t0) / n * 1e3
+        for name, graph in (("engine", False), ("graph", True)):
+            eng = RolloutEngine(m, B, use_graph=graph, warmup_decodes=6)
+            for i in range(S + 8):
+                eng.step(*frames[i % 4], text)
+            torch.cuda.synchronize()
+            n = 20
+            t0 = time.perf_counter()
+            for i in range(n):
+                eng.step(*frames[i % 4], text)
+            torch.cuda.synchronize()
+            row[name + "_ms_per_step"] = (time.perf_counter() - t0) / n * 1e3
+            if graph:
+                row["graph_captured"] = eng._graph is not None
+        row["episode_steps_per_s"] = {k[:-12]: B * 1e3 / v for k, v in row.items() if k.endswith("_ms_per_step")}
+        out["rows"].append(row)
+        print(json.dumps(row), flush=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "rollout_bench.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

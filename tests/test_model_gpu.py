@@ -24,3 +24,12 @@ def test_hip_full_model_vs_golden(name):
 @pytest.mark.gpu
 def test_hip_whole_model_gradients_vs_oracle():
     _assert_all(C.hip_grad_checks())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("head,graph", [("mlp", False), ("mlp", True), ("dit", False), ("dit", True)])
+def test_rollout_engine_vs_full_window_forward(head, graph):
+    """dreamvla_amd.rollout.RolloutEngine (per-frame token cache, optional hipGraph decode) against the reference
+    wrapper's semantics: full-window model(..., mode="test") on the queued frames, action of the newest real frame."""
+    from tests import rollout_checks
+    _assert_all(rollout_checks.gpu_rollout_checks(head=head, use_graph=graph))
