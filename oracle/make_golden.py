@@ -177,6 +177,20 @@ def full_fixture(name):
                 torch.randn = lambda *a, **k: test_noise.clone()
                 out = m(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], mode="test")
                 fx["test"] = [None if o is None else o.detach().clone() for o in out]
+                # the reference's OWN bf16 path (train.py --precision amp_bf16 -> autocast) on the same inputs / noise, five
+                # times (CPU bf16 GEMMs are not run-to-run deterministic): its scatter around the fp32 value is the bf16 floor
+                # of the action-MSE and sets the tolerance of the GPU check (tests/model_checks.py).  Run last, so the fp32
+                # outputs above stay bit-identical to earlier fixture generations.
+                torch.randn = real["randn"]
+                torch.randn_like = lambda x, **k: noise.clone()
+                torch.randint = lambda *a, **k: tstep.clone()
+                runs = []
+                for _ in range(5):
+                    with torch.autocast("cpu", dtype=BF):
+                        o16 = m(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], action=None,
+                                action_label=label, mode="train")
+                    runs.append(float(o16[0]))
+                fx["train_loss_ref_amp_bf16_runs"] = runs
     finally:
         for k, v in real.items():
             setattr(torch, k, v)
