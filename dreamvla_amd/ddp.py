@@ -10,8 +10,14 @@ are constructed but never used.  This reducer is built for the MI355X node inste
     a bucket has been accumulated its all-reduce is launched asynchronously on the communication stream while
     backward keeps running -- xGMI is point-to-point (7 links x ~153 GB/s per GPU), so few large collectives beat
     many 25 MB ones;
-  * parameters that receive no gradient (the reference's unused modules) simply never fire: their buckets are
-    flushed at `finish()` with zeros -- no per-iteration graph walk;
+  * parameters that receive no gradient (the reference's constructed-but-unused modules: action_pose_encoder,
+    recon_state_decoder, the DiT history embedder ... -- they sit in three of the four buckets of the CALVIN
+    configuration) never fire.  The first step flushes their buckets at `finish()`; from the set of parameters that did
+    fire the reducer then LEARNS which ones to wait for, so from the second step on a bucket is launched as soon as its
+    used parameters are done and the exchange overlaps with backward (no per-iteration graph walk as in
+    find_unused_parameters=True).  If the used set ever grows, the bucket is held until `finish()` for that step and the
+    set is re-learned; a gradient arriving after its bucket was launched raises (pass static_unused=False to always
+    flush such buckets at `finish()`);
   * `finish()` waits for the handles and averages (divide by world size), exactly DDP's semantics.
 """
 import torch
@@ -19,9 +25,10 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, params, bucket_bytes=256 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=256 << 20, process_group=None, static_unused=True):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
+        self.static_unused = bool(static_unused)
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []       # dicts: flat, params, pending
         order = list(reversed(self.params))
@@ -40,8 +47,8 @@ class GradBucketReducer:
         self._handles = []
         self._hooks = []
         for bi, b in enumerate(self.buckets):
-            for p in b["params"]:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+            for pi, p in enumerate(b["params"]):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, pi)))
 
     ALIGN = 128   # elements: every view starts on a 256-byte boundary (the kernels read parameters / gradients as 16-B vectors)
 
@@ -53,13 +60,25 @@ class GradBucketReducer:
         flat = torch.zeros(off, dtype=plist[0].dtype, device=plist[0].device)
         for p, o in zip(plist, offsets):
             p.grad = flat[o:o + p.numel()].view_as(p)
-        self.buckets.append({"flat": flat, "params": plist, "offsets": offsets, "pending": len(plist), "launched": False})
+        self.buckets.append({"flat": flat, "params": plist, "offsets": offsets, "pending": len(plist), "launched": False,
+                             "fired": [False] * len(plist),      # this step
+                             "expected": [True] * len(plist),    # parameters the launch waits for (learned)
+                             "hold": False})
 
-    def _make_hook(self, bi):
+    def _make_hook(self, bi, pi):
         def hook(param):
             b = self.buckets[bi]
+            if b["fired"][pi]:
+                return
+            b["fired"][pi] = True
+            if not b["expected"][pi]:
+                if b["launched"]:
+                    raise RuntimeError("GradBucketReducer: a parameter that received no gradient in earlier steps received one "
+                                       "after its bucket's all-reduce was launched; use static_unused=False")
+                b["hold"] = True          # the used set grew: flush at finish() this step, re-learn there
+                return
             b["pending"] -= 1
-            if b["pending"] == 0 and not b["launched"]:
+            if b["pending"] == 0 and not b["launched"] and not b["hold"]:
                 self._launch(b)
         return hook
 
@@ -72,11 +91,10 @@ class GradBucketReducer:
         """zero the flat buffers (grads stay views) and re-arm the hooks for the next backward."""
         for b in self.buckets:
             b["flat"].zero_()
-            b["pending"] = len(b["params"])
+            b["pending"] = sum(b["expected"])
             b["launched"] = False
-            for p in b["params"]:
-                if p.grad is None or p.grad.data_ptr() < b["flat"].data_ptr():
-                    pass
+            b["hold"] = False
+            b["fired"] = [False] * len(b["params"])
         self._handles = []
 
     def finish(self):
@@ -84,6 +102,11 @@ class GradBucketReducer:
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)
+            if self.static_unused and any(b["fired"]):
+                if b["hold"]:                       # grew: wait for everything seen so far
+                    b["expected"] = [e or f for e, f in zip(b["expected"], b["fired"])]
+                elif all(b["expected"]):            # first learning step: wait only for what fired
+                    b["expected"] = list(b["fired"])
         for h in self._handles:
             h.wait()
         self._handles = []

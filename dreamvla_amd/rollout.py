@@ -11,9 +11,10 @@ over independent episodes) and removes the redundant work:
   * per-frame token cache: `DreamVLA.encode_frames` output (text | state | 2 x 16 resampled image tokens | 2 cls tokens
     = 36 x H per frame) of every frame seen so far lives in a (B, S, 36, H) ring in HBM; a control step encodes ONLY
     the newest frame (1/S of the ViT + resampler + CLIP work), shifts the ring and decodes;
-  * the decode (token assembly, 24-layer trunk under the block mask, action head incl. the 10-step DDIM sampler with
-    classifier-free guidance) has static shapes, so it is captured once into a hipGraph (`torch.cuda.CUDAGraph`; the
-    ctypes kernel launches go to torch's current stream, which is the capture stream) and replayed per step -- ~1 400
+  * both halves of a step have static shapes -- the newest-frame encode (CLIP text tower, ViT on two views, resampler,
+    projectors) and the decode (token assembly, 24-layer trunk under the block mask, action head incl. the 10-step DDIM
+    sampler with classifier-free guidance) -- so each is captured once into a hipGraph (`torch.cuda.CUDAGraph`; the
+    ctypes kernel launches go to torch's current stream, which is the capture stream) and replayed per step: ~1 700
     kernel launches of a few microseconds each at B = 1 are launch-bound otherwise.
 
 Episodes of one batch advance in lock-step (one `step` = one control step of every episode); `reset(mask)` restarts
@@ -22,6 +23,38 @@ the episodes selected by a boolean mask (their history is cleared, the others ke
 import torch
 
 from .ops import GemmTuner
+
+
+class _Graphed:
+    """fn(*tensors) -> tuple of tensors, static shapes: `warmup` eager calls (the GEMM tuner locks its choices, lazily
+    built tables and per-kernel attributes get set up), then one capture into a hipGraph and replays on static buffers."""
+
+    def __init__(self, fn, warmup):
+        self.fn, self.warmup = fn, int(warmup)
+        self.calls = 0
+        self.graph = None
+        self.static_in = self.static_out = None
+
+    def __call__(self, *tensors):
+        if self.graph is None:
+            if self.calls < self.warmup:
+                self.calls += 1
+                return self.fn(*tensors)
+            self.static_in = [t.clone() for t in tensors]
+            torch.cuda.synchronize()
+            was = GemmTuner.frozen
+            GemmTuner.frozen = True                      # no timing events / trials inside the capture
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.static_out = self.fn(*self.static_in)
+                self.graph = g
+            finally:
+                GemmTuner.frozen = was
+        for s, t in zip(self.static_in, tensors):
+            s.copy_(t)
+        self.graph.replay()
+        return tuple(o.clone() for o in self.static_out)
 
 
 class RolloutEngine:
@@ -41,10 +74,8 @@ class RolloutEngine:
         self.count = torch.zeros(self.B, dtype=torch.long)          # host: frames seen per episode (capped at S)
         self.use_graph = bool(use_graph)
         self.warmup_decodes = int(warmup_decodes)
-        self._graph = None
-        self._static_in = None
-        self._static_out = None
-        self._decodes = 0
+        self._decode_g = _Graphed(self._decode_eager, warmup_decodes) if self.use_graph else None
+        self._encode_g = _Graphed(self._encode_eager, warmup_decodes) if self.use_graph else None
 
     # ------------------------------------------------------------------------------------------------------------
     def reset(self, mask=None):
@@ -54,13 +85,18 @@ class RolloutEngine:
         else:
             self.count[torch.as_tensor(mask, dtype=torch.bool).cpu()] = 0
 
-    @torch.no_grad()
-    def encode_newest(self, image_primary, image_wrist, state, text_token):
-        """(B,3,224,224) x 2, (B,7|8), (B,77) int64 -> (B, 36, H) tokens of the newest frame"""
+    def _encode_eager(self, image_primary, image_wrist, state, text_token):
         m = self.model
         parts = m.encode_frames(image_primary.unsqueeze(1), image_wrist.unsqueeze(1), state.unsqueeze(1),
                                 text_token.unsqueeze(1))
-        return torch.cat(parts, dim=2)[:, 0]
+        return (torch.cat(parts, dim=2)[:, 0],)
+
+    @torch.no_grad()
+    def encode_newest(self, image_primary, image_wrist, state, text_token):
+        """(B,3,224,224) x 2, (B,7|8), (B,77) int64 -> (B, 36, H) tokens of the newest frame (CLIP text tower, state
+        encoders, ViT on both views, resampler, projectors: ~330 launches, one hipGraph when use_graph)"""
+        f = self._encode_g if self.use_graph else self._encode_eager
+        return f(image_primary.contiguous(), image_wrist.contiguous(), state.contiguous(), text_token.contiguous())[0]
 
     def _push(self, new_tok):
         """queue semantics of ModelWrapper.step: append; while an episode has seen k < S frames its window is
@@ -92,31 +128,11 @@ class RolloutEngine:
 
     @torch.no_grad()
     def _decode(self, tokens):
-        if not self.use_graph:
-            return self._decode_eager(tokens)
-        if self._graph is None:
-            if self._decodes < self.warmup_decodes:     # eager steps first: the GEMM tuner locks, lazy tables get built
-                self._decodes += 1
-                return self._decode_eager(tokens)
-            self._static_in = tokens.clone()
-            torch.cuda.synchronize()
-            was = GemmTuner.frozen
-            GemmTuner.frozen = True                      # no timing events / trials inside the capture
-            try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    self._decode_eager(self._static_in)  # once on the capture-side stream (per-stream workspaces)
-                torch.cuda.current_stream().wait_stream(side)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._static_out = self._decode_eager(self._static_in)
-                self._graph = g
-            finally:
-                GemmTuner.frozen = was
-        self._static_in.copy_(tokens)
-        self._graph.replay()
-        return self._static_out[0].clone(), self._static_out[1].clone()
+        return (self._decode_g if self.use_graph else self._decode_eager)(tokens)
+
+    @property
+    def graphs_captured(self):
+        return self.use_graph and self._decode_g.graph is not None and self._encode_g.graph is not None
 
     @torch.no_grad()
     def step(self, image_primary, image_wrist, state, text_token):

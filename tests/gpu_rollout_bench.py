@@ -59,7 +59,7 @@ def main():
             torch.cuda.synchronize()
             row[name + "_ms_per_step"] = (time.perf_counter() - t0) / n * 1e3
             if graph:
-                row["graph_captured"] = eng._graph is not None
+                row["graph_captured"] = eng.graphs_captured
         row["episode_steps_per_s"] = {k[:-12]: B * 1e3 / v for k, v in row.items() if k.endswith("_ms_per_step")}
         out["rows"].append(row)
         print(json.dumps(row), flush=True)

@@ -78,5 +78,5 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7, tol=2e-2):
             r2 = float((arm.float() - ra.float()).norm() / max(float(ra.float().norm()), 1e-12))
             res.append({"name": f"rollout.{head}.graph{int(use_graph)}.t{t}.arm_all_positions", "rel_l2": r2, "tol": tol, "ok": r2 <= tol})
     if use_graph:
-        res.append({"name": f"rollout.{head}.graph_captured", "rel_l2": 0.0, "tol": 0.0, "ok": eng._graph is not None})
+        res.append({"name": f"rollout.{head}.graph_captured", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
     return res

@@ -25,8 +25,13 @@ class Tiny(nn.Module):
         self.unused = nn.Linear(4, 4)          # constructed but never used (like the reference's action_projector)
         self.tok = nn.Parameter(torch.zeros(1, 8))
 
+        self.use_extra = False
+
     def forward(self, x):
-        return self.b(torch.relu(self.a(x))) + self.tok
+        y = self.b(torch.relu(self.a(x))) + self.tok
+        if self.use_extra:                     # the used set grows in a later step
+            y = y + self.unused(x[:, :4]).sum(dim=1, keepdim=True)
+        return y
 
 
 def _worker(rank, world, port, q):
@@ -41,16 +46,26 @@ def _worker(rank, world, port, q):
     X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
     xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
     out = {}
-    for it in range(2):                                              # two steps: buffers must re-arm correctly
+    early = {}
+    for it in range(5):                 # steps 0-2: `unused` gets no gradient (learned after step 0); 3-4: it does
+        m.use_extra = it >= 3
         red.zero_grad()
         loss = ((m(xs) - ys) ** 2).mean()
         loss.backward()
+        early[it] = [b["launched"] for b in red.buckets]             # launched during backward, before finish()
         red.finish()
         assert red.grads_are_views()
         out[it] = {n: p.grad.clone() for n, p in m.named_parameters()}
         with torch.no_grad():
             for p in m.parameters():
                 p -= 0.1 * p.grad
+    ub = [i for i, b in enumerate(red.buckets) if any(p is m.unused.weight or p is m.unused.bias for p in b["params"])]
+    mixed = [i for i in ub if any(p is not m.unused.weight and p is not m.unused.bias for p in red.buckets[i]["params"])]
+    assert not all(early[0])                        # step 0: buckets holding an unused parameter wait for finish()
+    for i in mixed:                                 # steps 1-2: they are launched as soon as their USED parameters are done
+        assert not early[0][i] and early[1][i] and early[2][i], (early, i)
+    for i in ub:                                    # step 3: the used set grew -> held until finish(); step 4: re-learned
+        assert not early[3][i] and early[4][i], (early, i)
     if rank == 0:
         q.put({it: {k: v.numpy() for k, v in d.items()} for it, d in out.items()})
     dist.barrier()
@@ -74,7 +89,8 @@ def test_bucket_reducer_matches_full_batch_gradients():
     m = Tiny()
     g = torch.Generator().manual_seed(5)
     X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
-    for it in range(2):
+    for it in range(5):
+        m.use_extra = it >= 3
         m.zero_grad()
         ((m(X) - Y) ** 2).mean().backward()
         for n, p in m.named_parameters():
