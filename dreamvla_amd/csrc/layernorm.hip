@@ -113,7 +113,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
                                                             const void* __restrict__ gamma, int pf32,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             bf16_t* __restrict__ dx, float* __restrict__ partial,
-                                                            int64_t rows, int cols) {
+                                                            int64_t rows, int cols, const bf16_t* __restrict__ dres) {
   __shared__ float red[4][64 * 8];  // one vector-slot at a time: [wave][lane*8+e]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols >> 3;
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
     s1 = wave_sum(s1) * inv_n;
     s2 = wave_sum(s2) * inv_n;
     uint4* dr = reinterpret_cast<uint4*>(dx + row * cols);
+    const uint4* rr = dres ? reinterpret_cast<const uint4*>(dres + row * cols) : nullptr;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int vi = lane + 64 * i;
@@ -163,6 +164,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
+        if (rr) {   // gradient of the residual stream that bypassed this LayerNorm: dx = dres + LN'(dy), one rounding
+          float a[8];
+          unpack8(rr[vi], a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += a[e];
+        }
         dr[vi] = pack8(o);
       }
     }
@@ -247,10 +254,22 @@ extern "C" int dvla_layernorm_fwd(const void* x, const void* gamma, const void* 
   return dvla_check_launch();
 }
 
+extern "C" int dvla_layernorm_bwd_add(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
+                                      const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
+                                      float* dbeta, float* partial, int64_t rows, int64_t cols, void* stream_);
+
 extern "C" int dvla_layernorm_bwd(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                   float* partial, int64_t rows, int64_t cols, void* stream_) {
+  return dvla_layernorm_bwd_add(dy, x, gamma, param_dtype, mean, rstd, nullptr, dx, dgamma, dbeta, partial, rows, cols, stream_);
+}
+
+extern "C" int dvla_layernorm_bwd_add(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
+                                      const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
+                                      float* dbeta, float* partial, int64_t rows, int64_t cols, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const bf16_t* drp = reinterpret_cast<const bf16_t*>(dres);
+  if ((reinterpret_cast<uintptr_t>(dres) & 15) != 0) return DVLA_ERR_UNSUPPORTED;
   if (!dy || !x || !mean || !rstd || !dx || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
   if ((dgamma || dbeta) && !partial) return DVLA_ERR_ARG;
   if (rows == 0) return DVLA_OK;
@@ -266,10 +285,10 @@ extern "C" int dvla_layernorm_bwd(const void* dy, const void* x, const void* gam
   const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
   bf16_t* dxp = reinterpret_cast<bf16_t*>(dx);
   switch (vpl) {
-    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols); break;
-    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols); break;
-    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols); break;
-    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols); break;
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp); break;
+    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp); break;
   }
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;

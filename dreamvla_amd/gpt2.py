@@ -91,9 +91,10 @@ class GPT2Block(nn.Module):
         self.mlp = GPT2MLP(inner_dim, config)
 
     def forward(self, hidden_states, mask_tables=None):
-        hidden_states = self.attn(self.ln_1(hidden_states), mask_tables=mask_tables, residual=hidden_states)
-        hidden_states = self.mlp(self.ln_2(hidden_states), residual=hidden_states)
-        return hidden_states
+        res, normed = self.ln_1.fork(hidden_states)     # x and LN(x): backward adds dL/dx of both paths in one kernel
+        hidden_states = self.attn(normed, mask_tables=mask_tables, residual=res)
+        res, normed = self.ln_2.fork(hidden_states)
+        return self.mlp(normed, residual=res)
 
 
 class GPT2Model(nn.Module):

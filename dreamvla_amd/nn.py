@@ -24,6 +24,11 @@ class LayerNorm(nn.LayerNorm):
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
+    def fork(self, x):
+        """(x, LayerNorm(x)) for pre-LN residual blocks: backward adds the residual-stream gradient inside the
+        LayerNorm-backward kernel (ops._LayerNormFork)."""
+        return ops.layer_norm_fork(x, self.weight, self.bias, self.eps)
+
 
 class Conv1D(nn.Module):
     """HF GPT-2 Conv1D: y = x @ W + b with W of shape (nx, nf)."""
@@ -86,6 +91,11 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act=act)
 
     def forward(self, x):
+        if isinstance(self.norm1, LayerNorm) and isinstance(self.norm2, LayerNorm):
+            r, n = self.norm1.fork(x)
+            x = self.attn(n, residual=r)
+            r, n = self.norm2.fork(x)
+            return self.mlp(n, residual=r)
         x = self.attn(self.norm1(x), residual=x)
         x = self.mlp(self.norm2(x), residual=x)
         return x

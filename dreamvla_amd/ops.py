@@ -347,7 +347,8 @@ def layernorm_fwd(x2, gamma, beta, eps, want_stats):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads):
+def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads, dres2=None):
+    """dres2: gradient of the residual stream that bypassed the LayerNorm; added to dx inside the kernel"""
     lib = _lib.load()
     rows, cols = x2.shape
     dx = torch.empty_like(x2)
@@ -357,9 +358,9 @@ def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads):
         db = torch.empty(cols, dtype=torch.float32, device=x2.device)
         part = torch.empty(2 * lib.dvla_layernorm_bwd_partial_rows() * cols, dtype=torch.float32, device=x2.device)
     pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
-    check(lib.dvla_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), _ptr(gamma), pdt, mean.data_ptr(), rstd.data_ptr(),
-                                 dx.data_ptr(), _ptr(dg), _ptr(db), _ptr(part), rows, cols, _stream()),
-          "dvla_layernorm_bwd")
+    check(lib.dvla_layernorm_bwd_add(dy2.data_ptr(), x2.data_ptr(), _ptr(gamma), pdt, mean.data_ptr(), rstd.data_ptr(),
+                                     _ptr(dres2), dx.data_ptr(), _ptr(dg), _ptr(db), _ptr(part), rows, cols, _stream()),
+          "dvla_layernorm_bwd_add")
     return dx, dg, db
 
 
@@ -711,6 +712,57 @@ class _LayerNorm(torch.autograd.Function):
 
 def layer_norm(x, weight, bias, eps):
     return _LayerNorm.apply(x, weight, bias, float(eps))
+
+
+class _LayerNormFork(torch.autograd.Function):
+    """(x, LN(x)) for a pre-LN residual block h = x + f(LN(x)): the first output is x itself, to be used as the residual
+    operand of f's last GEMM.  Backward receives both gradients and returns dL/dh + LN'(dL/dLN) from ONE kernel
+    (dvla_layernorm_bwd_add) instead of LayerNorm-backward followed by autograd's accumulation add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _req(x, "layernorm.input")
+        cols = x.shape[-1]
+        x2 = x.reshape(-1, cols)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        need_grad = any(ctx.needs_input_grad)
+        y, mean, rstd = layernorm_fwd(x2, gamma, beta, eps, need_grad)
+        ctx.has_affine = gamma is not None
+        ctx.has_beta = beta is not None
+        ctx.x_shape = x.shape
+        if need_grad:
+            ctx.save_for_backward(x2, gamma, mean, rstd)
+        return x.view_as(x), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        if dy is None:          # the normalised branch was not used
+            return dres, None, None, None
+        dy2 = _req(dy, "layernorm.grad_output").reshape(x2.shape)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dres2 = None
+        if dres is not None:
+            dres2 = _req(dres, "layernorm.grad_residual").reshape(x2.shape)
+            if not dres2.is_contiguous():
+                dres2 = dres2.contiguous()
+        need_p = ctx.has_affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p, dres2)
+        dgam = dbet = None
+        if need_p:
+            dgam = cast_to(dg, gamma.dtype)
+            if ctx.has_beta:
+                dbet = cast_to(db, gamma.dtype)
+        return dx.view(ctx.x_shape), dgam, dbet, None
+
+
+def layer_norm_fork(x, weight, bias, eps):
+    """-> (x as the residual operand, LayerNorm(x)); see _LayerNormFork.  Without autograd it is layer_norm."""
+    if not (torch.is_grad_enabled() and (x.requires_grad or (weight is not None and weight.requires_grad))):
+        return x, _LayerNorm.apply(x, weight, bias, float(eps))
+    return _LayerNormFork.apply(x, weight, bias, float(eps))
 
 
 class _SelfAttention(torch.autograd.Function):

@@ -90,6 +90,13 @@ int dvla_layernorm_fwd(const void* x, const void* gamma, const void* beta, int32
 int dvla_layernorm_bwd(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
                        const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                        float* partial, int64_t rows, int64_t cols, void* stream);
+/* same, plus the gradient of the residual stream that bypassed the LayerNorm (pre-LN blocks: h = x + f(LN(x)), so
+ * dL/dx = dL/dh + LN'(...)): dx = dres + LN-backward(dy), one bf16 rounding -- replaces the separate autograd
+ * accumulation add after every norm1 / norm2 / ln_1 / ln_2 backward (models/gpt2.py:312-339, timm Block).  dres may
+ * alias dx.  dres == NULL is dvla_layernorm_bwd. */
+int dvla_layernorm_bwd_add(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
+                           const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
+                           float* dbeta, float* partial, int64_t rows, int64_t cols, void* stream);
 int64_t dvla_layernorm_bwd_partial_rows(void);
 
 /* ---------------------------------------------------------------------------------------------------

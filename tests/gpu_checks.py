@@ -126,6 +126,34 @@ def check_layernorm(rows, cols, affine=True, eps=1e-5, param_f32=False, seed=0):
     return out
 
 
+def check_layernorm_fork(rows, cols, affine=True, eps=1e-5, seed=0):
+    """ops.layer_norm_fork: (x, LN(x)) whose backward is dvla_layernorm_bwd_add (dres + LN'(dy) in one kernel), against
+    the oracle's two-path autograd: loss = <x, dres> + <LN(x), dy>."""
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(199 + seed)
+    x = R.bf16_round(rnd((rows, cols), g, 2.0) + 0.5)
+    w = R.bf16_round(rnd((cols,), g) + 1.0) if affine else None
+    b = R.bf16_round(rnd((cols,), g)) if affine else None
+    dy, dres = rnd((rows, cols), g), rnd((rows, cols), g)
+    xd = x.to(DEV, BF).requires_grad_(True)
+    wd = w.to(DEV, BF).requires_grad_(True) if affine else None
+    bd = b.to(DEV, BF).requires_grad_(True) if affine else None
+    r, y = ops.layer_norm_fork(xd, wd, bd, eps)
+    torch.autograd.backward([r, y], [dres.to(DEV, BF), dy.to(DEV, BF)])
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True) if affine else None
+    br = b.clone().requires_grad_(True) if affine else None
+    yr = R.layer_norm(xr, wr, br, eps)
+    torch.autograd.backward([xr * 1.0, yr], [dres, dy])
+    tag = f"layernorm_fork {rows}x{cols} affine{int(affine)}"
+    out = [metrics(tag + " residual is x", r, x, 0.0), metrics(tag + " y", y, yr, TOL_FWD),
+           metrics(tag + " dx", xd.grad, xr.grad, TOL_GRAD)]
+    if affine:
+        out.append(metrics(tag + " dgamma", wd.grad, wr.grad, TOL_GRAD))
+        out.append(metrics(tag + " dbeta", bd.grad, br.grad, TOL_GRAD))
+    return out
+
+
 def make_block_mask(L, blk, nA):
     """small analogue of generate_attention_mask (dreamvla_model.py:25-66): block-causal over `blk`-token steps,
     the last blk-nA tokens of every step are never keys."""
@@ -349,6 +377,8 @@ def all_checks(quick=False):
         (check_layernorm, dict(rows=64, cols=512)),
         (check_layernorm, dict(rows=33, cols=768, affine=False, eps=1e-6)),
         (check_layernorm, dict(rows=9, cols=2048)),
+        (check_layernorm_fork, dict(rows=1000, cols=1024)),
+        (check_layernorm_fork, dict(rows=77, cols=768, affine=False, eps=1e-6)),
     ]
     L += [
         (check_self_attention, dict(B=2, H=2, L=32)),
