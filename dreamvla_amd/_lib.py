@@ -68,11 +68,12 @@ SYMBOLS = {
     "dvla_gemm_library_bf16": (C.c_int, [C.POINTER(GemmParams), _P, _I64, _P]),
     "dvla_layernorm_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I64, _I64, _F, _P]),
     "dvla_layernorm_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
-    "dvla_layernorm_bwd_add": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "dvla_layernorm_bwd_add": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
     "dvla_layernorm_bwd_partial_rows": (_I64, []),
     "dvla_attn_fwd": (C.c_int, [C.POINTER(AttnParams), _P]),
     "dvla_attn_bwd": (C.c_int, [C.POINTER(AttnParams), _P]),
     "dvla_colsum": (C.c_int, [_P, _I64, _I64, _I64, _P, _P, _P]),
+    "dvla_colsum_dt": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P, _P]),
     "dvla_colsum_partial_rows": (_I64, []),
     "dvla_dropout": (C.c_int, [_P, _P, _I64, _I64, _F, _U32, _U32, _P]),
     "dvla_act_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _F, _U32, _U32, _P]),

@@ -93,9 +93,10 @@ class DiTBlock(nn.Module):
         self.mlp = Mlp(in_features=hidden_size, hidden_features=int(hidden_size * mlp_ratio), act="gelu_tanh")
 
     def forward(self, x):
-        x = self.attn(self.norm1(x), residual=x)
-        x = self.mlp(self.norm2(x), residual=x)
-        return x
+        r, n = self.norm1.fork(x)          # (x, LN(x)): one backward kernel for dL/dx of both paths (ops._LayerNormFork)
+        x = self.attn(n, residual=r)
+        r, n = self.norm2.fork(x)
+        return self.mlp(n, residual=r)
 
 
 class FinalLayer(nn.Module):

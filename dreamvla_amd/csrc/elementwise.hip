@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
 
 // stage 2 (also used for the LayerNorm parameter gradients): out[c] = sum_k partial[k*stride + c]; block = 64 columns x 4
 // interleaved slab subsets, combined through LDS (fixed order -> deterministic).
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab,
-                                                            int64_t cols, int64_t stride) {
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, void* __restrict__ out, int out_bf16,
+                                                            int nslab, int64_t cols, int64_t stride) {
   // 16 columns x 16 row-parts per workgroup: a thread adds nslab / 16 partial rows, then a 16-way LDS reduction
   __shared__ float red[16][16];
   const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
     float tot = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) tot += red[q][cl];
-    out[c] = tot;
+    if (out_bf16) reinterpret_cast<bf16_t*>(out)[c] = f2bf(tot);   // the bias gradient in the parameter's dtype, no cast kernel
+    else reinterpret_cast<float*>(out)[c] = tot;
   }
 }
 
@@ -131,9 +132,17 @@ inline uint32_t thr_of(float p) {
 extern "C" int dvla_abi_version(void) { return 1; }
 extern "C" int64_t dvla_colsum_partial_rows(void) { return CS_BLOCKS; }
 
+extern "C" int dvla_colsum_dt(const void* x, int64_t ld, int64_t rows, int64_t cols, void* out, int32_t out_dtype,
+                              float* partial, void* stream_);
 extern "C" int dvla_colsum(const void* x, int64_t ld, int64_t rows, int64_t cols, float* out, float* partial, void* stream_) {
+  return dvla_colsum_dt(x, ld, rows, cols, out, DVLA_DT_F32, partial, stream_);
+}
+
+extern "C" int dvla_colsum_dt(const void* x, int64_t ld, int64_t rows, int64_t cols, void* out, int32_t out_dtype,
+                              float* partial, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!x || !out || !partial || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
+  if (out_dtype != DVLA_DT_F32 && out_dtype != DVLA_DT_BF16) return DVLA_ERR_ARG;
   const int64_t colblocks = (cols + 511) / 512;
   int64_t nslab = rows / 16;
   if (nslab > CS_BLOCKS) nslab = CS_BLOCKS;
@@ -144,7 +153,7 @@ extern "C" int dvla_colsum(const void* x, int64_t ld, int64_t rows, int64_t cols
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, stream, partial, out,
-                     (int)nslab, cols, cols);
+                     out_dtype == DVLA_DT_BF16 ? 1 : 0, (int)nslab, cols, cols);
   return dvla_check_launch();
 }
 

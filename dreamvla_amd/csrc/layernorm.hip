@@ -198,8 +198,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
 
 // out[c] = sum over blocks of partial[b][which][c]; 16 columns x 16 interleaved block subsets per workgroup
 // (deterministic; a thread adds nblocks / 16 partial rows with 4 loads in flight, then a 16-way LDS reduction)
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int nblocks, int cols) {
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, void* __restrict__ dgamma,
+                                                            void* __restrict__ dbeta, int grad_bf16, int nblocks, int cols) {
   __shared__ float red[2][16][16];
   const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -217,8 +217,13 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     float tg = 0.f, tb = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { tg += red[0][q][cl]; tb += red[1][q][cl]; }
-    if (dgamma) dgamma[c] = tg;
-    if (dbeta) dbeta[c] = tb;
+    if (grad_bf16) {   // parameter gradients in the parameters' dtype: no cast kernels behind this one
+      if (dgamma) reinterpret_cast<bf16_t*>(dgamma)[c] = f2bf(tg);
+      if (dbeta) reinterpret_cast<bf16_t*>(dbeta)[c] = f2bf(tb);
+    } else {
+      if (dgamma) reinterpret_cast<float*>(dgamma)[c] = tg;
+      if (dbeta) reinterpret_cast<float*>(dbeta)[c] = tb;
+    }
   }
 }
 
@@ -255,19 +260,23 @@ extern "C" int dvla_layernorm_fwd(const void* x, const void* gamma, const void* 
 }
 
 extern "C" int dvla_layernorm_bwd_add(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
-                                      const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
-                                      float* dbeta, float* partial, int64_t rows, int64_t cols, void* stream_);
+                                      const float* mean, const float* rstd, const void* dres, void* dx, void* dgamma,
+                                      void* dbeta, int32_t grad_dtype, float* partial, int64_t rows, int64_t cols,
+                                      void* stream_);
 
 extern "C" int dvla_layernorm_bwd(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                   float* partial, int64_t rows, int64_t cols, void* stream_) {
-  return dvla_layernorm_bwd_add(dy, x, gamma, param_dtype, mean, rstd, nullptr, dx, dgamma, dbeta, partial, rows, cols, stream_);
+  return dvla_layernorm_bwd_add(dy, x, gamma, param_dtype, mean, rstd, nullptr, dx, dgamma, dbeta, DVLA_DT_F32, partial, rows,
+                                cols, stream_);
 }
 
 extern "C" int dvla_layernorm_bwd_add(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
-                                      const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
-                                      float* dbeta, float* partial, int64_t rows, int64_t cols, void* stream_) {
+                                      const float* mean, const float* rstd, const void* dres, void* dx, void* dgamma,
+                                      void* dbeta, int32_t grad_dtype, float* partial, int64_t rows, int64_t cols,
+                                      void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (grad_dtype != DVLA_DT_F32 && grad_dtype != DVLA_DT_BF16) return DVLA_ERR_ARG;
   const bf16_t* drp = reinterpret_cast<const bf16_t*>(dres);
   if ((reinterpret_cast<uintptr_t>(dres) & 15) != 0) return DVLA_ERR_UNSUPPORTED;
   if (!dy || !x || !mean || !rstd || !dx || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
@@ -294,7 +303,7 @@ extern "C" int dvla_layernorm_bwd_add(const void* dy, const void* x, const void*
   if (rc != DVLA_OK) return rc;
   if (part) {
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, stream, part, dgamma,
-                       dbeta, (int)nb, (int)cols);
+                       dbeta, grad_dtype == DVLA_DT_BF16 ? 1 : 0, (int)nb, (int)cols);
     rc = dvla_check_launch();
   }
   return rc;

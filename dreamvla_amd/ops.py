@@ -108,7 +108,7 @@ class GemmProfiler:
             a = agg.setdefault(sh, [0, 0.0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
         rows = [{"M": k[0], "N": k[1], "K": k[2], "a_trans": k[3], "b_trans": k[4], "split_k": k[5], "kernel": k[6],
-                 "launches": v[0], "ms": v[1], "tflops": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for k, v in agg.items()]
+                 "variant": k[7], "epilogue": k[8], "launches": v[0], "ms": v[1], "tflops": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for k, v in agg.items()]
         return sorted(rows, key=lambda r: -r["ms"])
 
     def __enter__(self):
@@ -327,7 +327,8 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
         trial["pending"].append((variant, e0, e1))
     if prof is not None:
         prof.records.append((e0, e1, 2.0 * M * N * K))
-        prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k), "library" if ran_library else "hip"))
+        prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k), "library" if ran_library else "hip",
+                            int(variant), "plain" if plain else "fused"))
     return (out, preact) if want_preact else out
 
 
@@ -347,30 +348,35 @@ def layernorm_fwd(x2, gamma, beta, eps, want_stats):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads, dres2=None):
-    """dres2: gradient of the residual stream that bypassed the LayerNorm; added to dx inside the kernel"""
+def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads, dres2=None, grad_dtype=torch.float32):
+    """dres2: gradient of the residual stream that bypassed the LayerNorm; added to dx inside the kernel.
+    dgamma / dbeta come back in grad_dtype (bf16 or fp32) straight from the reduction kernel."""
     lib = _lib.load()
     rows, cols = x2.shape
     dx = torch.empty_like(x2)
     dg = db = part = None
     if need_param_grads:
-        dg = torch.empty(cols, dtype=torch.float32, device=x2.device)
-        db = torch.empty(cols, dtype=torch.float32, device=x2.device)
+        dg = torch.empty(cols, dtype=grad_dtype, device=x2.device)
+        db = torch.empty(cols, dtype=grad_dtype, device=x2.device)
         part = torch.empty(2 * lib.dvla_layernorm_bwd_partial_rows() * cols, dtype=torch.float32, device=x2.device)
     pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
+    gdt = DT_F32 if grad_dtype == torch.float32 else DT_BF16
     check(lib.dvla_layernorm_bwd_add(dy2.data_ptr(), x2.data_ptr(), _ptr(gamma), pdt, mean.data_ptr(), rstd.data_ptr(),
-                                     _ptr(dres2), dx.data_ptr(), _ptr(dg), _ptr(db), _ptr(part), rows, cols, _stream()),
+                                     _ptr(dres2), dx.data_ptr(), _ptr(dg), _ptr(db), gdt, _ptr(part), rows, cols, _stream()),
           "dvla_layernorm_bwd_add")
     return dx, dg, db
 
 
-def colsum(x2):
+def colsum(x2, out_dtype=torch.float32):
+    """column sums (bias gradients), written in out_dtype (fp32 or bf16) by the reduction kernel itself"""
     lib = _lib.load()
     rows, cols = x2.shape
-    out = torch.empty(cols, dtype=torch.float32, device=x2.device)
+    if out_dtype not in (torch.float32, BF16):
+        raise TypeError(f"colsum: fp32 or bf16 output, got {out_dtype}")
+    out = torch.empty(cols, dtype=out_dtype, device=x2.device)
     part = torch.empty(lib.dvla_colsum_partial_rows() * cols, dtype=torch.float32, device=x2.device)
-    check(lib.dvla_colsum(x2.data_ptr(), x2.stride(0), rows, cols, out.data_ptr(), part.data_ptr(), _stream()),
-          "dvla_colsum")
+    check(lib.dvla_colsum_dt(x2.data_ptr(), x2.stride(0), rows, cols, out.data_ptr(),
+                             DT_F32 if out_dtype == torch.float32 else DT_BF16, part.data_ptr(), _stream()), "dvla_colsum_dt")
     return out
 
 
@@ -602,7 +608,7 @@ class _Linear(torch.autograd.Function):
             else:        # dW[n,k] = sum_m dz[m,n] x[m,k]
                 dw = gemm(dz, x2, a_trans=True, b_trans=True, split_k=auto_split_k(N, K, M))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = cast_to(colsum(dz), ctx.bias_dtype)
+            db = colsum(dz, ctx.bias_dtype)
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None, None
@@ -659,14 +665,14 @@ class _Mlp(torch.autograd.Function):
             dw2 = (gemm(h, dz, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, N, M)) if conv1d else
                    gemm(dz, h, a_trans=True, b_trans=True, split_k=auto_split_k(N, Hd, M)))
         if ctx.has_b2 and ctx.needs_input_grad[4]:
-            db2 = cast_to(colsum(dz), ctx.b2_dtype)
+            db2 = colsum(dz, ctx.b2_dtype)
         if ctx.needs_input_grad[0]:
             dx = gemm(du, w1, b_trans=not conv1d).view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
             dw1 = (gemm(x2, du, a_trans=True, b_trans=True, split_k=auto_split_k(K, Hd, M)) if conv1d else
                    gemm(du, x2, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, K, M)))
         if ctx.has_b1 and ctx.needs_input_grad[2]:
-            db1 = cast_to(colsum(du), ctx.b1_dtype)
+            db1 = colsum(du, ctx.b1_dtype)
         if ctx.has_res and ctx.needs_input_grad[5]:
             dres = dy
         return dx, dw1, db1, dw2, db2, dres, None, None, None
@@ -701,13 +707,8 @@ class _LayerNorm(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         need_p = ctx.has_affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p)
-        dgam = dbet = None
-        if need_p:
-            dgam = cast_to(dg, gamma.dtype)
-            if ctx.has_beta:
-                dbet = cast_to(db, gamma.dtype)
-        return dx.view(ctx.x_shape), dgam, dbet, None
+        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p, None, gamma.dtype if need_p else torch.float32)
+        return dx.view(ctx.x_shape), dg, (db if ctx.has_beta else None), None
 
 
 def layer_norm(x, weight, bias, eps):
@@ -749,13 +750,8 @@ class _LayerNormFork(torch.autograd.Function):
             if not dres2.is_contiguous():
                 dres2 = dres2.contiguous()
         need_p = ctx.has_affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p, dres2)
-        dgam = dbet = None
-        if need_p:
-            dgam = cast_to(dg, gamma.dtype)
-            if ctx.has_beta:
-                dbet = cast_to(db, gamma.dtype)
-        return dx.view(ctx.x_shape), dgam, dbet, None
+        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p, dres2, gamma.dtype if need_p else torch.float32)
+        return dx.view(ctx.x_shape), dg, (db if ctx.has_beta else None), None
 
 
 def layer_norm_fork(x, weight, bias, eps):

@@ -92,11 +92,12 @@ int dvla_layernorm_bwd(const void* dy, const void* x, const void* gamma, int32_t
                        float* partial, int64_t rows, int64_t cols, void* stream);
 /* same, plus the gradient of the residual stream that bypassed the LayerNorm (pre-LN blocks: h = x + f(LN(x)), so
  * dL/dx = dL/dh + LN'(...)): dx = dres + LN-backward(dy), one bf16 rounding -- replaces the separate autograd
- * accumulation add after every norm1 / norm2 / ln_1 / ln_2 backward (models/gpt2.py:312-339, timm Block).  dres may
- * alias dx.  dres == NULL is dvla_layernorm_bwd. */
+ * accumulation add after every norm1 / norm2 / ln_1 / ln_2 backward (models/gpt2.py:312-339, timm Block).  dres must
+ * not overlap dx; dres == NULL gives plain LayerNorm backward.  dgamma / dbeta are written in `grad_dtype` (0 = bf16:
+ * the parameters' dtype, no cast kernel afterwards; 1 = fp32). */
 int dvla_layernorm_bwd_add(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
-                           const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
-                           float* dbeta, float* partial, int64_t rows, int64_t cols, void* stream);
+                           const float* mean, const float* rstd, const void* dres, void* dx, void* dgamma,
+                           void* dbeta, int32_t grad_dtype, float* partial, int64_t rows, int64_t cols, void* stream);
 int64_t dvla_layernorm_bwd_partial_rows(void);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -151,6 +152,9 @@ int dvla_attn_bwd(const dvla_attn_params* p, void* stream);
 /* out[n] = sum_m x[m,n]  (bias gradients).  out fp32; `partial` = fp32 workspace of
  * dvla_colsum_partial_rows() * cols floats. */
 int dvla_colsum(const void* x, int64_t ld, int64_t rows, int64_t cols, float* out, float* partial, void* stream);
+/* same with `out` written in out_dtype (0 = bf16: the bias gradient in the parameter's dtype, no cast kernel; 1 = fp32) */
+int dvla_colsum_dt(const void* x, int64_t ld, int64_t rows, int64_t cols, void* out, int32_t out_dtype, float* partial,
+                   void* stream);
 int64_t dvla_colsum_partial_rows(void);
 /* y = dropout(x) * 1/(1-p) with the stateless hash RNG; rows x cols, row stride = cols.
  * GPT2Model.drop (models/gpt2.py:459) and its backward (same call on the gradient). */
