@@ -129,6 +129,7 @@ class DreamVLA(nn.Module):
         assert self.phase in ["pretrain", "finetune", "evaluate"]
         self.share_query = share_query
         self.gripper_width = gripper_width
+        self.share_text_over_time = True   # encode_frames: run the text tower once per sample when its S token rows are equal
         self.vit_checkpoint_path = vit_checkpoint_path
         self.pred_num = pred_num
         H = self.hidden_dim
@@ -373,9 +374,18 @@ class DreamVLA(nn.Module):
         wdt = self.text_projector.weight.dtype
 
         # text: frozen CLIP text tower -> Linear(512, H)                                  (643-653)
-        with torch.no_grad():
-            text_feature = self.clip_model.encode_text(text_token.flatten(0, 1))
-        text_embedding = self.text_projector(text_feature.to(wdt)).view(B, S, -1, H)
+        # The training loop feeds the SAME instruction to every frame of a window (`text_tokens.unsqueeze(1).repeat(1,
+        # window_size, 1)`, utils/train_utils.py:124): when all S rows of a sample are equal (checked on the device, one
+        # scalar read-back per forward) the 12-layer tower runs on B sequences instead of B*S and the result is broadcast.
+        if (S > 1 and self.share_text_over_time and text_token.is_cuda and not torch.cuda.is_current_stream_capturing()
+                and bool((text_token == text_token[:, :1]).all())):
+            with torch.no_grad():
+                text_feature = self.clip_model.encode_text(text_token[:, 0].contiguous())
+            text_embedding = self.text_projector(text_feature.to(wdt)).view(B, 1, -1, H).expand(B, S, -1, H)
+        else:
+            with torch.no_grad():
+                text_feature = self.clip_model.encode_text(text_token.flatten(0, 1))
+            text_embedding = self.text_projector(text_feature.to(wdt)).view(B, S, -1, H)
 
         # state: arm Linear(6,H) | gripper one-hot(2) -> Linear(2,H) -> cat -> Linear(2H,H)   (656-664)
         st = state.flatten(0, 1).to(wdt)

@@ -190,6 +190,33 @@ def hip_full_model_checks(name):
     return res
 
 
+def hip_text_sharing_checks():
+    """encode_frames with the text tower run once per sample (equal token rows over time) vs on every frame."""
+    fx = load("dreamvla_A.pt")
+    m = build_hip_model(fx["cfg"]).to(BF).to("cuda")
+    m._init_model_type()
+    m.eval()
+    inp = {k: v.to("cuda") for k, v in golden_inputs(fx).items()}
+    args = (inp["image_primary"].to(BF), inp["image_wrist"].to(BF), inp["state"].to(BF), inp["text_token"])
+    res = []
+    with torch.no_grad():
+        m.share_text_over_time = True
+        shared = m.encode_frames(*args)[0]
+        m.share_text_over_time = False
+        per_frame = m.encode_frames(*args)[0]
+        r = rel_l2(shared, per_frame)
+        res.append({"name": "text tower shared over time == per frame", "rel_l2": r, "tol": 2e-3, "ok": r <= 2e-3})
+        tt = inp["text_token"].clone()
+        tt[:, 1, 3] = (tt[:, 1, 3] + 1) % 49000          # rows differ -> the shared path must NOT be taken
+        m.share_text_over_time = True
+        a = m.encode_frames(args[0], args[1], args[2], tt)[0]
+        m.share_text_over_time = False
+        b = m.encode_frames(args[0], args[1], args[2], tt)[0]
+        r = rel_l2(a, b)
+        res.append({"name": "unequal token rows fall back to per-frame encoding", "rel_l2": r, "tol": 0.0, "ok": r == 0.0})
+    return res
+
+
 def hip_grad_checks():
     """whole-model backward on config A (dream heads + MLP action head) vs oracle autograd in fp32: per-parameter
     gradient cosine similarity for the trainable tensors that receive gradient."""

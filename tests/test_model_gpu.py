@@ -22,6 +22,11 @@ def test_hip_full_model_vs_golden(name):
 
 
 @pytest.mark.gpu
+def test_text_tower_shared_over_time():
+    _assert_all(C.hip_text_sharing_checks())
+
+
+@pytest.mark.gpu
 def test_hip_whole_model_gradients_vs_oracle():
     _assert_all(C.hip_grad_checks())
 
