@@ -350,9 +350,11 @@ class DreamVLA(nn.Module):
         Hd = self.hidden_dim
         emb = projector(feat.reshape(-1, feat.shape[-1])).view(n2, n_q, Hd)
         pos = pos.to(emb.dtype)
-        base_mask = (mask_token.to(emb.dtype) + pos[:, n_q:]).expand(n2, -1, -1)
-        x = torch.cat((emb + pos[:, :n_q], base_mask), dim=1)
-        x = decoder(x)
+        # the n_mask trailing tokens (mask_token + position) are the same in every sequence: the first decoder block
+        # computes their LayerNorm / qkv projection once (nn.Block.forward_shared_suffix)
+        x = decoder[0].forward_shared_suffix(emb + pos[:, :n_q], (mask_token.to(emb.dtype) + pos[:, n_q:])[0], n2)
+        for blk in list(decoder)[1:]:
+            x = blk(x)
         x = norm(x[:, -n_mask:, :].reshape(-1, Hd))
         return pred(x, act=act)
 

@@ -100,6 +100,22 @@ class Block(nn.Module):
         x = self.mlp(self.norm2(x), residual=x)
         return x
 
+    def forward_shared_suffix(self, prefix, suffix, n_seq):
+        """This block on a batch of sequences [prefix_b ; suffix] whose trailing tokens are IDENTICAL in every sequence --
+        the dream-head decoders feed 9 per-sample query tokens followed by 196 / 256 copies of `mask_token + position`
+        (models/dreamvla_model.py:800-809).  norm1 and the qkv projection are row-wise, so for the shared rows they are
+        computed ONCE (n_suffix rows instead of n_seq * n_suffix: 96 % of this block's qkv GEMM, its input-gradient GEMM and
+        its weight-gradient contraction) and broadcast into the per-sequence qkv buffer; from the attention on everything
+        is per sequence.  Same function values as forward(cat(prefix, suffix.expand)); autograd sums the shared rows'
+        gradient over the batch before the (tiny) backward GEMMs.   prefix (n_seq, n_q, D), suffix (n_suffix, D)."""
+        x = torch.cat((prefix, suffix.unsqueeze(0).expand(n_seq, -1, -1)), dim=1)
+        qkv = torch.cat((self.attn.qkv(self.norm1(prefix)),
+                         self.attn.qkv(self.norm1(suffix)).unsqueeze(0).expand(n_seq, -1, -1)), dim=1)
+        o = ops.self_attention(qkv, self.attn.num_heads, scale=self.attn.scale)
+        x = self.attn.proj(o, residual=x)
+        r, n = self.norm2.fork(x)
+        return self.mlp(n, residual=r)
+
 
 class PatchEmbed(nn.Module):
     """timm PatchEmbed: Conv2d(in_chans, embed_dim, k = s = patch) -> flatten(2).transpose(1,2).
