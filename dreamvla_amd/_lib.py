@@ -59,6 +59,10 @@ class AttnParams(C.Structure):
     ]
 
 
+class FrameView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("stride_b", C.c_int64), ("stride_t", C.c_int64), ("T", C.c_int32)]
+
+
 # every symbol include/dvla.h declares: (name, restype, argtypes)
 _P, _I64, _I32, _F, _U32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint32
 SYMBOLS = {
@@ -81,6 +85,13 @@ SYMBOLS = {
     "dvla_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_cast_bf16_to_f32": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
+    "dvla_loss_partial_len": (C.c_int64, []),
+    "dvla_patch_mse_fwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _P, _I64, _P, _P, _P]),
+    "dvla_patch_mse_bwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _P, _I64, _P, C.POINTER(FrameView), _P]),
+    "dvla_cosine_loss_fwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _I32, _I32, _I64, _P, _P, _P]),
+    "dvla_cosine_loss_bwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _I32, _I32, _I64, _P, C.POINTER(FrameView), _P]),
+    "dvla_silog_loss_fwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _I64, _F, _P, _P, _P]),
+    "dvla_silog_loss_bwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _I64, _F, _P, _P, C.POINTER(FrameView), _P]),
     "dvla_sumsq_partial_len": (C.c_int64, []),
     "dvla_sumsq_bf16": (C.c_int, [_P, _I64, _P, _P, C.c_int32, _P]),
     "dvla_adamw_bf16": (C.c_int, [_P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P,

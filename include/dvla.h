@@ -185,6 +185,33 @@ int dvla_adamw_bf16(void* param, const void* grad, void* exp_avg, void* exp_avg_
                     float beta2, float eps, float weight_decay, int64_t step, const float* grad_sumsq, float max_norm,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Training-loss reductions (the caller-side loss block of the reference, utils/train_utils.py:172-450 + utils/sigloss.py:
+ * patchify -> per-patch normalise -> (flow mask) -> MSE; 1 - cosine_similarity; SiLog on un-patchified depth).  bf16 data,
+ * fp32 arithmetic, deterministic two-stage sums.  Tensors are addressed per FRAME through a view so the caller's slices
+ * (prediction[:, view, 0], label[:, future : future + T]) are read in place: frame f lives at
+ *   base + (f / T) * stride_b + (f % T) * stride_t          (element strides; the inner block of a frame is contiguous).
+ * fwd: out2[0] = loss (fp32 scalar), out2[1] = auxiliary (SiLog: mean d, needed by bwd); `partial` = fp32 workspace of
+ *      dvla_loss_partial_len() floats.   bwd: dpred (bf16, same addressing as pred) = grad_out[0] * dLoss/dpred.
+ */
+typedef struct dvla_frame_view { const void* base; int64_t stride_b; int64_t stride_t; int32_t T; } dvla_frame_view;
+int64_t dvla_loss_partial_len(void);
+/* pred frames (196, 768); image frames (3, 224, 224); patch_mask NULL or fp32 (n_frames, 196) of {0,1} */
+int dvla_patch_mse_fwd(const dvla_frame_view* pred, const dvla_frame_view* image, const float* patch_mask, int64_t n_frames,
+                       float* out2, float* partial, void* stream);
+int dvla_patch_mse_bwd(const dvla_frame_view* pred, const dvla_frame_view* image, const float* patch_mask, int64_t n_frames,
+                       const float* grad_out, const dvla_frame_view* dpred, void* stream);
+/* pred / label frames (rows_per_frame, cols); cols % 64 == 0, cols <= 1024 */
+int dvla_cosine_loss_fwd(const dvla_frame_view* pred, const dvla_frame_view* label, int32_t rows_per_frame, int32_t cols,
+                         int64_t n_frames, float* out2, float* partial, void* stream);
+int dvla_cosine_loss_bwd(const dvla_frame_view* pred, const dvla_frame_view* label, int32_t rows_per_frame, int32_t cols,
+                         int64_t n_frames, const float* grad_out, const dvla_frame_view* dpred, void* stream);
+/* pred frames (196, 256) = 16x16 depth patches; depth frames (1, 224, 224) */
+int dvla_silog_loss_fwd(const dvla_frame_view* pred, const dvla_frame_view* depth, int64_t n_frames, float lambd, float* out2,
+                        float* partial, void* stream);
+int dvla_silog_loss_bwd(const dvla_frame_view* pred, const dvla_frame_view* depth, int64_t n_frames, float lambd, const float* out2,
+                        const float* grad_out, const dvla_frame_view* dpred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -370,6 +370,7 @@ def all_checks(quick=False):
         (check_gemm, dict(M=2048, N=1024, K=96, b_trans=True, variant=8)),
     ]
     L += [(check_flat_adamw, dict())]
+    L += [(check_fused_losses, dict(case_name=c)) for c in ("C_calvin_dit", "E_libero_all_heads", "E_atten_goal")]
     L += [
         (check_layernorm, dict(rows=37, cols=768, eps=1e-6)),
         (check_layernorm, dict(rows=1000, cols=1024)),
@@ -404,6 +405,42 @@ def all_checks(quick=False):
         (check_misc, dict()),
     ]
     return L
+
+
+def check_fused_losses(case_name):
+    """the HIP loss kernels (dvla_patch_mse_* / dvla_cosine_loss_* / dvla_silog_loss_*) against the ATen formulation of
+    dreamvla_amd/losses.py -- which is pinned to the real training loop (tests/test_losses_golden.py) -- on the same
+    bf16 inputs: loss terms (fp32 sums in another order: 2e-5 rel) and the bf16 prediction gradients."""
+    from dreamvla_amd import losses
+    from oracle.make_golden_losses import CASES, loss_case_tensors
+    case = CASES[case_name]
+    batch, preds = loss_case_tensors(case)
+    batch["actions"][..., 6:] = (batch["actions"][..., 6:] + 1) // 2
+    S, ag = case["S"], case.get("atten_goal", 0)
+    dev_batch = {k: (v.to(DEV, BF) if torch.is_floating_point(v) else v.to(DEV)) for k, v in batch.items()}
+    lab = losses.label_actions(dev_batch["actions"], S, 3, atten_goal=ag)
+    out, results = [], {}
+    for fused in (True, False):
+        leaves = {k: v.to(DEV, BF).clone().requires_grad_(True) for k, v in preds.items()}
+        if case["use_dit_head"]:
+            leaves["arm"] = preds["arm"].to(DEV).float().requires_grad_(True)
+        g = leaves.get
+        o = (leaves["arm"], g("gripper", leaves["arm"]), g("image"), None, None, None, g("depth"), g("traj"), g("dino"), g("sam"))
+        total, parts = losses.calvin_losses(o, dev_batch, sequence_length=S, atten_goal=ag, use_dit_head=case["use_dit_head"],
+                                            label_action=lab, flow_as_mask=case["flow_as_mask"], fused=None if fused else False)
+        total.backward()
+        results[fused] = (total.detach(), {k: v.detach() for k, v in parts.items()},
+                          {k: v.grad.detach().float() for k, v in leaves.items() if v.grad is not None})
+    tf, pf, gf = results[True]
+    ta, pa, ga = results[False]
+    tag = f"fused losses {case_name}"
+    out.append(metrics(tag + " total", tf.reshape(1), ta.reshape(1).cpu(), 2e-5, round_ref=False))
+    for k in ("image", "depth", "dino", "sam"):
+        out.append(metrics(f"{tag} {k}", pf[k].float().reshape(1), pa[k].float().reshape(1).cpu(), 2e-5, round_ref=False))
+    for k in ("image", "depth", "dino", "sam"):
+        if k in ga:
+            out.append(metrics(f"{tag} d{k}", gf[k], ga[k].cpu(), TOL_GRAD, round_ref=False))
+    return out
 
 
 def check_flat_adamw(seed=0):
