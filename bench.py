@@ -153,7 +153,7 @@ def main():
         ddp_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True,
                                                               gradient_as_bucket_view=True)
     else:
-        reducer = GradBucketReducer(params)
+        reducer = GradBucketReducer(params, direct_grads=True)   # backward kernels write gradients into the bucket slots
     flat_opt = None
     if reducer is not None and not args.torch_adamw:
         from dreamvla_amd.optim import FlatAdamW

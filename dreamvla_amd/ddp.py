@@ -18,17 +18,23 @@ are constructed but never used.  This reducer is built for the MI355X node inste
     find_unused_parameters=True).  If the used set ever grows, the bucket is held until `finish()` for that step and the
     set is re-learned; a gradient arriving after its bucket was launched raises (pass static_unused=False to always
     flush such buckets at `finish()`);
-  * `finish()` waits for the handles and averages (divide by world size), exactly DDP's semantics.
+  * `finish()` waits for the handles and averages (divide by world size), exactly DDP's semantics;
+  * `direct_grads=True`: `zero_grad()` leaves `p.grad = None` and publishes each parameter's bucket slot as
+    `p._dvla_grad_view`; the backward of dreamvla_amd.ops (weight-gradient GEMMs, bias column sums, LayerNorm parameter
+    gradients) writes its result straight into that slot and returns it, autograd's AccumulateGrad then adopts the tensor
+    (no `grad += new` kernel per parameter -- ~400 launches per step on DreamVLA), and the hook below copies only the
+    gradients that some other operator produced elsewhere (learned tokens, position embeddings).
 """
 import torch
 import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, params, bucket_bytes=256 << 20, process_group=None, static_unused=True):
+    def __init__(self, params, bucket_bytes=256 << 20, process_group=None, static_unused=True, direct_grads=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.static_unused = bool(static_unused)
+        self.direct_grads = bool(direct_grads)
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []       # dicts: flat, params, pending
         order = list(reversed(self.params))
@@ -59,7 +65,10 @@ class GradBucketReducer:
             off += -(-p.numel() // self.ALIGN) * self.ALIGN
         flat = torch.zeros(off, dtype=plist[0].dtype, device=plist[0].device)
         for p, o in zip(plist, offsets):
-            p.grad = flat[o:o + p.numel()].view_as(p)
+            view = flat[o:o + p.numel()].view_as(p)
+            p._dvla_grad_view = view
+            p._dvla_grad_free = False
+            p.grad = None if self.direct_grads else view
         self.buckets.append({"flat": flat, "params": plist, "offsets": offsets, "pending": len(plist), "launched": False,
                              "fired": [False] * len(plist),      # this step
                              "expected": [True] * len(plist),    # parameters the launch waits for (learned)
@@ -71,6 +80,12 @@ class GradBucketReducer:
             if b["fired"][pi]:
                 return
             b["fired"][pi] = True
+            if self.direct_grads:       # adopt gradients that were not produced in place
+                view = param._dvla_grad_view
+                g = param.grad
+                if g is not None and g.data_ptr() != view.data_ptr():
+                    view.copy_(g)
+                    param.grad = view
             if not b["expected"][pi]:
                 if b["launched"]:
                     raise RuntimeError("GradBucketReducer: a parameter that received no gradient in earlier steps received one "
@@ -95,6 +110,10 @@ class GradBucketReducer:
             b["launched"] = False
             b["hold"] = False
             b["fired"] = [False] * len(b["params"])
+            if self.direct_grads:
+                for p in b["params"]:
+                    p.grad = None
+                    p._dvla_grad_free = True       # dreamvla_amd.ops may write this step's gradient into the slot once
         self._handles = []
 
     def finish(self):
@@ -115,9 +134,16 @@ class GradBucketReducer:
                 b["flat"].div_(self.world)
 
     def grads_are_views(self):
+        """every gradient lives in its bucket (direct_grads: every gradient that exists)"""
         ok = True
         for b in self.buckets:
             base = b["flat"].untyped_storage().data_ptr()
             for p in b["params"]:
+                if self.direct_grads and p.grad is None:
+                    continue
                 ok &= p.grad is not None and p.grad.untyped_storage().data_ptr() == base
         return ok
+
+    def grad_of(self, p):
+        """this step's (reduced) gradient of a parameter as a view of its bucket, also when p.grad is None"""
+        return p._dvla_grad_view

@@ -348,7 +348,8 @@ def layernorm_fwd(x2, gamma, beta, eps, want_stats):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads, dres2=None, grad_dtype=torch.float32):
+def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads, dres2=None, grad_dtype=torch.float32, dg_out=None,
+                  db_out=None):
     """dres2: gradient of the residual stream that bypassed the LayerNorm; added to dx inside the kernel.
     dgamma / dbeta come back in grad_dtype (bf16 or fp32) straight from the reduction kernel."""
     lib = _lib.load()
@@ -356,8 +357,8 @@ def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads, dres2=None, grad
     dx = torch.empty_like(x2)
     dg = db = part = None
     if need_param_grads:
-        dg = torch.empty(cols, dtype=grad_dtype, device=x2.device)
-        db = torch.empty(cols, dtype=grad_dtype, device=x2.device)
+        dg = dg_out if dg_out is not None else torch.empty(cols, dtype=grad_dtype, device=x2.device)
+        db = db_out if db_out is not None else torch.empty(cols, dtype=grad_dtype, device=x2.device)
         part = torch.empty(2 * lib.dvla_layernorm_bwd_partial_rows() * cols, dtype=torch.float32, device=x2.device)
     pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
     gdt = DT_F32 if grad_dtype == torch.float32 else DT_BF16
@@ -367,13 +368,16 @@ def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads, dres2=None, grad
     return dx, dg, db
 
 
-def colsum(x2, out_dtype=torch.float32):
+def colsum(x2, out_dtype=torch.float32, out=None):
     """column sums (bias gradients), written in out_dtype (fp32 or bf16) by the reduction kernel itself"""
     lib = _lib.load()
     rows, cols = x2.shape
     if out_dtype not in (torch.float32, BF16):
         raise TypeError(f"colsum: fp32 or bf16 output, got {out_dtype}")
-    out = torch.empty(cols, dtype=out_dtype, device=x2.device)
+    if out is None:
+        out = torch.empty(cols, dtype=out_dtype, device=x2.device)
+    elif out.dtype != out_dtype or out.numel() != cols or not out.is_contiguous():
+        raise ValueError("colsum: bad `out`")
     part = torch.empty(lib.dvla_colsum_partial_rows() * cols, dtype=torch.float32, device=x2.device)
     check(lib.dvla_colsum_dt(x2.data_ptr(), x2.stride(0), rows, cols, out.data_ptr(),
                              DT_F32 if out_dtype == torch.float32 else DT_BF16, part.data_ptr(), _stream()), "dvla_colsum_dt")
@@ -560,6 +564,19 @@ def attn_bwd_raw(q, k, v, o, lse, dout, dq, dk, dv, *, scale, mask_tables=None, 
 # ---------------------------------------------------------------------------------------------------
 # autograd Functions
 # ---------------------------------------------------------------------------------------------------
+def _grad_dest(param, dtype=None):
+    """The slot a gradient reducer published for this parameter's gradient (dreamvla_amd.ddp.GradBucketReducer with
+    direct_grads=True), if nothing has been written there in this step -- the backward kernels then produce the gradient
+    in place and AccumulateGrad adopts the returned tensor instead of adding it to a zeroed one.  None otherwise."""
+    if param is None or not getattr(param, "_dvla_grad_free", False) or param.grad is not None:
+        return None
+    view = param._dvla_grad_view
+    if dtype is not None and view.dtype != dtype:
+        return None
+    param._dvla_grad_free = False
+    return view
+
+
 class _Linear(torch.autograd.Function):
     """y = residual + dropout(act(x . W^T + b)).  conv1d=True: W is HF Conv1D (in, out) (models/gpt2.py:53)."""
 
@@ -583,12 +600,12 @@ class _Linear(torch.autograd.Function):
         ctx.x_shape = x.shape
         ctx.bias_dtype = b.dtype if b is not None else None
         if need_grad:
-            ctx.save_for_backward(x2, w, pre)
+            ctx.save_for_backward(x2, w, pre, b)
         return y2.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, pre = ctx.saved_tensors
+        x2, w, pre, b = ctx.saved_tensors
         conv1d = ctx.conv1d
         N = w.shape[1] if conv1d else w.shape[0]
         K = w.shape[0] if conv1d else w.shape[1]
@@ -603,12 +620,13 @@ class _Linear(torch.autograd.Function):
             # dx[m,k] = sum_n dz[m,n] W(n,k)
             dx = gemm(dz, w, b_trans=not conv1d).view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
+            dst = _grad_dest(w, BF16)      # the reducer's bucket slot, written in place (None: a fresh tensor)
             if conv1d:   # dW[k,n] = sum_m x[m,k] dz[m,n]
-                dw = gemm(x2, dz, a_trans=True, b_trans=True, split_k=auto_split_k(K, N, M))
+                dw = gemm(x2, dz, a_trans=True, b_trans=True, split_k=auto_split_k(K, N, M), out=dst)
             else:        # dW[n,k] = sum_m dz[m,n] x[m,k]
-                dw = gemm(dz, x2, a_trans=True, b_trans=True, split_k=auto_split_k(N, K, M))
+                dw = gemm(dz, x2, a_trans=True, b_trans=True, split_k=auto_split_k(N, K, M), out=dst)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dz, ctx.bias_dtype)
+            db = colsum(dz, ctx.bias_dtype, out=_grad_dest(b, ctx.bias_dtype))
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None, None
@@ -645,12 +663,12 @@ class _Mlp(torch.autograd.Function):
         ctx.b1_dtype = b1.dtype if b1 is not None else None
         ctx.b2_dtype = b2.dtype if b2 is not None else None
         if need_grad:
-            ctx.save_for_backward(x2, w1, w2, u, h)
+            ctx.save_for_backward(x2, w1, w2, u, h, b1, b2)
         return y2.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w1, w2, u, h = ctx.saved_tensors
+        x2, w1, w2, u, h, b1, b2 = ctx.saved_tensors
         conv1d = ctx.conv1d
         N = w2.shape[1] if conv1d else w2.shape[0]
         Hd = w1.shape[1] if conv1d else w1.shape[0]
@@ -662,17 +680,19 @@ class _Mlp(torch.autograd.Function):
         du = gemm(dz, w2, b_trans=not conv1d, dact_aux=u, dact=ctx.act)
         dx = dw1 = db1 = dw2 = db2 = dres = None
         if ctx.needs_input_grad[3]:
-            dw2 = (gemm(h, dz, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, N, M)) if conv1d else
-                   gemm(dz, h, a_trans=True, b_trans=True, split_k=auto_split_k(N, Hd, M)))
+            dst = _grad_dest(w2, BF16)
+            dw2 = (gemm(h, dz, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, N, M), out=dst) if conv1d else
+                   gemm(dz, h, a_trans=True, b_trans=True, split_k=auto_split_k(N, Hd, M), out=dst))
         if ctx.has_b2 and ctx.needs_input_grad[4]:
-            db2 = colsum(dz, ctx.b2_dtype)
+            db2 = colsum(dz, ctx.b2_dtype, out=_grad_dest(b2, ctx.b2_dtype))
         if ctx.needs_input_grad[0]:
             dx = gemm(du, w1, b_trans=not conv1d).view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
-            dw1 = (gemm(x2, du, a_trans=True, b_trans=True, split_k=auto_split_k(K, Hd, M)) if conv1d else
-                   gemm(du, x2, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, K, M)))
+            dst = _grad_dest(w1, BF16)
+            dw1 = (gemm(x2, du, a_trans=True, b_trans=True, split_k=auto_split_k(K, Hd, M), out=dst) if conv1d else
+                   gemm(du, x2, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, K, M), out=dst))
         if ctx.has_b1 and ctx.needs_input_grad[2]:
-            db1 = colsum(du, ctx.b1_dtype)
+            db1 = colsum(du, ctx.b1_dtype, out=_grad_dest(b1, ctx.b1_dtype))
         if ctx.has_res and ctx.needs_input_grad[5]:
             dres = dy
         return dx, dw1, db1, dw2, db2, dres, None, None, None
@@ -697,17 +717,20 @@ class _LayerNorm(torch.autograd.Function):
         ctx.has_beta = beta is not None
         ctx.x_shape = x.shape
         if need_grad:
-            ctx.save_for_backward(x2, gamma, mean, rstd)
+            ctx.save_for_backward(x2, gamma, mean, rstd, beta)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, gamma, mean, rstd = ctx.saved_tensors
+        x2, gamma, mean, rstd, beta = ctx.saved_tensors
         dy2 = _req(dy, "layernorm.grad_output").reshape(x2.shape)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         need_p = ctx.has_affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p, None, gamma.dtype if need_p else torch.float32)
+        gdt = gamma.dtype if need_p else torch.float32
+        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p, None, gdt,
+                                   _grad_dest(gamma, gdt) if need_p else None,
+                                   _grad_dest(beta, gdt) if need_p and ctx.has_beta else None)
         return dx.view(ctx.x_shape), dg, (db if ctx.has_beta else None), None
 
 
@@ -733,12 +756,12 @@ class _LayerNormFork(torch.autograd.Function):
         ctx.has_beta = beta is not None
         ctx.x_shape = x.shape
         if need_grad:
-            ctx.save_for_backward(x2, gamma, mean, rstd)
+            ctx.save_for_backward(x2, gamma, mean, rstd, beta)
         return x.view_as(x), y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dres, dy):
-        x2, gamma, mean, rstd = ctx.saved_tensors
+        x2, gamma, mean, rstd, beta = ctx.saved_tensors
         if dy is None:          # the normalised branch was not used
             return dres, None, None, None
         dy2 = _req(dy, "layernorm.grad_output").reshape(x2.shape)
@@ -750,7 +773,10 @@ class _LayerNormFork(torch.autograd.Function):
             if not dres2.is_contiguous():
                 dres2 = dres2.contiguous()
         need_p = ctx.has_affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p, dres2, gamma.dtype if need_p else torch.float32)
+        gdt = gamma.dtype if need_p else torch.float32
+        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p, dres2, gdt,
+                                   _grad_dest(gamma, gdt) if need_p else None,
+                                   _grad_dest(beta, gdt) if need_p and ctx.has_beta else None)
         return dx.view(ctx.x_shape), dg, (db if ctx.has_beta else None), None
 
 

@@ -369,7 +369,7 @@ def all_checks(quick=False):
         (check_gemm, dict(M=1024, N=768, K=4128, a_trans=True, b_trans=True, out_f32=True, variant=8)),
         (check_gemm, dict(M=2048, N=1024, K=96, b_trans=True, variant=8)),
     ]
-    L += [(check_flat_adamw, dict())]
+    L += [(check_flat_adamw, dict()), (check_direct_grads, dict())]
     L += [(check_fused_losses, dict(case_name=c)) for c in ("C_calvin_dit", "E_libero_all_heads", "E_atten_goal")]
     L += [
         (check_layernorm, dict(rows=37, cols=768, eps=1e-6)),
@@ -440,6 +440,47 @@ def check_fused_losses(case_name):
     for k in ("image", "depth", "dino", "sam"):
         if k in ga:
             out.append(metrics(f"{tag} d{k}", gf[k], ga[k].cpu(), TOL_GRAD, round_ref=False))
+    return out
+
+
+def check_direct_grads(seed=0):
+    """GradBucketReducer(direct_grads=True): the backward kernels write weight / bias / LayerNorm gradients into the bucket
+    slots and autograd adopts them (no accumulation add) -- same gradients as plain autograd, and p.grad aliases the slot."""
+    import dreamvla_amd.nn as dnn
+    from dreamvla_amd.ddp import GradBucketReducer
+    torch.manual_seed(11 + seed)
+    blk = torch.nn.Sequential(dnn.Block(128, 2, mlp_ratio=4, qkv_bias=True), dnn.Block(128, 2, mlp_ratio=4, qkv_bias=True))
+    head = dnn.Linear(128, 64)
+    mods = torch.nn.ModuleList([blk, head]).to(DEV, BF)
+    params = list(mods.parameters())
+    g = torch.Generator().manual_seed(5 + seed)
+    out = []
+    ref = None
+    for mode in ("plain", "direct"):
+        red = GradBucketReducer(params, bucket_bytes=200_000, direct_grads=True) if mode == "direct" else None
+        for step in range(2):
+            x = rnd((6, 40, 128), torch.Generator().manual_seed(100 + step)).to(DEV, BF)
+            if red is not None:
+                red.zero_grad()
+            else:
+                for p in params:
+                    p.grad = None
+            y = head(blk(x))
+            y.float().pow(2).mean().backward()
+            if red is not None:
+                red.finish()
+        grads = [(red.grad_of(p) if red is not None else p.grad).detach().float().cpu() for p in params]
+        if mode == "plain":
+            ref = grads
+        else:
+            aliased = sum(int(p.grad is not None and p.grad.data_ptr() == red.grad_of(p).data_ptr()) for p in params)
+            out.append({"name": f"direct_grads: {aliased}/{len(params)} gradients adopted in place", "rel_l2": 0.0, "tol": 0.0,
+                        "ok": aliased == len(params)})
+            got = torch.cat([t.reshape(-1) for t in grads])
+            want = torch.cat([t.reshape(-1) for t in ref])
+            out.append(metrics("direct_grads: gradients == plain autograd", got, want, TOL_GRAD, round_ref=False))
+            for p in params:                   # leave the parameters as plain leaves
+                p.grad = None
     return out
 
 

@@ -34,13 +34,13 @@ class Tiny(nn.Module):
         return y
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, direct):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dreamvla_amd.ddp import GradBucketReducer
     torch.manual_seed(0)
     m = Tiny()
-    red = GradBucketReducer(m.parameters(), bucket_bytes=1500)      # force several buckets
+    red = GradBucketReducer(m.parameters(), bucket_bytes=1500, direct_grads=direct)      # force several buckets
     assert len(red.buckets) >= 3 and red.grads_are_views()
     g = torch.Generator().manual_seed(5)
     X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
@@ -55,10 +55,13 @@ def _worker(rank, world, port, q):
         early[it] = [b["launched"] for b in red.buckets]             # launched during backward, before finish()
         red.finish()
         assert red.grads_are_views()
-        out[it] = {n: p.grad.clone() for n, p in m.named_parameters()}
+        out[it] = {n: red.grad_of(p).clone() for n, p in m.named_parameters()}
+        if direct:      # parameters without a gradient keep p.grad = None; the others were adopted into their bucket slot
+            assert m.unused.weight.grad is None or it >= 3
+            assert m.a.weight.grad.data_ptr() == red.grad_of(m.a.weight).data_ptr()
         with torch.no_grad():
             for p in m.parameters():
-                p -= 0.1 * p.grad
+                p -= 0.1 * red.grad_of(p)
     ub = [i for i, b in enumerate(red.buckets) if any(p is m.unused.weight or p is m.unused.bias for p in b["params"])]
     mixed = [i for i in ub if any(p is not m.unused.weight and p is not m.unused.bias for p in red.buckets[i]["params"])]
     assert not all(early[0])                        # step 0: buckets holding an unused parameter wait for finish()
@@ -73,11 +76,12 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_bucket_reducer_matches_full_batch_gradients():
+@pytest.mark.parametrize("direct", [False, True], ids=["grad_views", "direct_grads"])
+def test_bucket_reducer_matches_full_batch_gradients(direct):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, direct)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=240)
