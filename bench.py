@@ -102,9 +102,10 @@ def main():
     ap.add_argument("--seq", type=int, default=7)
     ap.add_argument("--heads", default="C", choices=sorted(HEAD_SETS))
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--tune-steps", type=int, default=3,
+    ap.add_argument("--tune-steps", type=int, default=8,
                     help="untimed steps BEFORE the warm-up in which dreamvla_amd.ops.GemmTuner tries each GEMM kernel "
-                         "configuration once per problem shape and locks the fastest (setup, like building the extension)")
+                         "configuration once per problem shape and locks the fastest (setup, like building the extension); "
+                         "there are six candidates, so GEMM shapes that occur once per step need seven steps to lock")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--torch-ddp", action="store_true", help="use torch DDP instead of dreamvla_amd.ddp.GradBucketReducer")
