@@ -141,9 +141,9 @@ class GemmTuner:
     and once every candidate has `ROUNDS` finished timing(s) the key is locked to the best one.  A forced variant that
     does not apply to a shape falls back to the register-staged kernel inside the library, so every trial is valid.
     Disable with DVLA_GEMM_AUTOTUNE=0 (the library's cost model is then used for every call)."""
-    CANDIDATES = (0, 4, 5, 6, 2)
+    CANDIDATES = tuple(int(v) for v in os.environ.get("DVLA_GEMM_CANDIDATES", "0,4,5,6,2").split(","))
     LIBRARY = 8     # hipBLASLt through dvla_gemm_library_bf16: offered for epilogue-free GEMMs only (plain=True)
-    ROUNDS = 1
+    ROUNDS = int(os.environ.get("DVLA_GEMM_TUNE_ROUNDS", "1"))
     enabled = os.environ.get("DVLA_GEMM_AUTOTUNE", "1") != "0" and os.environ.get("DVLA_GEMM_VARIANT") is None
     library = os.environ.get("DVLA_GEMM_LIBRARY", "1") != "0"
     table = {}      # key -> locked variant
