@@ -35,6 +35,7 @@ class GradBucketReducer:
         self.group = process_group
         self.static_unused = bool(static_unused)
         self.direct_grads = bool(direct_grads)
+        self.copied = 0     # direct_grads: gradients the hook had to copy into their slot (not produced in place)
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []       # dicts: flat, params, pending
         order = list(reversed(self.params))
@@ -86,6 +87,7 @@ class GradBucketReducer:
                 if g is not None and g.data_ptr() != view.data_ptr():
                     view.copy_(g)
                     param.grad = view
+                    self.copied += 1
             if not b["expected"][pi]:
                 if b["launched"]:
                     raise RuntimeError("GradBucketReducer: a parameter that received no gradient in earlier steps received one "

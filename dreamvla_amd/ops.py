@@ -574,7 +574,9 @@ def _grad_dest(param, dtype=None):
     if dtype is not None and view.dtype != dtype:
         return None
     param._dvla_grad_free = False
-    return view
+    # a FRESH alias: AccumulateGrad adopts an incoming gradient only if nobody else holds a reference to that tensor
+    # object (otherwise it clones it) -- the slot tensor itself is referenced by the reducer
+    return view.view_as(view)
 
 
 class _Linear(torch.autograd.Function):

@@ -474,8 +474,8 @@ def check_direct_grads(seed=0):
             ref = grads
         else:
             aliased = sum(int(p.grad is not None and p.grad.data_ptr() == red.grad_of(p).data_ptr()) for p in params)
-            out.append({"name": f"direct_grads: {aliased}/{len(params)} gradients adopted in place", "rel_l2": 0.0, "tol": 0.0,
-                        "ok": aliased == len(params)})
+            out.append({"name": f"direct_grads: {aliased}/{len(params)} gradients in their slot, {red.copied} copied by the hook",
+                        "rel_l2": 0.0, "tol": 0.0, "ok": aliased == len(params) and red.copied == 0})
             got = torch.cat([t.reshape(-1) for t in grads])
             want = torch.cat([t.reshape(-1) for t in ref])
             out.append(metrics("direct_grads: gradients == plain autograd", got, want, TOL_GRAD, round_ref=False))
