@@ -91,48 +91,75 @@ __global__ __launch_bounds__(LOSS_THREADS) void patch_mse_kernel(View pred, View
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// cosine: rows of C elements (C % 64 == 0, C <= 1024).  F.cosine_similarity: x.y / sqrt(max(|x|^2 |y|^2, eps^2)), eps 1e-8
+// cosine: rows of C elements (C % 8 == 0, C <= 1024), read as 16-byte vectors.  C <= 256: two rows per wave (one per
+// 32-lane half, reductions stay inside the half); otherwise one row per wave, vector v = lane + 64 i.
+// F.cosine_similarity: x.y / sqrt(max(|x|^2 |y|^2, eps^2)), eps 1e-8
+__device__ __forceinline__ float group_sum(float v, int width) {   // width 64 or 32: xor offsets below `width`
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    if (o < width) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void unpack8l(const uint4& u, float (&f)[8]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { f[2 * k] = bf2f((bf16_t)(w[k] & 0xffff)); f[2 * k + 1] = bf2f((bf16_t)(w[k] >> 16)); }
+}
 template <bool BWD>
 __global__ __launch_bounds__(LOSS_THREADS) void cosine_kernel(View pred, View lab, int rows_per_frame, int C, int64_t n_frames,
                                                              float* __restrict__ partial, ViewW dpred, const float* __restrict__ gout,
                                                              float gscale) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n_rows = n_frames * rows_per_frame;
-  const int per = C >> 6;   // elements per lane (<= 16)
+  const int nvec = C >> 3;                        // 16-byte vectors per row (<= 128)
+  const int rpw = nvec <= 32 ? 2 : 1;             // rows per wave
+  const int width = rpw == 2 ? 32 : 64;
+  const int sub = rpw == 2 ? (lane >> 5) : 0, sl = rpw == 2 ? (lane & 31) : lane;
   float acc = 0.f;
   float g = 0.f;
   if (BWD) g = gout[0] * gscale;
-  for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < n_rows; u += (int64_t)gridDim.x * 4) {
-    const int64_t f = u / rows_per_frame;
-    const int r = (int)(u - f * rows_per_frame);
-    const bf16_t* pr = pred.frame(f) + (int64_t)r * C;
-    const bf16_t* lr = lab.frame(f) + (int64_t)r * C;
-    float x[16], y[16];
+  for (int64_t u0 = ((int64_t)blockIdx.x * 4 + wave) * rpw; u0 < n_rows; u0 += (int64_t)gridDim.x * 4 * rpw) {
+    const int64_t u = u0 + sub;
+    const bool live = u < n_rows;
+    const int64_t uc = live ? u : n_rows - 1;
+    const int64_t f = uc / rows_per_frame;
+    const int r = (int)(uc - f * rows_per_frame);
+    const uint4* pr = reinterpret_cast<const uint4*>(pred.frame(f) + (int64_t)r * C);
+    const uint4* lr = reinterpret_cast<const uint4*>(lab.frame(f) + (int64_t)r * C);
+    float x[2][8], y[2][8];
     float sxy = 0.f, sxx = 0.f, syy = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i < per) {
-        x[i] = bf2f(pr[lane + 64 * i]); y[i] = bf2f(lr[lane + 64 * i]);
-        sxy += x[i] * y[i]; sxx += x[i] * x[i]; syy += y[i] * y[i];
+    for (int i = 0; i < 2; ++i) {
+      const int v = sl + 64 * i;
+      if (v < nvec) {
+        unpack8l(pr[v], x[i]); unpack8l(lr[v], y[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sxy += x[i][e] * y[i][e]; sxx += x[i][e] * x[i][e]; syy += y[i][e] * y[i][e]; }
       }
     }
-    sxy = wave_sum(sxy); sxx = wave_sum(sxx); syy = wave_sum(syy);
-    const float den2 = fmaxf(sxx * syy, 1.e-16f);
-    const float inv = rsqrtf(den2);
+    sxy = group_sum(sxy, width); sxx = group_sum(sxx, width); syy = group_sum(syy, width);
+    const float inv = rsqrtf(fmaxf(sxx * syy, 1.e-16f));
     const float cosv = sxy * inv;
     if (!BWD) {
-      acc += 1.0f - cosv;
-    } else {
+      if (live && sl == 0) acc += 1.0f - cosv;    // one lane per row carries the row's value
+    } else if (live) {
       // d(1 - cos)/dx = -(y / den - cos x / |x|^2)   (den clamp inactive for non-degenerate rows)
-      bf16_t* dp = dpred.frame(f) + (int64_t)r * C;
+      uint4* dp = reinterpret_cast<uint4*>(dpred.frame(f) + (int64_t)r * C);
       const float inv_xx = sxx > 0.f ? 1.0f / sxx : 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (i < per) dp[lane + 64 * i] = f2bf(-g * (y[i] * inv - cosv * x[i] * inv_xx));
+      for (int i = 0; i < 2; ++i) {
+        const int v = sl + 64 * i;
+        if (v < nvec) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = -g * (y[i][e] * inv - cosv * x[i][e] * inv_xx);
+          dp[v] = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+        }
+      }
     }
   }
   if (!BWD) {
-    float v[2] = {acc, 0.f};    // one row's value is uniform over the wave: lane 0's copy is the wave's sum
+    float v[2] = {wave_sum(acc), 0.f};
     block_partials(v, partial, 1);
   }
 }
@@ -239,7 +266,7 @@ extern "C" int dvla_cosine_loss_fwd(const dvla_frame_view* pred, const dvla_fram
                                     int64_t n_frames, float* out2, float* partial, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!pred || !label || !pred->base || !label->base || !out2 || !partial || n_frames <= 0 || rows_per_frame <= 0) return DVLA_ERR_ARG;
-  if (cols <= 0 || cols % 64 != 0 || cols > 1024) return DVLA_ERR_UNSUPPORTED;
+  if (cols <= 0 || cols % 8 != 0 || cols > 1024) return DVLA_ERR_UNSUPPORTED;   // 16-byte vectors; frame bases must be 16-B aligned
   const int nb = blocks_for(n_frames * rows_per_frame);
   hipLaunchKernelGGL(cosine_kernel<false>, dim3(nb), dim3(LOSS_THREADS), 0, stream, view_of(*pred), view_of(*label), rows_per_frame, cols,
                      n_frames, partial, ViewW{nullptr, 0, 0, 1}, nullptr, 0.f);
@@ -255,7 +282,7 @@ extern "C" int dvla_cosine_loss_bwd(const dvla_frame_view* pred, const dvla_fram
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!pred || !label || !dpred || !pred->base || !label->base || !dpred->base || !grad_out || n_frames <= 0 || rows_per_frame <= 0)
     return DVLA_ERR_ARG;
-  if (cols <= 0 || cols % 64 != 0 || cols > 1024) return DVLA_ERR_UNSUPPORTED;
+  if (cols <= 0 || cols % 8 != 0 || cols > 1024) return DVLA_ERR_UNSUPPORTED;   // 16-byte vectors; frame bases must be 16-B aligned
   const int nb = blocks_for(n_frames * rows_per_frame);
   hipLaunchKernelGGL(cosine_kernel<true>, dim3(nb), dim3(LOSS_THREADS), 0, stream, view_of(*pred), view_of(*label), rows_per_frame, cols,
                      n_frames, nullptr, viewW_of(*dpred), grad_out, (float)(1.0 / ((double)n_frames * rows_per_frame)));

@@ -31,6 +31,7 @@ def timeit(fn, iters=20, warmup=3):
 def main():
     res = []
     torch.manual_seed(0)
+    ops.GemmTuner.enabled = False      # time the library's own cost-model choice, not the tuner's trial calls
 
     def rec(name, sec, flops=None, nbytes=None):
         r = {"name": name, "us": sec * 1e6}
