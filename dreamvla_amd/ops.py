@@ -142,7 +142,7 @@ class GemmTuner:
     does not apply to a shape falls back to the register-staged kernel inside the library, so every trial is valid.
     Disable with DVLA_GEMM_AUTOTUNE=0 (the library's cost model is then used for every call)."""
     CANDIDATES = tuple(int(v) for v in os.environ.get("DVLA_GEMM_CANDIDATES", "0,4,5,6,2").split(","))
-    LIBRARY = 8     # hipBLASLt through dvla_gemm_library_bf16: offered for epilogue-free GEMMs only (plain=True)
+    LIBRARY = 8     # hipBLASLt through dvla_gemm_library_bf16: offered for plain / bias-only GEMMs (plain=True)
     ROUNDS = int(os.environ.get("DVLA_GEMM_TUNE_ROUNDS", "1"))
     enabled = os.environ.get("DVLA_GEMM_AUTOTUNE", "1") != "0" and os.environ.get("DVLA_GEMM_VARIANT") is None
     library = os.environ.get("DVLA_GEMM_LIBRARY", "1") != "0"
@@ -277,8 +277,9 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     p.accumulate = int(accumulate)
     p.split_k = max(1, int(split_k))
     prof = GemmProfiler.active
-    plain = (bias is None and act == 0 and not want_preact and dact_aux is None and residual is None
-             and dropout_p == 0.0)
+    # "plain": nothing but (optionally) the bias vector rides on the GEMM -- what the library candidate may take
+    plain = (act == 0 and not want_preact and dact_aux is None and residual is None and dropout_p == 0.0
+             and not (bias is not None and accumulate))
     trial, key = None, None
     forced = variant is not None
     variant = int(variant) if forced else 0
@@ -328,7 +329,7 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     if prof is not None:
         prof.records.append((e0, e1, 2.0 * M * N * K))
         prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k), "library" if ran_library else "hip",
-                            int(variant), "plain" if plain else "fused"))
+                            int(variant), ("bias" if bias is not None else "plain") if plain else "fused"))
     return (out, preact) if want_preact else out
 
 

@@ -368,6 +368,8 @@ def all_checks(quick=False):
     L += [
         (check_gemm, dict(M=1024, N=768, K=4128, a_trans=True, b_trans=True, out_f32=True, variant=8)),
         (check_gemm, dict(M=2048, N=1024, K=96, b_trans=True, variant=8)),
+        (check_gemm, dict(M=1024, N=768, K=256, bias=True, variant=8)),                  # the library's own bias epilogue
+        (check_gemm, dict(M=640, N=3072, K=1024, b_trans=True, bias=True, variant=8)),   # Conv1D c_attn layout
     ]
     L += [(check_flat_adamw, dict()), (check_direct_grads, dict())]
     L += [(check_fused_losses, dict(case_name=c)) for c in ("C_calvin_dit", "E_libero_all_heads", "E_atten_goal")]
