@@ -127,6 +127,40 @@ inline uint32_t thr_of(float p) {
   return thr >= 4294967295.0 ? 4294967295u : (uint32_t)thr;
 }
 
+// ---- token assembly (models/dreamvla_model.py:739-759): out[b, s, t, :] = part_k[b, s, t - t0_k, :] + pos[s, :].
+// The parts are the per-frame conditioning tokens and the learned query tokens (broadcast: zero batch / time strides); one
+// gather-write pass replaces torch.cat + the position add.  One 16-byte vector per thread.
+struct AsmSrc { const bf16_t* p; int64_t sb, ss; int t0; };
+struct AsmArgs { AsmSrc src[DVLA_MAX_TOKEN_SRCS]; int n_src; bf16_t* out; const bf16_t* pos; int64_t pos_ss; int B, S, T, H; };
+__global__ __launch_bounds__(256) void assemble_kernel(AsmArgs a) {
+  const int hv = a.H >> 3;
+  const int64_t total = (int64_t)a.B * a.S * a.T * hv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int v = (int)(i % hv);
+    const int64_t row = i / hv;
+    const int t = (int)(row % a.T);
+    const int64_t bs = row / a.T;
+    const int s = (int)(bs % a.S);
+    const int64_t b = bs / a.S;
+    int k = 0;
+    while (k + 1 < a.n_src && t >= a.src[k + 1].t0) ++k;      // sources are sorted by first token
+    const bf16_t* sp = a.src[k].p + b * a.src[k].sb + (int64_t)s * a.src[k].ss + (int64_t)(t - a.src[k].t0) * a.H + v * 8;
+    const uint4 x = *reinterpret_cast<const uint4*>(sp);
+    uint4 o = x;
+    if (a.pos) {
+      const uint4 z = *reinterpret_cast<const uint4*>(a.pos + (int64_t)s * a.pos_ss + v * 8);
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, zs[4] = {z.x, z.y, z.z, z.w};
+      uint32_t r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        r[q] = pack2bf(bf2f((bf16_t)(xs[q] & 0xffff)) + bf2f((bf16_t)(zs[q] & 0xffff)),
+                       bf2f((bf16_t)(xs[q] >> 16)) + bf2f((bf16_t)(zs[q] >> 16)));
+      o = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+    *reinterpret_cast<uint4*>(a.out + row * a.H + v * 8) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" int dvla_abi_version(void) { return 1; }
@@ -204,6 +238,32 @@ extern "C" int dvla_cast_bf16_to_f32(const void* src, float* dst, int64_t n, voi
   hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<const bf16_t*>(src), dst, n);
   return dvla_check_launch();
 }
+extern "C" int dvla_assemble_tokens(const dvla_token_src* srcs, int32_t n_src, const void* pos, int64_t pos_stride_s, void* out,
+                                    int32_t B, int32_t S, int32_t T, int32_t H, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!srcs || !out || n_src < 1 || n_src > DVLA_MAX_TOKEN_SRCS || B < 0 || S < 1 || T < 1 || H < 8) return DVLA_ERR_ARG;
+  if (B == 0) return DVLA_OK;
+  if (H % 8 != 0 || (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(pos) & 15) || (pos && pos_stride_s % 8 != 0))
+    return DVLA_ERR_UNSUPPORTED;
+  AsmArgs a;
+  a.n_src = n_src;
+  int next = 0;
+  for (int k = 0; k < n_src; ++k) {
+    const dvla_token_src& q = srcs[k];
+    if (!q.base || q.tok_count < 1 || q.tok_begin != next) return DVLA_ERR_ARG;      // contiguous cover of [0, T), in order
+    if ((reinterpret_cast<uintptr_t>(q.base) & 15) || q.stride_b % 8 != 0 || q.stride_s % 8 != 0) return DVLA_ERR_UNSUPPORTED;
+    a.src[k] = AsmSrc{reinterpret_cast<const bf16_t*>(q.base), q.stride_b, q.stride_s, q.tok_begin};
+    next += q.tok_count;
+  }
+  if (next != T) return DVLA_ERR_ARG;
+  a.out = reinterpret_cast<bf16_t*>(out);
+  a.pos = reinterpret_cast<const bf16_t*>(pos);
+  a.pos_ss = pos_stride_s;
+  a.B = B; a.S = S; a.T = T; a.H = H;
+  hipLaunchKernelGGL(assemble_kernel, dim3(grid_for((int64_t)B * S * T * H, 8)), dim3(256), 0, stream, a);
+  return dvla_check_launch();
+}
+
 extern "C" int dvla_add(const void* a, const void* b, void* out, int64_t n, int64_t b_period, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!a || !b || !out || n < 0) return DVLA_ERR_ARG;

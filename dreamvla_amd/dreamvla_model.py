@@ -452,8 +452,8 @@ class DreamVLA(nn.Module):
                 parts.append(self.trajectory_tokens.to(wdt).expand(B, S, -1, -1))
         if self.action_pred_steps > 0:
             parts.append(self.action_pred_token.to(wdt).expand(B, S, -1, -1))
-        transformer_input = torch.cat(parts, dim=2)
-        transformer_input = transformer_input + self.transformer_backbone_position_embedding.to(wdt)
+        # one gather-write kernel: cat along the token axis + the window-position embedding (ops.assemble_tokens)
+        transformer_input = ops.assemble_tokens(parts, self.transformer_backbone_position_embedding.to(wdt))
         transformer_input = transformer_input.flatten(1, 2)
 
         # trunk                                                                              (762-790)

@@ -872,6 +872,60 @@ def cross_attention(q, kv, num_heads, *, scale=None):
     return _CrossAttention.apply(q, kv, int(num_heads), float(scale))
 
 
+class _AssembleTokens(torch.autograd.Function):
+    """cat(parts, dim=2) + pos in one gather-write pass (dvla_assemble_tokens).  parts: (B, S, t_k, H) tensors -- ordinary,
+    or expanded views of learned tokens / of a per-sample embedding (zero strides are read in place); pos (1, S, 1, H) or
+    None.  Backward is slicing: every part's gradient is a view of the output gradient (autograd's expand-backward sums
+    the broadcast ones), the position gradient a sum over batch and tokens."""
+
+    @staticmethod
+    def forward(ctx, pos, *parts):
+        lib = _lib.load()
+        B, S, _, H = parts[0].shape
+        srcs = (_lib.TokenSrc * len(parts))()
+        keep, t0 = [], 0
+        for k, p in enumerate(parts):
+            _req(p, "assemble_tokens.part")
+            if p.dim() != 4 or p.shape[0] != B or p.shape[1] != S or p.shape[3] != H:
+                raise ValueError("assemble_tokens: parts must be (B, S, t, H)")
+            ok = (p.stride(3) == 1 and (p.shape[2] == 1 or p.stride(2) == H) and p.stride(0) % 8 == 0 and p.stride(1) % 8 == 0
+                  and p.data_ptr() % 16 == 0)
+            if not ok:
+                p = p.contiguous()
+            keep.append(p)
+            srcs[k] = _lib.TokenSrc(p.data_ptr(), p.stride(0), p.stride(1), t0, p.shape[2])
+            t0 += p.shape[2]
+        out = torch.empty((B, S, t0, H), dtype=BF16, device=parts[0].device)
+        pz = None
+        if pos is not None:
+            pz = _req(pos, "assemble_tokens.pos").reshape(S, H)
+            if not pz.is_contiguous():
+                pz = pz.contiguous()
+        check(lib.dvla_assemble_tokens(srcs, len(parts), _ptr(pz), H, out.data_ptr(), B, S, t0, H, _stream()),
+              "dvla_assemble_tokens")
+        ctx.counts = [p.shape[2] for p in parts]
+        ctx.pos_shape = None if pos is None else pos.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, t0 = [], 0
+        for k, n in enumerate(ctx.counts):
+            grads.append(g[:, :, t0:t0 + n, :] if ctx.needs_input_grad[1 + k] else None)
+            t0 += n
+        gpos = None
+        if ctx.pos_shape is not None and ctx.needs_input_grad[0]:
+            gpos = g.sum(dim=(0, 2)).reshape(ctx.pos_shape)
+        return (gpos, *grads)
+
+
+def assemble_tokens(parts, pos=None):
+    """(B, S, sum t_k, H) = cat(parts, dim=2) + pos"""
+    if len(parts) > 16:
+        raise ValueError("assemble_tokens: at most 16 parts")
+    return _AssembleTokens.apply(pos, *parts)
+
+
 class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p):

@@ -188,6 +188,18 @@ int dvla_adamw_bf16(void* param, const void* grad, void* exp_avg, void* exp_avg_
                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Token assembly (models/dreamvla_model.py:739-759): out[b, s, t, :] = part_k[b, s, t - tok_begin_k, :] + pos[s, :]
+ * for the part k that owns token t -- the per-frame conditioning tokens (text, state, resampled image tokens, cls tokens)
+ * and the learned prediction-query tokens (stride_b = stride_s = 0: broadcast parameters) -- replacing torch.cat + the
+ * window-position add.  Parts cover [0, T) in order; element strides; every base 16-byte aligned; H % 8 == 0.
+ * pos may be NULL (no add) and is read at pos + s * pos_stride_s.  bf16.
+ */
+#define DVLA_MAX_TOKEN_SRCS 16
+typedef struct dvla_token_src { const void* base; int64_t stride_b; int64_t stride_s; int32_t tok_begin; int32_t tok_count; } dvla_token_src;
+int dvla_assemble_tokens(const dvla_token_src* srcs, int32_t n_src, const void* pos, int64_t pos_stride_s, void* out,
+                         int32_t B, int32_t S, int32_t T, int32_t H, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Training-loss reductions (the caller-side loss block of the reference, utils/train_utils.py:172-450 + utils/sigloss.py:
  * patchify -> per-patch normalise -> (flow mask) -> MSE; 1 - cosine_similarity; SiLog on un-patchified depth).  bf16 data,
  * fp32 arithmetic, deterministic two-stage sums.  Tensors are addressed per FRAME through a view so the caller's slices

@@ -371,7 +371,7 @@ def all_checks(quick=False):
         (check_gemm, dict(M=1024, N=768, K=256, bias=True, variant=8)),                  # the library's own bias epilogue
         (check_gemm, dict(M=640, N=3072, K=1024, b_trans=True, bias=True, variant=8)),   # Conv1D c_attn layout
     ]
-    L += [(check_flat_adamw, dict()), (check_direct_grads, dict())]
+    L += [(check_flat_adamw, dict()), (check_direct_grads, dict()), (check_assemble_tokens, dict())]
     L += [(check_fused_losses, dict(case_name=c)) for c in ("C_calvin_dit", "E_libero_all_heads", "E_atten_goal")]
     L += [
         (check_layernorm, dict(rows=37, cols=768, eps=1e-6)),
@@ -442,6 +442,34 @@ def check_fused_losses(case_name):
     for k in ("image", "depth", "dino", "sam"):
         if k in ga:
             out.append(metrics(f"{tag} d{k}", gf[k], ga[k].cpu(), TOL_GRAD, round_ref=False))
+    return out
+
+
+def check_assemble_tokens(B=3, S=4, H=1024, seed=0):
+    """ops.assemble_tokens (dvla_assemble_tokens) == torch.cat(parts, dim=2) + pos bit for bit (bf16 add of the same two
+    values), with ordinary parts, a per-sample embedding broadcast over time and learned tokens broadcast over (B, S);
+    gradients == autograd of the cat formulation."""
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(321 + seed)
+    mk = lambda *s: rnd(s, g).to(DEV, BF)
+    out = []
+    leaves = {}
+    for mode in ("hip", "ref"):
+        gg = torch.Generator().manual_seed(321 + seed)
+        mk = lambda *s: rnd(s, gg).to(DEV, BF).requires_grad_(True)
+        text, state, img = mk(B, 1, 1, H), mk(B, S, 1, H), mk(B, S, 16, H)
+        tok_a, tok_b, pos = mk(1, 1, 18, H), mk(1, 1, 3, H), mk(1, S, 1, H)
+        sliced = mk(B, S, 40, H)
+        parts = [text.expand(B, S, 1, H), state, img, sliced[:, :, 5:7], tok_a.expand(B, S, -1, -1), tok_b.expand(B, S, -1, -1)]
+        y = ops.assemble_tokens(parts, pos) if mode == "hip" else torch.cat(parts, dim=2) + pos
+        w = rnd(tuple(y.shape), torch.Generator().manual_seed(9)).to(DEV, BF)
+        (y.float() * w.float()).sum().backward()
+        leaves[mode] = (y.detach(), [t.grad.detach().float() for t in (text, state, img, tok_a, tok_b, pos, sliced)])
+    yh, gh = leaves["hip"]
+    yr, gr = leaves["ref"]
+    out.append({"name": "assemble_tokens == cat + pos (bit-exact)", "rel_l2": rel_l2(yh, yr), "tol": 0.0, "ok": bool(torch.equal(yh, yr))})
+    for nm, a, b in zip(("text", "state", "img", "tok_a", "tok_b", "pos", "sliced"), gh, gr):
+        out.append(metrics(f"assemble_tokens d{nm}", a, b.cpu(), 1e-6, round_ref=False))
     return out
 
 
