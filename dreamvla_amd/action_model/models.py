@@ -114,46 +114,44 @@ class DiT(nn.Module):
                  class_dropout_prob=0.1, token_size=4096, future_action_window_size=1, past_action_window_size=0,
                  learn_sigma=False):
         super().__init__()
-        assert past_action_window_size == 0, "Error: action_history is not used now"
-        self.learn_sigma = learn_sigma
-        self.in_channels = in_channels
-        self.out_channels = in_channels * 2 if learn_sigma else in_channels
+        if past_action_window_size != 0:
+            raise AssertionError("Error: action_history is not used now")
+        self.learn_sigma, self.in_channels, self.num_heads = learn_sigma, in_channels, num_heads
+        self.out_channels = in_channels * (2 if learn_sigma else 1)
         self.class_dropout_prob = class_dropout_prob
-        self.num_heads = num_heads
-        self.past_action_window_size = past_action_window_size
-        self.future_action_window_size = future_action_window_size
-        self.history_embedder = HistoryEmbedder(action_size=in_channels, hidden_size=hidden_size)
-        self.x_embedder = ActionEmbedder(action_size=in_channels, hidden_size=hidden_size)
-        self.t_embedder = TimestepEmbedder(hidden_size)
-        self.z_embedder = LabelEmbedder(in_size=token_size, hidden_size=hidden_size, dropout_prob=class_dropout_prob,
-                                        conditions_shape=(1, 1, token_size))
-        scale = hidden_size ** -0.5
-        self.positional_embedding = nn.Parameter(
-            scale * torch.randn(future_action_window_size + past_action_window_size + 1 + future_action_window_size + 1,
-                                hidden_size))
-        self.blocks = nn.ModuleList([DiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
-        self.final_layer = FinalLayer(hidden_size, self.out_channels)
+        self.past_action_window_size, self.future_action_window_size = past_action_window_size, future_action_window_size
+        # Registration order is the reference's (action_model/models.py:186-205): it fixes the state_dict key order and the
+        # order in which the initialisers below draw from the RNG.
+        n_pos = 2 * future_action_window_size + past_action_window_size + 2      # condition token + current action + windows
+        for name, build in (
+                ("history_embedder", lambda: HistoryEmbedder(action_size=in_channels, hidden_size=hidden_size)),
+                ("x_embedder", lambda: ActionEmbedder(action_size=in_channels, hidden_size=hidden_size)),
+                ("t_embedder", lambda: TimestepEmbedder(hidden_size)),
+                ("z_embedder", lambda: LabelEmbedder(in_size=token_size, hidden_size=hidden_size, dropout_prob=class_dropout_prob,
+                                                     conditions_shape=(1, 1, token_size))),
+                ("positional_embedding", lambda: nn.Parameter(hidden_size ** -0.5 * torch.randn(n_pos, hidden_size))),
+                ("blocks", lambda: nn.ModuleList(DiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth))),
+                ("final_layer", lambda: FinalLayer(hidden_size, self.out_channels))):
+            setattr(self, name, build())
         self.initialize_weights()
 
     def initialize_weights(self):
-        def _basic_init(module):
-            if isinstance(module, nn.Linear):
-                torch.nn.init.xavier_uniform_(module.weight)
-                if module.bias is not None:
-                    nn.init.constant_(module.bias, 0)
-        self.apply(_basic_init)
-        nn.init.normal_(self.x_embedder.linear.weight, std=0.02)
-        nn.init.constant_(self.x_embedder.linear.bias, 0)
-        nn.init.normal_(self.history_embedder.linear.weight, std=0.02)
-        nn.init.constant_(self.history_embedder.linear.bias, 0)
+        """action_model/models.py:207-232: Xavier-uniform on every Linear (depth-first order, as `self.apply` visits them),
+        then N(0, 0.02) on the embedders / timestep MLP and zeros on the output layer."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        narrow = [self.x_embedder.linear.weight, self.history_embedder.linear.weight]
         if self.class_dropout_prob > 0:
-            nn.init.normal_(self.z_embedder.uncondition, std=0.02)
-        nn.init.normal_(self.z_embedder.linear.weight, std=0.02)
-        nn.init.constant_(self.z_embedder.linear.bias, 0)
-        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
-        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
-        nn.init.constant_(self.final_layer.linear.weight, 0)
-        nn.init.constant_(self.final_layer.linear.bias, 0)
+            narrow.append(self.z_embedder.uncondition)
+        narrow += [self.z_embedder.linear.weight, self.t_embedder.mlp[0].weight, self.t_embedder.mlp[2].weight]
+        for w in narrow:
+            nn.init.normal_(w, std=0.02)
+        for b in (self.x_embedder.linear.bias, self.history_embedder.linear.bias, self.z_embedder.linear.bias,
+                  self.final_layer.linear.weight, self.final_layer.linear.bias):
+            nn.init.zeros_(b)
 
     def forward(self, x, t, z):
         """x: (N, T, 7) noisy actions, t: (N,) timesteps, z: (N, T', token) conditions -> (N, T, 7)"""

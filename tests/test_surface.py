@@ -54,3 +54,21 @@ def test_forward_on_cpu_raises(model_and_surface):
     with pytest.raises((DvlaError, TypeError)):
         m(torch.zeros(B, S, 3, 224, 224), torch.zeros(B, S, 3, 224, 224), torch.zeros(B, S, 7),
           torch.zeros(B, S, 77, dtype=torch.long), mode="test")
+
+
+def test_dit_initialisation_matches_reference_bit_for_bit():
+    """Same seed -> same DiT parameters as the REAL reference class (key order, RNG draw order of the initialisers):
+    action_model/models.py:186-232.  Needs /root/reference (build container only)."""
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    from dreamvla_amd.action_model.models import DiT
+    ref = ref_loader.ref_module("models.action_model.models")
+    kw = dict(in_channels=7, hidden_size=768, depth=2, num_heads=12, token_size=1024, future_action_window_size=2)
+    torch.manual_seed(0)
+    ours = DiT(**kw).state_dict()
+    torch.manual_seed(0)
+    theirs = ref.DiT(**kw).state_dict()
+    assert list(ours) == list(theirs)
+    for k in ours:
+        assert torch.equal(ours[k].float(), theirs[k].float()), k
