@@ -13,7 +13,8 @@ heads, DiT diffusion head) -> reference loss block -> backward -> gradient all-r
 Extra objects in the line:
   roofline     : the dominant kernels (gemm_ring_kernel / gemm_kernel, bf16 MFMA).  achieved = algorithmic FLOPs of every GEMM launch of one
                  instrumented step / summed launch durations (HIP events on the launch stream), peak = 2500 TFLOP/s dense.
-  cpu_baseline : the oracle (oracle/model_ref.py, "port") timed on this box's host cores on a bounded sample.
+  cpu_baseline : the oracle (oracle/model_ref.py, "port") timed on this box's host cores on a bounded sample (B = 2).
+  eager_rocm_baseline : the same step run eagerly on PyTorch-ROCm bf16 on this GPU (the >= 4x target's denominator).
 """
 import argparse
 import json
@@ -53,7 +54,8 @@ def label_heads(heads):
 
 
 def cpu_baseline(heads, S):
-    """Oracle forward + loss + backward on the host cores, B = 1 (bounded: ~10-30 s)."""
+    """Oracle forward + loss + backward on the host cores: BASELINE configs[0] (B = 2, S = 7, fp32), one un-timed
+    warm-up step, then two timed steps (bounded: ~20-30 s on 16 threads)."""
     from oracle import model_ref as M
     from oracle import weights
     from dreamvla_amd.dreamvla_model import DreamVLA
@@ -67,17 +69,20 @@ def cpu_baseline(heads, S):
     leaves = {k: v.requires_grad_(True) for k, v in sd.items()
               if torch.is_floating_point(v) and not k.startswith(("clip_model.", "vision_encoder.")) and k != "attention_mask"
               and "decoder_position_embedding" not in k}
-    B = 1
+    B = 2
     b = weights.synthetic_batch(B, S, window=S + 3, seed=7, heads=label_heads(heads))
     b["actions"][..., 6:] = (b["actions"][..., 6:] > 0.5).float()
     lab = losses.label_actions(b["actions"], S, 3)
     g = torch.Generator().manual_seed(3)
     noise = torch.randn(8 * B * S, 3, 7, generator=g)
     tstep = torch.randint(0, 100, (8 * B * S,), generator=g)
-    nsteps = 3
-    t0 = time.time()
+    nsteps = 2
     t_fwd = 0.0
-    for _ in range(nsteps):
+    t0 = None
+    for it in range(nsteps + 1):
+        if it == 1:
+            t0 = time.time()           # the first (cold: allocator, thread pool, page faults) step is not timed
+            t_fwd = 0.0
         for v in leaves.values():
             v.grad = None
         t1 = time.time()
@@ -88,9 +93,19 @@ def cpu_baseline(heads, S):
         total.backward()
     dt = time.time() - t0
     return {"value": B * nsteps / dt, "unit": "samples/s", "cores": nthreads, "kind": "port",
-            "sample": f"{nsteps} steps (first one un-warmed) of oracle/model_ref.py forward+loss+backward, fp32, B={B}, S={S}, "
+            "sample": f"{nsteps} timed steps after 1 warm-up of oracle/model_ref.py forward+loss+backward, fp32, B={B}, S={S}, "
                       f"head set {heads}, full 1024/24/16 model, {nthreads} threads of {os.cpu_count()}; "
-                      f"fwd {t_fwd:.1f}s of {dt:.1f}s"}
+                      f"fwd {t_fwd / nsteps:.2f} s + bwd {(dt - t_fwd) / nsteps:.2f} s per step"}
+
+
+def eager_rocm_baseline(heads, S, B, steps=5):
+    """The >= 4x target's denominator: the reference step run EAGERLY on
+    PyTorch-ROCm on this same GPU in bf16 -- hipBLASLt GEMMs + SDPA + ATen elementwise, fused AdamW -- at the same B, S and
+    head set.  The reference itself cannot travel to the GPU box, so this drives the oracle's functional restatement of it
+    (tests/gpu_eager_baseline.py: same ATen op sequence; no dropout and no (B,1,L,L) mask copy, both of which would only
+    make eager slower).  Baseline leg only: nothing here is on the product path."""
+    from tests import gpu_eager_baseline
+    return gpu_eager_baseline.run(heads, B, steps, S=S)
 
 
 def main():
@@ -102,12 +117,14 @@ def main():
     ap.add_argument("--seq", type=int, default=7)
     ap.add_argument("--heads", default="C", choices=sorted(HEAD_SETS))
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--tune-steps", type=int, default=8,
+    ap.add_argument("--tune-steps", type=int, default=11,
                     help="untimed steps BEFORE the warm-up in which dreamvla_amd.ops.GemmTuner tries each GEMM kernel "
                          "configuration once per problem shape and locks the fastest (setup, like building the extension); "
-                         "there are six candidates, so GEMM shapes that occur once per step need seven steps to lock")
+                         "five candidates x GemmTuner.ROUNDS (2) trials: shapes that occur once per step need eleven steps to lock")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true",
+                    help="skip the eager PyTorch-ROCm comparator (rank 0, N = 1 only; ~10 s after the timed region)")
     ap.add_argument("--torch-ddp", action="store_true", help="use torch DDP instead of dreamvla_amd.ddp.GradBucketReducer")
     ap.add_argument("--torch-adamw", action="store_true",
                     help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of dreamvla_amd.optim.FlatAdamW (HIP, flat buffers)")
@@ -235,27 +252,29 @@ def main():
         with prof:
             step()
         torch.cuda.synchronize()
-        r_all, r_lib = prof.summary(), prof.summary("library")
-        r = prof.summary("hip")     # the roofline is quoted on the hand-written kernels only
+        r = prof.summary()          # every GEMM launch of the step is a hand-written kernel (no vendor library is linked)
+        n_lib = sum(1 for sh in prof.shapes if sh[6] != "hip")
         if os.environ.get("DVLA_GEMM_BREAKDOWN"):
             with open(os.environ["DVLA_GEMM_BREAKDOWN"], "w") as f:
                 json.dump(prof.breakdown(), f, indent=1)
+        # HBM-side traffic of the GEMM dispatches cannot be collected from inside the process: it comes from separate
+        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command (tests/pmc_traffic.sh), stored with the
+        # commit they were measured on; a file from another tree is reported as stale, never presented as current
         traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (cannot be collected from inside)
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)
-            traffic, traffic_src = t["gemm_bytes_per_launch"], t["source"]
+            traffic = t.get("gemm_bytes_per_launch")
+            traffic_src = {"source": t.get("source"), "measured_on_commit": t.get("commit"),
+                           "algorithmic_bytes_per_launch": t.get("algorithmic_bytes_per_launch")}
         roofline = {"bound": "mfma",
-                    "kernel": "gemm_ring_kernel + gemm_kernel (bf16 MFMA 32x32x16; every GEMM launch of one training step)",
+                    "kernel": "gemm_ring_kernel + gemm_kernel (hand-written bf16 MFMA 32x32x16; every GEMM launch of one training step)",
                     "achieved": r["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["tflops"] / BF16_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "launches": r["launches"], "avg_launch_us": r["avg_us"],
                     "gflop_per_launch": r["gflop_per_launch"], "gemm_ms_per_step": r["total_ms"],
                     "whole_step_frac_of_bf16_peak": TRAIN_GFLOP_PER_SAMPLE[args.heads] * (B * 1e3 / ms_per_step) / 1e3 / BF16_PEAK_TFLOPS,
-                    # epilogue-free GEMMs on which the tuner measured hipBLASLt faster than every hand-written
-                    # configuration (the per-shape gap list: DVLA_GEMM_BREAKDOWN=<file>); DVLA_GEMM_LIBRARY=0 removes the candidate
-                    "library_gemm": {"launches": r_lib["launches"], "ms_per_step": r_lib["total_ms"], "tflops": r_lib["tflops"]},
-                    "all_gemm": {"launches": r_all["launches"], "ms_per_step": r_all["total_ms"], "tflops": r_all["tflops"]},
+                    "library_gemm": {"launches": n_lib},
                     "tuner_wins_by_problem_key": GemmTuner.summary()}
 
     cpu = None
@@ -264,6 +283,16 @@ def main():
             cpu = cpu_baseline(args.heads, S)
         except Exception as e:  # noqa: BLE001
             cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+
+    eager = None
+    if rank == 0 and world == 1 and not args.no_eager_baseline:
+        try:
+            del model, ddp_model, reducer, flat_opt, opt, params
+            torch.cuda.empty_cache()
+            eager = eager_rocm_baseline(args.heads, S, B)
+            eager["ours_over_eager"] = value / eager["value"]
+        except Exception as e:  # noqa: BLE001
+            eager = {"value": None, "unit": "samples/s", "sample": f"failed: {e!r}"}
 
     if rank == 0:
         line = {
@@ -280,7 +309,7 @@ def main():
                        "grad_exchange": "torch DDP" if reducer is None else "GradBucketReducer (flat bf16 buckets, async all-reduce)",
                        "optimizer": "FlatAdamW (HIP: dvla_sumsq_bf16 + dvla_adamw_bf16 on flat buffers)" if flat_opt is not None
                                     else "clip_grad_norm_ + torch.optim.AdamW(fused)"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "eager_rocm_baseline": eager,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

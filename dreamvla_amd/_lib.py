@@ -74,7 +74,6 @@ SYMBOLS = {
     "dvla_abi_version": (C.c_int, []),
     "dvla_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), _P]),
     "dvla_set_gemm_variant": (None, [C.c_int]),
-    "dvla_gemm_library_bf16": (C.c_int, [C.POINTER(GemmParams), _P, _I64, _P]),
     "dvla_layernorm_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I64, _I64, _F, _P]),
     "dvla_layernorm_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "dvla_layernorm_bwd_add": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
@@ -123,6 +122,24 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+CMP_LIB_PATH = os.path.join(_HERE, "libdvla_cmp.so")
+_cmp = None
+
+
+def load_comparator():
+    """libdvla_cmp.so (include/dvla_cmp.h): the hipBLASLt yardstick.  Test / measurement infrastructure only -- no module
+    of the product path calls this."""
+    global _cmp
+    if _cmp is None:
+        if not os.path.exists(CMP_LIB_PATH):
+            raise DvlaError(f"{CMP_LIB_PATH} not found (built by __graft_entry__.build())")
+        lib = C.CDLL(CMP_LIB_PATH)
+        lib.dvla_gemm_library_bf16.restype = C.c_int
+        lib.dvla_gemm_library_bf16.argtypes = [C.POINTER(GemmParams), _P, _I64, _P]
+        _cmp = lib
+    return _cmp
 
 
 def check(rc, what):

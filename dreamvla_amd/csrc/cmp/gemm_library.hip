@@ -14,8 +14,8 @@
 #include <mutex>
 #include <unordered_map>
 
-#include "../../include/dvla.h"
-#include "common.h"
+#include "../../../include/dvla_cmp.h"
+#include "../common.h"
 
 namespace {
 

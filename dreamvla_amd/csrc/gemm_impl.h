@@ -1,0 +1,1241 @@
+// gemm.hip -- bf16 MFMA GEMM with fused epilogue for gfx950 (MI355X).
+//
+//   C[M,N] = epilogue( A[M,K] . B[N,K]^T ),   fp32 accumulate on v_mfma_f32_32x32x16_bf16
+//
+// Two tile configurations of ONE kernel template (K-tile = 64 in both):
+//   S : 128x128 block tile, 4 waves (2x2), 64x64 per wave (2x2 MFMA tiles),  64 KiB LDS, 2 workgroups / CU   [default]
+//   L : 256x256 block tile, 8 waves (2x4), 128x64 per wave (4x2 MFMA tiles), 128 KiB LDS, 1 workgroup / CU
+// Ablation on MI355X (profiles/r01_gemm_ablation.txt): the S kernel without MFMAs takes 96 % of the full kernel's time
+// and without global loads / LDS writes 58 %, i.e. it is bound by the operand staging path (~22 B/clk/CU from L2), not by
+// the matrix pipe.  The L tile halves that traffic per flop but currently loses more to its single staging set and
+// 1-workgroup occupancy than it gains (805 vs 880 TFLOP/s at 8192^3), so it is opt-in (DVLA_GEMM_VARIANT=3).
+//
+// Operands are staged global -> registers -> LDS.  Two register sets per operand: while tile kt is multiplied out of
+// LDS, tile kt+1 waits in one set (written to the other LDS buffer after the MFMAs) and the 16-byte global loads of
+// tile kt+2 are already in flight into the other set (the steady-state loop is branch-free so the compiler can wait
+// with a counted s_waitcnt vmcnt(8) instead of draining the queue).  One barrier per K-tile.
+//
+// Both operands may have either memory order (the autograd backward GEMMs need every combination):
+//   "k-contiguous" : element (r,k) at P[r*ld + k] -> swizzled row-major LDS image (rm_off), fragments by one
+//                    conflict-free ds_read_b128 per lane.
+//   "r-contiguous" : element (r,k) at P[k*ld + r] -> LDS "quad-interleaved" 8-byte units [k/4][rows]
+//                    (unit = {k..k+3} of one row): each thread transposes a 4(k) x 8(rows) block in
+//                    registers between its four coalesced 16-B global loads and four ds_write_b128;
+//                    fragments by two conflict-free ds_read_b64 per lane.
+// The MFMA k-slot <-> k mapping is the same for both layouts (slot (g,j) <-> k = 16*ks + 8*g + j).
+//
+// The MFMA is issued as mfma(a = B-operand fragment (n), b = A-operand fragment (m)) so that a lane
+// owns ONE output row m and 4 consecutive n per accumulator quad; the epilogue transposes each 32-row
+// slab through a wave-private fp32 LDS patch so a lane ends up with 8 consecutive n of one row and
+// reads bias / residual / aux and writes C with 16-byte accesses.
+//
+// Measured and rejected (kept out of the tree): LDS-DMA staging (global_load_lds_dwordx4) of the k-contiguous operand
+// with a 2-buffer ring was 8-12 % SLOWER than the 2-deep register prefetch (the barrier drains vmcnt(0)).
+#include <stdlib.h>
+
+#pragma once
+#include "common.h"
+#include "../../include/dvla.h"
+
+namespace dvla_gemm {
+
+constexpr int BK = 64;
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  `#pragma unroll` is only a request
+// (the optimizer declines it for the large epilogue body) and a rolled loop would index the accumulator array
+// dynamically, i.e. put 128 accumulator registers into scratch.
+template <int V> struct IntC { static constexpr int value = V; };
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(IntC<N - 1>{});
+  }
+}
+
+template <int WM_, int WN_, int TM_, int TN_, bool DEEP_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr bool DEEP = DEEP_;   // two register sets (prefetch distance 2) vs one (distance 1: fewer VGPRs)
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + B_BYTES;
+  static constexpr int SMEM_BYTES = 2 * BUF_BYTES;
+  static_assert(NT == 2 * BM && NT == 2 * BN, "staging maps assume 4 x 16 B per thread and operand");
+  static_assert(TN == 2, "epilogue patch is 64 columns wide");
+};
+using CfgS = Cfg<2, 2, 2, 2, true>;   // 128 x 128, 256 threads
+
+struct GemmKArgs {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* B; int64_t ldb;
+  void* C; int64_t ldc; int c_f32;
+  int64_t M, N, K;
+  const void* bias; int bias_f32;
+  int act;
+  bf16_t* preact; int64_t ld_preact;
+  const bf16_t* dact_aux; int64_t ld_dact; int dact;
+  float drop_scale; uint32_t drop_thr; uint32_t seed_lo, seed_hi; int has_drop;
+  const bf16_t* residual; int64_t ld_res; int64_t res_rows;
+  int accumulate;
+  int split_k; int64_t k_per_split; float* workspace;
+  int a_vec, b_vec, c_vec, aux_vec, epi_vec;
+  int tiles_m, tiles_n;
+  int direct_store;  // plain bf16 epilogues store from the accumulator layout: 0 never, 1 always, 2 (default) 256x256 tile only; env DVLA_GEMM_DIRECT
+};
+
+// Row-major image of a k-contiguous operand: row r = 128 B = 8 slots of 16 B; k-octet o of row r lives in slot
+// o ^ ((r >> 1) & 7).  Unpadded and conflict-free for ds_read_b128: in every 16-lane read group the rows of equal
+// parity have distinct (r >> 1) & 7.
+__device__ __forceinline__ int rm_off(int row, int oct) { return row * 128 + ((oct ^ ((row >> 1) & 7)) << 4); }
+
+// ---- staging: global -> registers (4 x 16 B per thread and operand; ROWS = tile rows, NT = 2 * ROWS threads) ----
+// k-contiguous operand: thread t loads rows (t>>3) + (NT/8)*i (i = 0..3), k-octet (t&7): 8 lanes = one 128-B row segment
+// r-contiguous operand: thread t loads k = 4*(t / (ROWS/8)) + kk (kk = 0..3), rows (t % (ROWS/8))*8 .. +7
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ void stage_load(uint4 (&reg)[4], const bf16_t* __restrict__ P, int64_t ld, int64_t row0,
+                                           int64_t rows, int64_t k0, int64_t k_end, bool vec_ok, int t) {
+  if (!TRANS) {
+    const int r = t >> 3, kc = (t & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reg[i] = load8_guard(P, ld, row0 + r + (ROWS / 4) * i, k0 + kc, rows, k_end, vec_ok);
+  } else {
+    const int kq = t / (ROWS / 8), r0 = (t % (ROWS / 8)) * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) reg[kk] = load8_guard(P, ld, k0 + 4 * kq + kk, row0 + r0, k_end, rows, vec_ok);
+  }
+}
+
+// Fast path (interior K-tile of a 16-B-vectorisable operand): four unconditional 16-B loads from per-thread pointers that
+// simply advance by one K-tile per iteration.  Rows past the end of a k-contiguous operand are clamped to the last row
+// (their products land in output rows the epilogue never stores); an r-contiguous operand takes the fast path only when
+// the whole row panel is in range.  Everything else (K tail, ragged / unaligned operands) goes through stage_load.
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ void fast_ptrs(const bf16_t* (&ptr)[4], const bf16_t* __restrict__ P, int64_t ld, int64_t row0,
+                                          int64_t rows, int64_t k0, int t) {
+  if (!TRANS) {
+    const int r = t >> 3, kc = (t & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t row = row0 + r + (ROWS / 4) * i;
+      row = row < rows ? row : rows - 1;
+      ptr[i] = P + row * ld + k0 + kc;
+    }
+  } else {
+    const int kq = t / (ROWS / 8), r0 = (t % (ROWS / 8)) * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ptr[kk] = P + (k0 + 4 * kq + kk) * ld + row0 + r0;
+  }
+}
+template <bool TRANS>
+__device__ __forceinline__ void fast_load(uint4 (&reg)[4], const bf16_t* (&ptr)[4], int64_t ld) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    reg[i] = *reinterpret_cast<const uint4*>(ptr[i]);
+    ptr[i] += TRANS ? (int64_t)BK * ld : (int64_t)BK;
+  }
+}
+
+// ---- staging: registers -> LDS ---------------------------------------------------------------------
+// k-contiguous: swizzled row-major image (rm_off).
+// r-contiguous: "quad-interleaved" 8-byte units [k/4][ROWS] = {k, k+1, k+2, k+3} of one row; the 4(k) x 8(rows)
+// register block is transposed in registers (two 16-bit merges per output dword) and leaves as four ds_write_b128.
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ void stage_store(const uint4 (&reg)[4], char* lds, int t) {
+  if (!TRANS) {
+    const int r = t >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(lds + rm_off(r + (ROWS / 4) * i, t & 7)) = reg[i];
+  } else {
+    const int kq = t / (ROWS / 8), r0 = (t % (ROWS / 8)) * 8;
+    uint32_t in[4][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { in[kk][0] = reg[kk].x; in[kk][1] = reg[kk].y; in[kk][2] = reg[kk].z; in[kk][3] = reg[kk].w; }
+    uint32_t o[16];  // row r0+i -> dwords o[2i] = {k0,k1}, o[2i+1] = {k2,k3}
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {  // dword w of every k-vector holds rows r0+2w (low half) and r0+2w+1 (high half)
+      o[4 * w + 0] = (in[0][w] & 0xffffu) | (in[1][w] << 16);
+      o[4 * w + 1] = (in[2][w] & 0xffffu) | (in[3][w] << 16);
+      o[4 * w + 2] = (in[0][w] >> 16) | (in[1][w] & 0xffff0000u);
+      o[4 * w + 3] = (in[2][w] >> 16) | (in[3][w] & 0xffff0000u);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(lds + ((size_t)(kq * ROWS + r0)) * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+  }
+}
+
+// ---- LDS -> MFMA fragment: row `row` of the tile, k16-step ks (0..3), lane group g; slot (g,j) <-> k = 16ks+8g+j --
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ bf16x8 frag_load(const char* lds, int row, int ks, int g) {
+  if (!TRANS) {
+    return *reinterpret_cast<const bf16x8*>(lds + rm_off(row, ks * 2 + g));
+  } else {
+    const int q0 = ks * 4 + g * 2;
+    union { uint2 h[2]; bf16x8 v; } u;
+    u.h[0] = *reinterpret_cast<const uint2*>(lds + ((size_t)(q0 * ROWS + row)) * 8);
+    u.h[1] = *reinterpret_cast<const uint2*>(lds + ((size_t)((q0 + 1) * ROWS + row)) * 8);
+    return u.v;
+  }
+}
+
+__device__ __forceinline__ void unpack8f(const uint4& u, float (&f)[8]) {
+  f[0] = bf2f((bf16_t)(u.x & 0xffff)); f[1] = bf2f((bf16_t)(u.x >> 16));
+  f[2] = bf2f((bf16_t)(u.y & 0xffff)); f[3] = bf2f((bf16_t)(u.y >> 16));
+  f[4] = bf2f((bf16_t)(u.z & 0xffff)); f[5] = bf2f((bf16_t)(u.z >> 16));
+  f[6] = bf2f((bf16_t)(u.w & 0xffff)); f[7] = bf2f((bf16_t)(u.w >> 16));
+}
+__device__ __forceinline__ void load8_aux(const bf16_t* q, int64_t n, int64_t N, bool vec, float (&f)[8]) {
+  if (vec) {
+    unpack8f(*reinterpret_cast<const uint4*>(q), f);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (n + e < N) ? bf2f(q[e]) : 0.f;
+  }
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* q, int64_t n, int64_t N, bool vec, const float (&v)[8]) {
+  if (vec) {
+    *reinterpret_cast<uint4*>(q) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (n + e < N) q[e] = f2bf(v[e]);
+  }
+}
+
+// eight consecutive outputs of row m: columns n .. n+7 (values arrive in fp32 from the LDS transpose).
+// FULL = the whole octet is in range and every pointer involved is 16-B vectorisable: no per-element guards.
+template <bool FULL>
+__device__ __forceinline__ void epilogue_oct(const GemmKArgs& p, int64_t m, int64_t n, float (&v)[8], int split) {
+  if (p.split_k > 1) {  // raw partial sums -> workspace[split][m][n]
+    float* w = p.workspace + ((int64_t)split * p.M + m) * p.N + n;
+    if (FULL) {
+      *reinterpret_cast<float4*>(w) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(w + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) w[e] = v[e];
+    }
+    return;
+  }
+  if (p.bias) {
+    if (FULL && !p.bias_f32) {
+      float bv[8];
+      unpack8f(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bias) + n), bv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bv[e];
+    } else if (FULL) {
+      const float4 b0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n);
+      const float4 b1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N)
+          v[e] += p.bias_f32 ? reinterpret_cast<const float*>(p.bias)[n + e]
+                             : bf2f(reinterpret_cast<const bf16_t*>(p.bias)[n + e]);
+    }
+  }
+  if (p.preact) {
+    store8_bf16(p.preact + m * p.ld_preact + n, n, p.N, FULL, v);
+    // the activation sees the value that was stored (bf16), exactly like act(preact_tensor)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+  }
+  act_fwd8(v, p.act);
+  if (p.has_drop) {
+    const uint32_t rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t h = drop_hash_rk(rowkey, (uint32_t)(n + e));
+      v[e] = (h >= p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+    }
+  }
+  // bf16 outputs: act' / residual are applied to the ROUNDED branch value -- the reference materialises
+  // `dropout(act(linear(x)))` and `dY @ W` as bf16 tensors first (same rule in the ring kernels' epilogue)
+  if (!p.c_f32 && (p.dact_aux || p.residual)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+  }
+  if (p.dact_aux) {
+    float a[8];
+    load8_aux(p.dact_aux + m * p.ld_dact + n, n, p.N, FULL, a);
+    act_bwd8_mul(v, a, p.dact);
+  }
+  if (p.residual) {
+    float a[8];
+    const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)m % (uint32_t)p.res_rows) : m;
+    load8_aux(p.residual + rr * p.ld_res + n, n, p.N, FULL, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += a[e];
+  }
+  if (p.c_f32) {
+    float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+    if (p.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (FULL || n + e < p.N) c[e] += v[e];
+    } else if (FULL) {
+      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (n + e < p.N) c[e] = v[e];
+    }
+  } else {
+    store8_bf16(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n, n, p.N, FULL, v);
+  }
+}
+
+// Tile epilogue shared by all kernel families.  acc[i][j][r] holds (m = 32j + l31, n = 32i + 8*(r>>2) + 4*g + (r&3)) of
+// the wave's (TM*32) x 64 patch.  Each 32-row slab is transposed through a wave-private fp32 LDS patch [32][64+4] so
+// that a lane then owns 8 consecutive n of one row (16-byte aux loads / C stores).  A lane's column octet is the same
+// for all its rows, so its bias values are loaded once; the residual / act'-aux octets of a slab are all requested
+// BEFORE the slab is transposed so their latency overlaps the LDS traffic instead of serialising 4 loads per slab.
+template <int TM>
+__device__ __forceinline__ void tile_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], char* smem, int wave, int lane,
+                                              int64_t m_base, int64_t n_base, int split) {
+  const bool has_dact = p.dact_aux != nullptr;
+  constexpr int PATCH_LD = 68;  // floats per patch row (272 B: 16-B aligned, 4-bank skew per row)
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PATCH_LD);
+  const int l31 = lane & 31, g = lane >> 5;
+  const int cg = lane & 7, r8 = lane >> 3;            // this lane's column octet and row-in-group
+  const int64_t n = n_base + cg * 8;
+  // whole-tile fast path: every octet of this wave's columns is in range and all pointers are 16-B vectorisable
+  const bool tile_full = (n_base + 64 <= p.N) && p.c_vec && p.aux_vec && p.epi_vec;
+  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tile_full && p.bias && p.split_k <= 1) {
+    if (!p.bias_f32) {
+      unpack8f(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bias) + n), bias8);
+    } else {
+      const float4 b0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n);
+      const float4 b1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n + 4);
+      bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+      bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+  }
+  static_for<TM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int64_t mrow0 = m_base + j * 32 + r8;       // rows mrow0 + 8*it, it = 0..3
+    // one prefetch array: the residual octets if there is a residual, else the act' operand (a launch with both
+    // loads the act' operand late; none of the model's GEMMs has both)
+    uint4 pre[4];
+    if (tile_full && p.split_k <= 1) {                 // request the slab's aux octets now
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t m = mrow0 + 8 * it;
+        const int64_t mc = m < p.M ? m : p.M - 1;
+        if (p.residual) {
+          const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
+          pre[it] = *reinterpret_cast<const uint4*>(p.residual + rr * p.ld_res + n);
+        } else if (has_dact) {
+          pre[it] = *reinterpret_cast<const uint4*>(p.dact_aux + mc * p.ld_dact + n);
+        }
+      }
+    }
+    __syncthreads();  // operand buffers (j = 0) / previous slab (j > 0) no longer read
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        *reinterpret_cast<float4*>(patch + l31 * PATCH_LD + 32 * i + 8 * rq + 4 * g) =
+            make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
+    __syncthreads();
+    if (tile_full && p.split_k <= 1) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + r8;
+        const int64_t m = mrow0 + 8 * it;
+        const float4 lo = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (m < p.M) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+          if (p.preact) {
+            store8_bf16(p.preact + m * p.ld_preact + n, n, p.N, true, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));   // the activation sees the stored (bf16) value
+          }
+          act_fwd8(v, p.act);
+          if (p.has_drop) {
+            const uint32_t rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const uint32_t h = drop_hash_rk(rowkey, (uint32_t)(n + e));
+              v[e] = (h >= p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+            }
+          }
+          if (!p.c_f32 && (has_dact || p.residual)) {   // act' / residual see the rounded branch value (see epilogue_oct)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+          }
+          if (has_dact) {
+            float a[8];
+            uint4 au = pre[it];
+            if (p.residual) au = *reinterpret_cast<const uint4*>(p.dact_aux + m * p.ld_dact + n);
+            unpack8f(au, a);
+            act_bwd8_mul(v, a, p.dact);
+          }
+          if (p.residual) {
+            float a[8];
+            unpack8f(pre[it], a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a[e];
+          }
+          if (p.c_f32) {
+            float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+            if (p.accumulate) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) c[e] += v[e];
+            } else {
+              *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+              *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+          } else {
+            store8_bf16(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n, n, p.N, true, v);
+          }
+        }
+      }
+    } else {                                            // ragged / unaligned tiles and split-K slabs: guarded path
+#pragma unroll 2
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + r8;
+        const int64_t m = mrow0 + 8 * it;
+        if (m < p.M && n < p.N) {
+          const float4 lo = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(patch + row * PATCH_LD + cg * 8 + 4);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          if (tile_full) epilogue_oct<true>(p, m, n, v, split);
+          else epilogue_oct<false>(p, m, n, v, split);
+        }
+      }
+    }
+  });
+}
+
+template <int TM>
+__device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], int lane, int64_t m_base,
+                                             int64_t n_base, int split);
+
+template <class CF, bool A_T, bool B_T, int DBG = 0>
+__global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
+  constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][A|B]
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave % CF::WM, wn = wave / CF::WM;
+  const int l31 = lane & 31, g = lane >> 5;
+
+  // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of tile ids so that
+  // the n-tiles sharing one A row-panel hit the same L2 (bijective form, cdna guide section 5 T1).
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int tile;
+  {
+    const int b = blockIdx.x, q = ntiles / 8, r = ntiles % 8, xcd = b % 8, idx = b / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int split = blockIdx.y;
+  const int64_t k_begin = (int64_t)split * p.k_per_split;
+  const int64_t k_end = (k_begin + p.k_per_split < p.K) ? (k_begin + p.k_per_split) : p.K;
+
+  f32x16 acc[TN][TM];  // [n-subtile i][m-subtile j]
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (int)((k_end - k_begin + BK - 1) / BK);
+  // number of leading K-tiles that are complete (fast path eligible); the ragged tail tile takes the guarded loader
+  const int nk_full = (int)((k_end - k_begin) / BK);
+  const bool a_fast = p.a_vec && (!A_T || m0 + BM <= p.M);
+  const bool b_fast = p.b_vec && (!B_T || n0 + BN <= p.N);
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+  fast_ptrs<A_T, BM>(pa, p.A, p.lda, m0, p.M, k_begin, t);
+  fast_ptrs<B_T, BN>(pb, p.B, p.ldb, n0, p.N, k_begin, t);
+  uint4 ra0[4], rb0[4], ra1[CF::DEEP ? 4 : 1], rb1[CF::DEEP ? 4 : 1];
+  auto load_tile = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
+    const int64_t k0 = k_begin + (int64_t)kt * BK;
+    if (a_fast && kt < nk_full) fast_load<A_T>(ra, pa, p.lda);
+    else stage_load<A_T, BM>(ra, p.A, p.lda, m0, p.M, k0, k_end, p.a_vec, t);
+    if (b_fast && kt < nk_full) fast_load<B_T>(rb, pb, p.ldb);
+    else stage_load<B_T, BN>(rb, p.B, p.ldb, n0, p.N, k0, k_end, p.b_vec, t);
+  };
+  auto store_tile = [&](const uint4 (&ra)[4], const uint4 (&rb)[4], char* buf) {
+    stage_store<A_T, BM>(ra, buf, t);
+    stage_store<B_T, BN>(rb, buf + CF::A_BYTES, t);
+  };
+  auto compute = [&](const char* cur) {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[j] = frag_load<A_T, BM>(cur, wm * (TM * 32) + j * 32 + l31, ks, g);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[i] = frag_load<B_T, BN>(cur + CF::A_BYTES, wn * (TN * 32) + i * 32 + l31, ks, g);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  char* buf0 = smem;
+  char* buf1 = smem + CF::BUF_BYTES;
+  if constexpr (CF::DEEP) {
+    if (nk > 0) {
+      load_tile(0, ra0, rb0);
+      store_tile(ra0, rb0, buf0);
+      if (nk > 1) load_tile(1, ra1, rb1);
+    }
+    __syncthreads();
+    int kt = 0;
+    if (a_fast && b_fast) {
+      // steady state, no conditionals inside: the compiler can then count the 8 newer loads and wait with vmcnt(8)
+      // (a conditional prefetch forces s_waitcnt vmcnt(0) at the join and serialises load latency with the MFMAs)
+      while (kt + 3 < nk_full) {
+        // DBG (ablation builds only): 1 = no global loads / LDS writes, 2 = no MFMAs, 4 = no barriers
+        if (!(DBG & 1)) { fast_load<A_T>(ra0, pa, p.lda); fast_load<B_T>(rb0, pb, p.ldb); }
+        __builtin_amdgcn_sched_barrier(0);  // issue the prefetch BEFORE the MFMAs (the scheduler would sink it)
+        if (!(DBG & 2)) compute(buf0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the ds_writes (and their vmcnt wait) BEHIND the MFMAs
+        if (!(DBG & 1)) store_tile(ra1, rb1, buf1);
+        if (!(DBG & 4)) __syncthreads();
+        if (!(DBG & 1)) { fast_load<A_T>(ra1, pa, p.lda); fast_load<B_T>(rb1, pb, p.ldb); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 2)) compute(buf1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 1)) store_tile(ra0, rb0, buf0);
+        if (!(DBG & 4)) __syncthreads();
+        kt += 2;
+      }
+    }
+    for (; kt < nk; kt += 2) {   // remaining (<= 3 full tiles + ragged tail) and the generic / guarded path
+      if (kt + 2 < nk) load_tile(kt + 2, ra0, rb0);
+      compute(buf0);
+      if (kt + 1 < nk) store_tile(ra1, rb1, buf1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) load_tile(kt + 3, ra1, rb1);
+      compute(buf1);
+      if (kt + 2 < nk) store_tile(ra0, rb0, buf0);
+      __syncthreads();
+    }
+  } else {
+    // one register set: tile kt+1 is loaded while tile kt is multiplied (128 accumulator + 24 fragment registers per
+    // lane leave no room for a second set under the 256-register / 2-waves-per-SIMD budget of a 512-thread workgroup)
+    if (nk > 0) { load_tile(0, ra0, rb0); store_tile(ra0, rb0, buf0); }
+    __syncthreads();
+    int kt = 0;
+    if (a_fast && b_fast) {
+      while (kt + 2 < nk_full) {
+        fast_load<A_T>(ra0, pa, p.lda); fast_load<B_T>(rb0, pb, p.ldb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(ra0, rb0, buf1);
+        __syncthreads();
+        fast_load<A_T>(ra0, pa, p.lda); fast_load<B_T>(rb0, pb, p.ldb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(ra0, rb0, buf0);
+        __syncthreads();
+        kt += 2;
+      }
+    }
+    for (; kt < nk; ++kt) {
+      char* cur = (kt & 1) ? buf1 : buf0;
+      char* nxt = (kt & 1) ? buf0 : buf1;
+      const bool more = kt + 1 < nk;
+      if (more) load_tile(kt + 1, ra0, rb0);
+      compute(cur);
+      if (more) store_tile(ra0, rb0, nxt);
+      __syncthreads();
+    }
+  }
+
+  if (p.direct_store == 3 && p.c_vec && p.aux_vec && p.epi_vec && (p.N & 63) == 0)
+    reg_epilogue<TM>(p, acc, lane, m0 + wm * (TM * 32), n0 + wn * 64, split);
+  else
+    tile_epilogue<TM>(p, acc, smem, wave, lane, m0 + wm * (TM * 32), n0 + wn * 64, split);
+}
+
+// ====================================================================================================
+// Ring kernel: PERSISTENT workgroups, LDS-DMA operand staging (global_load_lds_dwordx4) through a 4-stage LDS ring
+// that never drains between output tiles, and a barrier-free, wave-private epilogue.
+//
+//   work item = (output tile, K split).  grid = min(items, workgroup slots of the chip); workgroup b runs items
+//   it * grid + perm(b), it = 0, 1, ...  (perm puts the workgroups of one XCD on consecutive items, and consecutive
+//   items form compact GH x (32 / GH) blocks of tiles: the 32 workgroups of an XCD share few operand panels in its L2).
+//
+//   stage = K-slice of 32: (BM + BN) x 32 bf16.  The DMA cursor runs PD = 3 stages ahead of the multiply THROUGH item
+//   boundaries: while the last stages of a tile are multiplied and while its epilogue runs, the first stages of the
+//   next tile are already in flight (measured: with one launch per tile the ring fill + C burst of every tile cost
+//   ~19 us per 256-tile round at 20832 x 4096 -- 40 % of a K = 1024 GEMM -- because all CUs do them at the same time).
+//   A wave waits for ITS pieces of a stage with a counted s_waitcnt vmcnt(stages ahead * pieces-per-wave), then ONE
+//   raw s_barrier makes every wave's pieces visible and proves everybody is done with the previous stage, whose
+//   buffer is immediately refilled.  No VGPR staging, no ds_write, no vmcnt(0) in the steady state.  (The counted
+//   waits ignore the epilogue's own loads / stores, which are YOUNGER than the pieces waited for: VMEM operations of
+//   a wave complete in order, so a smaller count only waits longer, never too little.)
+//   k-contiguous operand : LDS rows of 64 B (4 slots of 16 B), k-octet o of row r in slot o ^ ((r>>2)&3)
+//                          (the swizzle is applied on the per-lane GLOBAL address; the LDS image is lane-linear as
+//                          LDS-DMA requires), fragments by conflict-free ds_read_b128.
+//   r-contiguous operand : copied as it is, [32 k][ROWS] (16-B piece (k, ro) in slot ro ^ 4*(k&3) of its k-row), and read
+//                          with the hardware transpose ds_read_b64_tr_b16 (lane i of a 16-lane group receives 4 consecutive k
+//                          of row i; semantics probed on hardware: tests/probes/tr_probe.hip) -- so Conv1D weights and
+//                          the weight-gradient GEMMs need no register transpose either.
+//   epilogue             : bias / activation / dropout in the accumulator layout, then each 32 x 64 slab goes through a
+//                          4-KiB wave-private LDS patch OUTSIDE the ring (as bf16, or as two fp32 halves) so that a
+//                          lane stores 16 contiguous bytes; act'-multiply and residual are applied after the transpose
+//                          on the rounded value (which is what `dropout(linear(x))` then `x + y` do in the reference).
+//                          No workgroup barrier: the ring keeps streaming underneath.
+// Requirements (host falls back to the register-staged kernel otherwise): 16-B-vectorisable operands / outputs,
+// K-range % 32 == 0, r-contiguous operands with rows % tile == 0.
+// ====================================================================================================
+template <int WM_, int WN_, int TM_, int TN_, int NS_, int WPE_, int GH_, int BKS_, int PROWS_>
+struct RCfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVES = WM * WN, NT = NWAVES * 64;
+  static constexpr int BKS = BKS_;           // K-slice per ring stage: 32 (64-B LDS rows) or 64 (128-B rows = whole cache lines
+                                             // of a k-contiguous operand per DMA request)
+  static constexpr int NS = NS_;             // NS ring stages: NS - 1 stages are in flight ahead of the one computed
+  static constexpr int WPE = WPE_;           // waves per SIMD the register budget must allow
+  static constexpr int GH = GH_;             // tile rows per raster group
+  static constexpr int PROWS = PROWS_;       // rows of the epilogue patch: 32 (4 KiB per wave) or 16 (2 KiB, two passes per slab)
+  static constexpr int A_BYTES = BM * BKS * 2, B_BYTES = BN * BKS * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int RING_BYTES = NS * STAGE_BYTES, PATCH_BYTES = PROWS * 128;
+  static constexpr int SMEM_BYTES = RING_BYTES + NWAVES * PATCH_BYTES;
+  static constexpr int WG_PER_CU = (2 * SMEM_BYTES <= 160 * 1024) ? 2 : 1;
+  static constexpr int A_CHUNKS = A_BYTES / 1024, B_CHUNKS = B_BYTES / 1024;
+  static constexpr int CPW = (A_CHUNKS + B_CHUNKS) / NWAVES;   // DMA instructions per wave and stage
+  static_assert((A_CHUNKS + B_CHUNKS) % NWAVES == 0, "chunks must divide evenly over the waves");
+  static_assert(TN == 2, "epilogue slabs are 64 columns wide");
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(NS >= 2 && NS <= 4 && (BKS == 32 || BKS == 64) && (PROWS == 32 || PROWS == 16), "supported shapes");
+  static_assert((NS - 1) * CPW <= 63, "vmcnt is a 6-bit counter");
+};
+using RCfgL = RCfg<2, 4, 4, 2, 4, 2, 4, 32, 32>;    // 256 x 256, BK 32, 8 waves of 128 x 64, 128 + 32 KiB, 1 workgroup / CU
+using RCfgM = RCfg<4, 2, 2, 2, 4, 2, 4, 32, 32>;    // 256 x 128, BK 32, 8 waves of  64 x 64,  96 + 32 KiB, 1 workgroup / CU
+using RCfgS = RCfg<2, 2, 2, 2, 4, 2, 8, 32, 32>;    // 128 x 128, BK 32, 4 waves of  64 x 64,  64 + 16 KiB, 2 workgroups / CU
+using RCfgM64 = RCfg<4, 2, 2, 2, 3, 2, 4, 64, 16>;  // 256 x 128, BK 64, 8 waves of  64 x 64, 144 + 16 KiB, 1 workgroup / CU
+using RCfgL64 = RCfg<2, 4, 4, 2, 2, 2, 4, 64, 32>;  // 256 x 256, BK 64 (whole 128-B lines of a k-contiguous operand), 2 stages, 128 + 32 KiB
+
+// per-lane global source address of chunk c of an operand tile at k0 (the LDS destination of lane l is chunk base + 16 l)
+template <bool TRANS, int ROWS, int BKS>
+__device__ __forceinline__ const bf16_t* dma_src(const bf16_t* __restrict__ P, int64_t ld, int64_t row0, int64_t rows,
+                                                 int64_t k0, int c, int lane) {
+  if (!TRANS) {   // k-contiguous: LDS rows of 2 BKS bytes; chunk c = 1 KiB = 16 (BK 32) or 8 (BK 64) consecutive rows
+    constexpr int LPR = BKS / 8;             // 16-B slots (= lanes) per row
+    const int rl = c * (64 / LPR) + lane / LPR;
+    const int sl = lane % LPR;
+    const int o = (BKS == 32) ? (sl ^ ((rl >> 2) & 3)) : (sl ^ ((rl >> 1) & 7));
+    int64_t row = row0 + rl;
+    row = row < rows ? row : rows - 1;
+    return P + row * ld + k0 + o * 8;
+  } else {        // chunk c = 64 consecutive 16-B pieces of the [k][ROWS] image
+    constexpr int PPR = ROWS / 8;   // pieces per k-row
+    const int piece = c * 64 + lane;
+    const int k = piece / PPR, slot = piece % PPR;
+    const int ro = slot ^ (4 * (k & 3));
+    return P + (k0 + k) * ld + row0 + ro * 8;
+  }
+}
+
+// One LDS-DMA instruction, issued from inline asm so that hipcc does not count it (it would otherwise put an
+// s_waitcnt vmcnt(0) in front of the next ds_read and serialise the ring).  M0 (LDS base of the transfer) is saved and
+// restored inside the statement (cdna guide section 5.7).  lds_dst must be wave-uniform.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// fragment of the 32-row sub-tile starting at tile row `rbase`, k16-step ks (0 .. BKS/16 - 1) of the stage
+template <bool TRANS, int ROWS, int BKS>
+__device__ __forceinline__ bf16x8 ring_frag(const char* lds_oper, int rbase, int ks, int lane) {
+  if (!TRANS) {
+    const int row = rbase + (lane & 31), o = 2 * ks + (lane >> 5);
+    if (BKS == 32) return *reinterpret_cast<const bf16x8*>(lds_oper + row * 64 + ((o ^ ((row >> 2) & 3)) << 4));
+    return *reinterpret_cast<const bf16x8*>(lds_oper + row * 128 + ((o ^ ((row >> 1) & 7)) << 4));
+  } else {
+    const int gi = lane >> 4, c = lane & 15;
+    const int r = rbase + 16 * (gi & 1) + 4 * (c & 3);                 // first of the 4 rows this lane FETCHES
+    union { s16x4 h[2]; bf16x8 v; } u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 16 * ks + 8 * (gi >> 1) + 4 * h + (c >> 2);       // k-row this lane fetches from
+      const int byte = k * (ROWS * 2) + ((((r >> 3) ^ (4 * (c >> 2)))) << 4) + (r & 7) * 2;
+      u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_oper + byte));
+    }
+    return u.v;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// work item -> (tile origin, K range).  Consecutive ids sweep groups of GH tile rows column by column.
+struct RingItem { int64_t m0, n0, k_begin; int ns, split; };
+template <class RC>
+__device__ __forceinline__ RingItem ring_item(const GemmKArgs& p, int id) {
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int split = id / ntiles, tile = id - split * ntiles;
+  const int per_panel = RC::GH * p.tiles_n;
+  const int panel = tile / per_panel, r = tile - panel * per_panel;
+  const int left = p.tiles_m - panel * RC::GH;
+  const int gh = left < RC::GH ? left : RC::GH;
+  const int tn = r / gh, tm = panel * RC::GH + (r - tn * gh);
+  RingItem it;
+  it.m0 = (int64_t)tm * RC::BM; it.n0 = (int64_t)tn * RC::BN; it.split = split;
+  it.k_begin = (int64_t)split * p.k_per_split;
+  const int64_t k_end = (it.k_begin + p.k_per_split < p.K) ? (it.k_begin + p.k_per_split) : p.K;
+  it.ns = (int)((k_end - it.k_begin) / RC::BKS);   // K range % BKS == 0 (ring_ok)
+  return it;
+}
+
+// patch addressing (wave-private 4 KiB): bf16 image = 32 rows x 16 units of 8 B, unit u of row r at u ^ (r & 15);
+// fp32 half-slab image = 32 rows x 8 units of 16 B, unit u of row r at u ^ (r & 7).
+__device__ __forceinline__ int patch_bf16(int row, int unit) { return row * 128 + ((unit ^ (row & 15)) << 3); }
+__device__ __forceinline__ int patch_f32(int row, int unit) { return row * 128 + ((unit ^ (row & 7)) << 4); }
+
+// Epilogue of one wave: (TM*32) x 64 block at (m_base, n_base).  acc[i][j][r] = element (m = 32j + l31,
+// n = 32i + 8*(r>>2) + 4*g + (r&3)).  Requires c_vec / aux_vec / epi_vec and N % 64 == 0 (ring_ok): only rows beyond M
+// need guards.
+template <int TM, int PROWS>
+__device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], char* patch, int lane,
+                                              int64_t m_base, int64_t n_base, int split) {
+  constexpr int NH = 32 / PROWS, NIT = PROWS / 8;   // patch passes per 32-row slab, 8-row store groups per pass
+  const int l31 = lane & 31, g = lane >> 5;
+  const int cg = lane & 7, r8 = lane >> 3;
+  const int lrow = l31 & (PROWS - 1);               // this lane's row inside the patch
+  const bool split_out = p.split_k > 1;
+  const bool has_dact = p.dact_aux != nullptr, has_res = p.residual != nullptr;
+  if (n_base >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
+
+  const bool f32_out = split_out || p.c_f32;
+  static_for<TM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int64_t m_acc = m_base + j * 32 + l31;           // this lane's row in the accumulator layout
+    const int64_t ms0 = m_base + j * 32 + r8;              // store layout: rows ms0 + PROWS*hh + 8*it
+    uint32_t rowkey = 0;
+    if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m_acc);
+
+    // ---- stage A (accumulator layout, fp32), evaluated per group of 4 columns right before it is written to the
+    // patch so that only four values are live: bias -> (round, if the pre-activation tensor is written) -> activation
+    // -> dropout ----
+    auto biased = [&](int i, int rq, float (&z)[4]) {
+      const int64_t n = n_base + 32 * i + 8 * rq + 4 * g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = acc[i][j][4 * rq + e];
+      if (!split_out && p.bias) {
+        if (p.bias_f32) {
+          const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n);
+          z[0] += b.x; z[1] += b.y; z[2] += b.z; z[3] += b.w;
+        } else {
+          const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.bias) + n);
+          z[0] += bf2f((bf16_t)(b.x & 0xffff)); z[1] += bf2f((bf16_t)(b.x >> 16));
+          z[2] += bf2f((bf16_t)(b.y & 0xffff)); z[3] += bf2f((bf16_t)(b.y >> 16));
+        }
+      }
+    };
+    auto finished = [&](int i, int rq, float (&z)[4]) {
+      biased(i, rq, z);
+      if (split_out) return;
+      if (p.preact) {   // the activation sees the stored (bf16) pre-activation
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = bf2f(f2bf(z[e]));
+      }
+      act_fwd4(z, p.act);
+      if (p.has_drop) {
+        const uint32_t n = (uint32_t)(n_base + 32 * i + 8 * rq + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t h = drop_hash_rk(rowkey, n + e);
+          z[e] = (h >= p.drop_thr) ? z[e] * p.drop_scale : 0.f;
+        }
+      }
+    };
+    if (!split_out && p.preact) {
+      // pre-activation tensor: same transposition as the bf16 output below
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        if (PROWS == 32 || (l31 >> 4) == hh) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              float z[4];
+              biased(i, rq, z);
+              *reinterpret_cast<uint2*>(patch + patch_bf16(lrow, 8 * i + 2 * rq + g)) =
+                  make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+            }
+        }
+        wait_lds();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int R = it * 8 + r8;
+          const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
+          const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
+          const int64_t m = ms0 + hh * PROWS + 8 * it;
+          if (m < p.M) *reinterpret_cast<uint4*>(p.preact + m * p.ld_preact + n_base + 8 * cg) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        wait_lds();
+      }
+    }
+
+    if (!f32_out && !has_res && !has_dact && (p.direct_store == 1 || (p.direct_store == 2 && TM == 4))) {
+      // ---- plain bf16 output of the 256x256 tile: 8-byte stores straight from the accumulator layout (32 rows x 16 B per
+      // instruction; the L2 merges the partial lines).  Measured on MI355X at 20832x4096: K = 64 launch 105.6 -> 75.3 us,
+      // K = 1024 265.5 -> 223.0 us for the 256x256 tile (whose 4 slabs per wave at 256 VGPRs make the patch path slow),
+      // but 60 -> 80 us for the 256x128 / 128x128 tiles, which therefore keep the transposition. ----
+      if (m_acc < p.M) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            float z[4];
+            finished(i, rq, z);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + m_acc * p.ldc + n_base + 32 * i + 8 * rq + 4 * g) =
+                make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+          }
+      }
+    } else if (!f32_out) {
+      // ---- bf16 output: prefetch the store-layout operands, transpose the slab as bf16, finish, store 16 B / lane ----
+      uint4 pre[4];
+      if (has_res || has_dact) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int64_t m = ms0 + (q4 / NIT) * PROWS + (q4 % NIT) * 8;
+          const int64_t mc = m < p.M ? m : p.M - 1;
+          if (has_res) {
+            const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
+            pre[q4] = *reinterpret_cast<const uint4*>(p.residual + rr * p.ld_res + n_base + 8 * cg);
+          } else {
+            pre[q4] = *reinterpret_cast<const uint4*>(p.dact_aux + mc * p.ld_dact + n_base + 8 * cg);
+          }
+        }
+      }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        if (PROWS == 32 || (l31 >> 4) == hh) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              float z[4];
+              finished(i, rq, z);
+              *reinterpret_cast<uint2*>(patch + patch_bf16(lrow, 8 * i + 2 * rq + g)) =
+                  make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+            }
+        }
+        wait_lds();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int R = it * 8 + r8;
+          const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
+          const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
+          uint4 out = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          const int64_t m = ms0 + hh * PROWS + 8 * it;
+          if (has_res || has_dact) {
+            float o[8], a[8];
+            unpack8f(out, o);
+            if (has_dact) {
+              uint4 au = pre[hh * NIT + it];
+              if (has_res) au = *reinterpret_cast<const uint4*>(p.dact_aux + (m < p.M ? m : p.M - 1) * p.ld_dact + n_base + 8 * cg);
+              unpack8f(au, a);
+              act_bwd8_mul(o, a, p.dact);
+            }
+            if (has_res) {
+              unpack8f(pre[hh * NIT + it], a);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] += a[e];
+            }
+            out = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+          }
+          if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n_base + 8 * cg) = out;
+        }
+        wait_lds();
+      }
+    } else {
+      // ---- fp32 output (fp32 C, accumulation, split-K partial sums): 32-column halves through the patch ----
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+          if (PROWS == 32 || (l31 >> 4) == hh) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              float z[4];
+              finished(i, rq, z);
+              *reinterpret_cast<float4*>(patch + patch_f32(lrow, 2 * rq + g)) = make_float4(z[0], z[1], z[2], z[3]);
+            }
+          }
+          wait_lds();
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int R = it * 8 + r8;
+            float4 o = *reinterpret_cast<const float4*>(patch + patch_f32(R, cg));
+            const int64_t m = m_base + j * 32 + hh * PROWS + R;
+            const int64_t n = n_base + 32 * i + 4 * cg;
+            if (m < p.M) {
+              if (split_out) {
+                *reinterpret_cast<float4*>(p.workspace + ((int64_t)split * p.M + m) * p.N + n) = o;
+              } else {
+                if (has_dact) {
+                  const uint2 a = *reinterpret_cast<const uint2*>(p.dact_aux + m * p.ld_dact + n);
+                  o.x *= act_bwd(bf2f((bf16_t)(a.x & 0xffff)), p.dact); o.y *= act_bwd(bf2f((bf16_t)(a.x >> 16)), p.dact);
+                  o.z *= act_bwd(bf2f((bf16_t)(a.y & 0xffff)), p.dact); o.w *= act_bwd(bf2f((bf16_t)(a.y >> 16)), p.dact);
+                }
+                if (has_res) {
+                  const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
+                  const uint2 a = *reinterpret_cast<const uint2*>(p.residual + rr * p.ld_res + n);
+                  o.x += bf2f((bf16_t)(a.x & 0xffff)); o.y += bf2f((bf16_t)(a.x >> 16));
+                  o.z += bf2f((bf16_t)(a.y & 0xffff)); o.w += bf2f((bf16_t)(a.y >> 16));
+                }
+                float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n);
+                if (p.accumulate) { const float4 old = *c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                *c = o;
+              }
+            }
+          }
+          wait_lds();
+        }
+      }
+    }
+  });
+}
+
+
+// ---- register-only epilogue (no LDS, no waits): the accumulator layout already holds 4 consecutive n per lane and
+// quad; one v_permlane32_swap per packed dword exchanges the quads of column groups (2q, 2q+1) between the two half-waves
+// so that a lane ends up with 8 consecutive bf16 (16 B) of its row:
+//     lanes  0..31 : [own quad 2q   | upper half's quad 2q  ]  -> columns 32i + 16q + 0..7
+//     lanes 32..63 : [lower's 2q+1  | own quad 2q+1         ]  -> columns 32i + 16q + 8..15
+// (cdna guide T21).  The same exchange maps a 16-byte load of a store-layout operand (residual, act' operand) back to
+// the accumulator layout, so bias / activation / dropout / act' / residual are all evaluated in registers.  fp32
+// outputs need no exchange at all (a quad is already 16 B).  One store instruction covers 32 rows x 32 B; the four
+// stores of a (32-row, 64-column) slab complete its 128-byte lines in the L2.
+__device__ __forceinline__ void swap_halves(uint32_t& lo_grp, uint32_t& hi_grp) {
+  const auto r = __builtin_amdgcn_permlane32_swap(lo_grp, hi_grp, false, false);
+  lo_grp = r[0]; hi_grp = r[1];
+}
+__device__ __forceinline__ void unpack2(uint32_t u, float& a, float& b) { a = bf2f((bf16_t)(u & 0xffff)); b = bf2f((bf16_t)(u >> 16)); }
+
+template <int TM>
+__device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], int lane, int64_t m_base,
+                                             int64_t n_base, int split) {
+  const int l31 = lane & 31, g = lane >> 5;
+  if (n_base >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
+  const bool split_out = p.split_k > 1;
+  const bool f32_out = split_out || p.c_f32;
+  const bool has_dact = p.dact_aux != nullptr, has_res = p.residual != nullptr;
+  const bool has_bias = !split_out && p.bias != nullptr;
+
+  // bias of this lane's 32 columns, packed bf16 pairs (fp32 bias vectors are read per use: rare)
+  uint32_t bias_pk[2][4][2];
+  if (has_bias && !p.bias_f32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
+        bias_pk[i][rq][0] = b.x; bias_pk[i][rq][1] = b.y;
+      }
+  }
+  static_for<TM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int64_t m = m_base + j * 32 + l31;
+    const bool row_ok = m < p.M;
+    const int64_t mc = row_ok ? m : p.M - 1;
+    uint32_t rowkey = 0;
+    if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
+
+    auto biased = [&](int i, int rq, float (&z)[4]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = acc[i][j][4 * rq + e];
+      if (has_bias) {
+        if (p.bias_f32) {
+          const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
+          z[0] += b.x; z[1] += b.y; z[2] += b.z; z[3] += b.w;
+        } else {
+          float b0, b1, b2, b3;
+          unpack2(bias_pk[i][rq][0], b0, b1); unpack2(bias_pk[i][rq][1], b2, b3);
+          z[0] += b0; z[1] += b1; z[2] += b2; z[3] += b3;
+        }
+      }
+    };
+    auto act_drop = [&](int i, int rq, float (&z)[4]) {
+      act_fwd4(z, p.act);
+      if (p.has_drop) {
+        const uint32_t n = (uint32_t)(n_base + 32 * i + 8 * rq + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t h = drop_hash_rk(rowkey, n + e);
+          z[e] = (h >= p.drop_thr) ? z[e] * p.drop_scale : 0.f;
+        }
+      }
+    };
+
+    if (f32_out) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float z[4];
+          biased(i, rq, z);
+          const int64_t n = n_base + 32 * i + 8 * rq + 4 * g;
+          if (split_out) {
+            if (row_ok) *reinterpret_cast<float4*>(p.workspace + ((int64_t)split * p.M + m) * p.N + n) = make_float4(z[0], z[1], z[2], z[3]);
+            continue;
+          }
+          if (p.preact) {
+            if (row_ok) *reinterpret_cast<uint2*>(p.preact + m * p.ld_preact + n) = make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = bf2f(f2bf(z[e]));
+          }
+          act_drop(i, rq, z);
+          if (has_dact) {
+            const uint2 a = *reinterpret_cast<const uint2*>(p.dact_aux + mc * p.ld_dact + n);
+            float a0, a1, a2, a3;
+            unpack2(a.x, a0, a1); unpack2(a.y, a2, a3);
+            z[0] *= act_bwd(a0, p.dact); z[1] *= act_bwd(a1, p.dact); z[2] *= act_bwd(a2, p.dact); z[3] *= act_bwd(a3, p.dact);
+          }
+          if (has_res) {
+            const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
+            const uint2 a = *reinterpret_cast<const uint2*>(p.residual + rr * p.ld_res + n);
+            float a0, a1, a2, a3;
+            unpack2(a.x, a0, a1); unpack2(a.y, a2, a3);
+            z[0] += a0; z[1] += a1; z[2] += a2; z[3] += a3;
+          }
+          if (row_ok) {
+            float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n);
+            float4 o = make_float4(z[0], z[1], z[2], z[3]);
+            if (p.accumulate) { const float4 old = *c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+            *c = o;
+          }
+        }
+      return;
+    }
+
+    // ---- bf16 output ----
+    // store-layout operands of this 32-row slab: requested up front (8 x 16 B per lane) so that their latency overlaps
+    // the activation arithmetic
+    uint4 aux[2][2];
+    const bool two_aux = has_dact && has_res;   // none of the model's GEMMs has both: the act' operand is then read late
+    if (has_res || has_dact) {
+      const int64_t rr = (has_res && p.res_rows > 0) ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
+      const bf16_t* src = has_res ? p.residual + rr * p.ld_res : p.dact_aux + mc * p.ld_dact;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) aux[i][q] = *reinterpret_cast<const uint4*>(src + n_base + 32 * i + 16 * q + 8 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int64_t ncol = n_base + 32 * i + 16 * q + 8 * g;   // this lane's 16 bytes in the store layout
+        float z0[4], z1[4];
+        biased(i, 2 * q, z0);
+        biased(i, 2 * q + 1, z1);
+        if (p.preact) {
+          uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
+          // the activation sees the stored (bf16) pre-activation
+          unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
+          swap_halves(a0, b0); swap_halves(a1, b1);
+          if (row_ok) *reinterpret_cast<uint4*>(p.preact + m * p.ld_preact + ncol) = make_uint4(a0, a1, b0, b1);
+        }
+        act_drop(i, 2 * q, z0);
+        act_drop(i, 2 * q + 1, z1);
+        uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
+        if (has_res || has_dact) {
+          // act' / residual are applied to the ROUNDED branch value (the reference materialises it as a bf16 tensor)
+          unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
+          if (has_dact) {
+            uint4 u = aux[i][q];
+            if (two_aux) u = *reinterpret_cast<const uint4*>(p.dact_aux + mc * p.ld_dact + ncol);
+            swap_halves(u.x, u.z); swap_halves(u.y, u.w);   // -> accumulator layout: (x, y) = quad 2q, (z, w) = quad 2q+1
+            float x0[4], x1[4];
+            unpack2(u.x, x0[0], x0[1]); unpack2(u.y, x0[2], x0[3]); unpack2(u.z, x1[0], x1[1]); unpack2(u.w, x1[2], x1[3]);
+            float v8[8] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3]};
+            const float a8[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            act_bwd8_mul(v8, a8, p.dact);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { z0[e] = v8[e]; z1[e] = v8[4 + e]; }
+          }
+          if (has_res) {
+            uint4 u = aux[i][q];
+            swap_halves(u.x, u.z); swap_halves(u.y, u.w);
+            float r0, r1;
+            unpack2(u.x, r0, r1); z0[0] += r0; z0[1] += r1;
+            unpack2(u.y, r0, r1); z0[2] += r0; z0[3] += r1;
+            unpack2(u.z, r0, r1); z1[0] += r0; z1[1] += r1;
+            unpack2(u.w, r0, r1); z1[2] += r0; z1[3] += r1;
+          }
+          a0 = pack2bf(z0[0], z0[1]); a1 = pack2bf(z0[2], z0[3]); b0 = pack2bf(z1[0], z1[1]); b1 = pack2bf(z1[2], z1[3]);
+        }
+        swap_halves(a0, b0); swap_halves(a1, b1);
+        if (row_ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + ncol) = make_uint4(a0, a1, b0, b1);
+      }
+  });
+}
+
+template <class RC, bool A_T, bool B_T>
+__global__ __launch_bounds__(RC::NT) __attribute__((amdgpu_waves_per_eu(RC::WPE, RC::WPE)))
+void gemm_ring_kernel(GemmKArgs p) {
+  constexpr int BM = RC::BM, BN = RC::BN, TM = RC::TM, TN = RC::TN, CPW = RC::CPW, NS = RC::NS, PD = RC::NS - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave % RC::WM, wn = wave / RC::WM;
+
+  const int nitems = p.tiles_m * p.tiles_n * p.split_k;
+  const int grid = gridDim.x;
+  // workgroup b sits on XCD b % 8: give each XCD a run of consecutive items
+  const int perm = (grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  auto item_of = [&](int it) -> int {   // item of iteration `it`, or -1
+    const int id = it * grid + perm;
+    return id < nitems ? id : -1;
+  };
+
+  // ---- DMA cursor: per-wave plan of CPW pieces per stage (fixed operand / chunk per slot i), per-lane source pointers
+  // that advance by one stage (32 k) per issue; destinations are wave-uniform byte offsets inside a stage buffer. ----
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const bf16_t* src[CPW];
+  int64_t step[CPW];
+  uint32_t dst[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int q = wave * CPW + i;   // wave-uniform
+    if (q < RC::A_CHUNKS) {
+      step[i] = A_T ? (int64_t)RC::BKS * p.lda : (int64_t)RC::BKS;
+      dst[i] = (uint32_t)(q * 1024);
+    } else {
+      step[i] = B_T ? (int64_t)RC::BKS * p.ldb : (int64_t)RC::BKS;
+      dst[i] = (uint32_t)(RC::A_BYTES + (q - RC::A_CHUNKS) * 1024);
+    }
+  }
+  int cur_it = 0, cur_s = 0, cur_ns = 0;   // cursor: item iteration, stage inside it, stages of it
+  bool cur_live = false;
+  auto cursor_open = [&](int it) {
+    const int id = item_of(it);
+    cur_live = id >= 0;
+    if (!cur_live) return;
+    const RingItem w = ring_item<RC>(p, id);
+    cur_ns = w.ns; cur_s = 0;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int q = wave * CPW + i;
+      src[i] = (q < RC::A_CHUNKS) ? dma_src<A_T, BM, RC::BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, q, lane)
+                                  : dma_src<B_T, BN, RC::BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, q - RC::A_CHUNKS, lane);
+    }
+  };
+  int islot = 0, inflight = 0;             // ring slot of the next issue; stages issued and not yet consumed
+  auto issue_next = [&]() {
+    if (!cur_live) return;
+    const uint32_t st = smem_base + (uint32_t)(islot * RC::STAGE_BYTES);
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      glds16(src[i], __builtin_amdgcn_readfirstlane(st + dst[i]));
+      src[i] += step[i];
+    }
+    islot = (islot + 1 == NS) ? 0 : islot + 1;
+    ++inflight;
+    if (++cur_s == cur_ns) cursor_open(++cur_it);
+  };
+  cursor_open(0);
+#pragma unroll
+  for (int d = 0; d < PD; ++d) issue_next();
+
+  char* patch = smem + RC::RING_BYTES + wave * RC::PATCH_BYTES;
+  int cslot = 0;
+  for (int it = 0;; ++it) {
+    const int id = item_of(it);
+    if (id < 0) break;
+    const RingItem w = ring_item<RC>(p, id);
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int s = 0; s < w.ns; ++s) {
+      // this wave's pieces of the oldest stage in flight have landed; the younger ones stay in flight
+      if (PD >= 3 && inflight >= 3) wait_vmcnt<(PD >= 3 ? 2 : 0) * CPW>();
+      else if (PD >= 2 && inflight == 2) wait_vmcnt<(PD >= 2 ? 1 : 0) * CPW>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // everybody's pieces are visible; everybody is done with the previous stage
+      __builtin_amdgcn_sched_barrier(0);
+      --inflight;
+      issue_next();                    // refills the previous stage's buffer (possibly with the NEXT item's data)
+      __builtin_amdgcn_sched_barrier(0);
+      const char* st = smem + cslot * RC::STAGE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < RC::BKS / 16; ++ks) {
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fa[j] = ring_frag<A_T, BM, RC::BKS>(st, wm * (TM * 32) + j * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fb[i] = ring_frag<B_T, BN, RC::BKS>(st + RC::A_BYTES, wn * (TN * 32) + i * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      cslot = (cslot + 1 == NS) ? 0 : cslot + 1;
+    }
+    if (p.direct_store == 3) reg_epilogue<TM>(p, acc, lane, w.m0 + wm * (TM * 32), w.n0 + wn * 64, w.split);
+    else ring_epilogue<TM, RC::PROWS>(p, acc, patch, lane, w.m0 + wm * (TM * 32), w.n0 + wn * 64, w.split);
+  }
+}
+
+inline int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <class CF, bool A_T, bool B_T, int DBG = 0>
+void launch_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = &gemm_kernel<CF, A_T, B_T, DBG>;
+  if (!attr_set) {  // > 64 KiB of LDS per workgroup needs the opt-in (160 KiB per CU on gfx950)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM_BYTES);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)split_k, 1), block(CF::NT, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, CF::SMEM_BYTES, stream, a);
+}
+
+template <class RC, bool A_T, bool B_T>
+void launch_ring_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = &gemm_ring_kernel<RC, A_T, B_T>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RC::SMEM_BYTES);
+    attr_set = true;
+  }
+  const int64_t items = (int64_t)a.tiles_m * a.tiles_n * split_k;
+  const int64_t slots = (int64_t)num_cus() * RC::WG_PER_CU;
+  dim3 grid((unsigned)(items < slots ? items : slots), 1, 1), block(RC::NT, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, RC::SMEM_BYTES, stream, a);
+}
+
+}  // namespace dvla_gemm

@@ -120,7 +120,7 @@ class GemmProfiler:
         return False
 
     def summary(self, kernel=None):
-        """all launches, or only the ones run by `kernel` ("hip": the hand-written kernels, "library": hipBLASLt)"""
+        """all launches (every one is a hand-written kernel; `kernel` is kept for the breakdown's column)"""
         torch.cuda.synchronize()
         recs = [r for r, sh in zip(self.records, self.shapes) if kernel is None or sh[6] == kernel]
         total_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
@@ -133,32 +133,25 @@ class GemmProfiler:
 class GemmTuner:
     """Online choice of the GEMM kernel configuration per problem key (like a convolution autotuner).
 
-    include/dvla.h exposes the configurations through `dvla_set_gemm_variant` (0 = the library's cost model, 2 =
-    register-staged 128x128, 4 / 5 / 6 = LDS-DMA ring 256x256 / 256x128 / 128x128; they differ only in fp32 summation
-    order).  Which one is fastest depends on more than (M, N, K): the epilogue, what the neighbouring kernels left in
-    L2 / Infinity Cache, the clocks.  So the first calls of every key run the candidates IN TURN -- each real call is
-    executed exactly once, with one candidate, bracketed by two events that are read back later without a host sync --
-    and once every candidate has `ROUNDS` finished timing(s) the key is locked to the best one.  A forced variant that
-    does not apply to a shape falls back to the register-staged kernel inside the library, so every trial is valid.
-    Disable with DVLA_GEMM_AUTOTUNE=0 (the library's cost model is then used for every call)."""
+    include/dvla.h exposes the configurations of the hand-written kernels through `dvla_set_gemm_variant` (0 = the
+    library's cost model, 2 = register-staged 128x128, 4 / 5 / 6 = LDS-DMA ring 256x256 / 256x128 / 128x128; they differ
+    only in fp32 summation order).  Which one is fastest depends on more than (M, N, K): the epilogue, what the
+    neighbouring kernels left in L2 / Infinity Cache, the clocks.  So the first calls of every key run the candidates IN
+    TURN -- each real call is executed exactly once, with one candidate, bracketed by two events that are read back later
+    without a host sync -- and once every candidate has `ROUNDS` finished timing(s) the key is locked to the best one
+    (median).  A forced variant that does not apply to a shape falls back to the register-staged kernel inside the
+    library, so every trial is valid.  Disable with DVLA_GEMM_AUTOTUNE=0 (the cost model is then used for every call).
+    Every candidate is a hand-written HIP kernel of libdvla_hip.so: no vendor GEMM library is linked or offered (the
+    hipBLASLt yardstick lives in libdvla_cmp.so and is driven only by tests/library_yardstick.py)."""
     CANDIDATES = tuple(int(v) for v in os.environ.get("DVLA_GEMM_CANDIDATES", "0,4,5,6,2").split(","))
-    LIBRARY = 8     # hipBLASLt through dvla_gemm_library_bf16: offered for plain / bias-only GEMMs (plain=True)
-    ROUNDS = int(os.environ.get("DVLA_GEMM_TUNE_ROUNDS", "1"))
+    ROUNDS = int(os.environ.get("DVLA_GEMM_TUNE_ROUNDS", "2"))
     enabled = os.environ.get("DVLA_GEMM_AUTOTUNE", "1") != "0" and os.environ.get("DVLA_GEMM_VARIANT") is None
-    library = os.environ.get("DVLA_GEMM_LIBRARY", "1") != "0"
     table = {}      # key -> locked variant
     trials = {}     # key -> {"pending": [(variant, e0, e1)], "times": {variant: [ms]}, "next": int}
-    banned = set()  # keys on which the library candidate failed (no kernel / no workspace): never offered again
     frozen = False  # True (hipGraph capture / replay-critical sections): no trials, no events -- locked choice or the cost model
 
     @classmethod
-    def candidates(cls, key, plain):
-        if plain and cls.library and key not in cls.banned:
-            return cls.CANDIDATES + (cls.LIBRARY,)
-        return cls.CANDIDATES
-
-    @classmethod
-    def pick(cls, key, plain=False):
+    def pick(cls, key):
         v = cls.table.get(key)
         if v is not None:
             return v, None
@@ -166,7 +159,7 @@ class GemmTuner:
             return 0, None
         st = cls.trials.get(key)
         if st is None:
-            st = cls.trials[key] = {"pending": [], "times": {c: [] for c in cls.candidates(key, plain)}, "next": 0}
+            st = cls.trials[key] = {"pending": [], "times": {c: [] for c in cls.CANDIDATES}, "next": 0}
         still = []
         for (var, e0, e1) in st["pending"]:
             if e1.query():
@@ -186,46 +179,23 @@ class GemmTuner:
         return var, st
 
     @classmethod
-    def ban_library(cls, key):
-        """the library candidate could not run this problem: drop it from the key's trial (or its lock)"""
-        cls.banned.add(key)
-        st = cls.trials.get(key)
-        if st is not None:
-            st["times"].pop(cls.LIBRARY, None)
-        if cls.table.get(key) == cls.LIBRARY:
-            del cls.table[key]
-
-    @classmethod
     def reset(cls):
-        cls.table.clear(); cls.trials.clear(); cls.banned.clear()
+        cls.table.clear(); cls.trials.clear()
 
     @classmethod
     def summary(cls):
         """how many problem keys each configuration won (bench.py reports it next to the roofline)"""
         out = {}
         for v in cls.table.values():
-            name = "library" if v == cls.LIBRARY else f"hip:{v}"
-            out[name] = out.get(name, 0) + 1
+            out[f"hip:{v}"] = out.get(f"hip:{v}", 0) + 1
         return out
-
-
-_LIB_WS = {}
-
-
-def _library_workspace(device):
-    """one 64-MiB scratch buffer per (device, stream) for hipBLASLt's own split-K; kernels of a stream run in order"""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _LIB_WS.get(key)
-    if ws is None:
-        ws = _LIB_WS[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
-    return ws
 
 
 def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=False, dact_aux=None, dact=0,
          dropout_p=0.0, seed=(0, 0), residual=None, res_rows=0, out_dtype=BF16, out=None, accumulate=False, split_k=1,
          variant=None):
-    """C[M,N] = epilogue(A . B^T); see include/dvla.h.  `variant` forces a kernel configuration (tests / sweeps;
-    GemmTuner.LIBRARY = hipBLASLt, epilogue-free problems only) instead of asking the tuner.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
+    """C[M,N] = epilogue(A . B^T); see include/dvla.h.  `variant` forces a kernel configuration (tests / sweeps)
+    instead of asking the tuner.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
     Returns C (and the pre-activation tensor if want_preact)."""
     lib = _lib.load()
     _req(a, "gemm.a"); _req(b, "gemm.b")
@@ -277,7 +247,7 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     p.accumulate = int(accumulate)
     p.split_k = max(1, int(split_k))
     prof = GemmProfiler.active
-    # "plain": nothing but (optionally) the bias vector rides on the GEMM -- what the library candidate may take
+    # "plain": nothing but (optionally) the bias vector rides on the GEMM (reported per shape by the profiler)
     plain = (act == 0 and not want_preact and dact_aux is None and residual is None and dropout_p == 0.0
              and not (bias is not None and accumulate))
     trial, key = None, None
@@ -287,48 +257,28 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
         key = (M, N, K, int(a_trans), int(b_trans), int(p.split_k), int(act), int(dact),
                bias is not None, want_preact, dact_aux is not None, residual is not None,
                dropout_p > 0.0, out.dtype == torch.float32, bool(accumulate))
-        variant, trial = GemmTuner.pick(key, plain)
-    ran_library = False
-    lws = None
-    if variant == GemmTuner.LIBRARY:
-        lws = _library_workspace(a.device)
-        p.split_k = 1                      # the library splits K itself, inside its workspace
-        if trial is not None and not accumulate:
-            # the library loads its kernel lazily on the first call of a problem: run the (idempotent) trial call once
-            # un-timed so the timed one measures the kernel, as it does for the in-library candidates
-            lib.dvla_gemm_library_bf16(C.byref(p), lws.data_ptr(), lws.numel(), _stream())
+        variant, trial = GemmTuner.pick(key)
     if prof is not None or trial is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if variant == GemmTuner.LIBRARY:
-        rc = lib.dvla_gemm_library_bf16(C.byref(p), lws.data_ptr(), lws.numel(), _stream())
-        if rc == 0:
-            ran_library = True
-        elif forced:
-            check(rc, "dvla_gemm_library_bf16")
-        else:                              # no library kernel for this problem: never offer it again, run ours now
-            GemmTuner.ban_library(key)
-            variant, trial = 0, None
-            p.split_k = max(1, int(split_k))
-    if not ran_library:
-        ws = None
-        if p.split_k > 1:
-            ws = torch.empty((p.split_k, M, N), dtype=torch.float32, device=a.device)
-            p.workspace = ws.data_ptr()
+    ws = None
+    if p.split_k > 1:
+        ws = torch.empty((p.split_k, M, N), dtype=torch.float32, device=a.device)
+        p.workspace = ws.data_ptr()
+    if variant:
+        lib.dvla_set_gemm_variant(variant)
+    try:
+        check(lib.dvla_gemm_bf16(C.byref(p), _stream()), "dvla_gemm_bf16")
+    finally:
         if variant:
-            lib.dvla_set_gemm_variant(variant)
-        try:
-            check(lib.dvla_gemm_bf16(C.byref(p), _stream()), "dvla_gemm_bf16")
-        finally:
-            if variant:
-                lib.dvla_set_gemm_variant(0)
+            lib.dvla_set_gemm_variant(0)
     if prof is not None or trial is not None:
         e1.record()
     if trial is not None:
         trial["pending"].append((variant, e0, e1))
     if prof is not None:
         prof.records.append((e0, e1, 2.0 * M * N * K))
-        prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k), "library" if ran_library else "hip",
+        prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k), "hip",
                             int(variant), ("bias" if bias is not None else "plain") if plain else "fused"))
     return (out, preact) if want_preact else out
 

@@ -68,16 +68,6 @@ int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
  * builds (wrong results by design, timing only).  Variants 0..6 differ only in fp32 summation order. */
 void dvla_set_gemm_variant(int variant);
 
-/* Library GEMM (hipBLASLt) on the same parameter block: C = A . B^T (+ bias[n], the library's own bias epilogue)
- * (C += when accumulate, fp32 C, no bias).  A *comparator and tuner candidate* for the plain GEMMs of the step -- weight
- * gradients dW = X^T dY and input gradients dX = dY W of nn.Linear / Conv1D (autograd of models/gpt2.py:160,172-173,
- * 296-301, timm Block Linear layers) and the bias-only projections (qkv: timm Attention, gpt2.py c_attn) -- never for a
- * GEMM fused with an activation / act' / dropout / residual / pre-activation store: any act / preact / dact / dropout /
- * residual / split_k > 1 in `p` returns DVLA_ERR_UNSUPPORTED (-3), as does a problem the library has no kernel for within
- * `workspace_bytes`.  `workspace` is caller-owned device memory the library may use for its own split-K (may be NULL
- * with 0 bytes). */
-int dvla_gemm_library_bf16(const dvla_gemm_params* p, void* workspace, int64_t workspace_bytes, void* stream);
-
 /* ---------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (rows x cols, bf16 in/out, fp32 statistics).
  * gamma/beta may be NULL (DiT elementwise_affine=False, action_model/models.py:129-131,148).

@@ -1,0 +1,278 @@
+// gemm_probe.cpp -- standalone (no torch) timing + correctness probe of dvla_gemm_bf16 through the C ABI.
+// Measurement infrastructure, not product.  Build (tests/probes/build_probes.sh):
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 tests/probes/gemm_probe.cpp -o build/gemm_probe -Ldreamvla_amd -ldvla_hip \
+//         -Wl,-rpath,'$ORIGIN/../dreamvla_amd'
+// Usage: gemm_probe [--variants 0,2,4,...] [--iters N] [--check-only] [--cases model|small|big]
+// For every case: a small-shape correctness pass of each variant against a naive fp32 device reference that restates the
+// epilogue of include/dvla.h (exact erf / tanh), then paired timing rounds (variants interleaved in one process, median
+// and min reported -- cdna guide section 5.4 rule 24).  One JSON object per line on stdout.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/dvla.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+typedef unsigned short bf16_t;
+__host__ __device__ static inline float bf2f(bf16_t h) { union { uint32_t u; float f; } v; v.u = ((uint32_t)h) << 16; return v.f; }
+__host__ __device__ static inline bf16_t f2bf(float f) {
+  union { uint32_t u; float f; } v; v.f = f;
+  if ((v.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((v.u >> 16) | 0x40);
+  const uint32_t r = 0x7fffu + ((v.u >> 16) & 1u);
+  return (bf16_t)((v.u + r) >> 16);
+}
+__host__ __device__ static inline uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+__global__ void fill_kernel(bf16_t* p, int64_t n, uint32_t seed, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t h = hash32((uint32_t)i * 2654435761u + seed);
+  const float u = ((h >> 8) * (1.0f / 16777216.0f)) * 2.f - 1.f;   // uniform [-1, 1): full-range random data (rule 25)
+  p[i] = f2bf(u * scale);
+}
+
+__device__ float ref_act(float x, int act) {
+  switch (act) {
+    case 1: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case 2: return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+    case 3: return x > 0.f ? x : 0.f;
+    case 4: return x / (1.f + expf(-x));
+    case 5: return x / (1.f + expf(-1.702f * x));
+    default: return x;
+  }
+}
+__device__ float ref_dact(float x, int act) {
+  switch (act) {
+    case 1: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+    case 2: {
+      const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x), t = tanhf(u);
+      return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x * x);
+    }
+    case 3: return x > 0.f ? 1.f : 0.f;
+    default: return 1.f;
+  }
+}
+
+// naive reference: one thread per output element, fp32 accumulate in k order, epilogue as include/dvla.h states it
+__global__ void ref_kernel(dvla_gemm_params p, float drop_scale, uint32_t drop_thr, float* out_f32, float* pre_f32) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.M * p.N) return;
+  const int64_t m = idx / p.N, n = idx % p.N;
+  const bf16_t* A = (const bf16_t*)p.A; const bf16_t* B = (const bf16_t*)p.B;
+  float s = 0.f;
+  for (int64_t k = 0; k < p.K; ++k) {
+    const float a = bf2f(p.a_trans ? A[k * p.lda + m] : A[m * p.lda + k]);
+    const float b = bf2f(p.b_trans ? B[k * p.ldb + n] : B[n * p.ldb + k]);
+    s = fmaf(a, b, s);
+  }
+  if (p.bias) s += bf2f(((const bf16_t*)p.bias)[n]);
+  if (p.preact) { pre_f32[idx] = s; s = bf2f(f2bf(s)); }
+  s = ref_act(s, p.act);
+  if (p.dropout_p > 0.f) {
+    const uint32_t rowkey = hash32((uint32_t)m ^ p.seed_hi) + p.seed_lo;
+    const uint32_t h = hash32(rowkey + (uint32_t)n * 0x9E3779B9u);
+    s = (h >= drop_thr) ? s * drop_scale : 0.f;
+  }
+  if (p.c_dtype == DVLA_DT_BF16 && (p.dact_aux || p.residual)) s = bf2f(f2bf(s));
+  if (p.dact_aux) s *= ref_dact(bf2f(((const bf16_t*)p.dact_aux)[m * p.ld_dact + n]), p.dact);
+  if (p.residual) {
+    const int64_t rr = p.res_rows > 0 ? m % p.res_rows : m;
+    s += bf2f(((const bf16_t*)p.residual)[rr * p.ld_res + n]);
+  }
+  out_f32[idx] = s;
+}
+
+struct Case {
+  std::string name; int64_t M, N, K; int at, bt; std::string epi; int split_k;
+};
+
+struct Buf { void* p = nullptr; size_t bytes = 0; };
+static Buf dalloc(size_t bytes) { Buf b; b.bytes = bytes; CK(hipMalloc(&b.p, bytes ? bytes : 16)); return b; }
+static void fill(Buf& b, uint32_t seed, float scale) {
+  const int64_t n = (int64_t)(b.bytes / 2);
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (bf16_t*)b.p, n, seed, scale);
+}
+
+struct Problem {
+  dvla_gemm_params p; Buf A, B, C, bias, preact, dact, res, ws;
+  void release() { for (Buf* b : {&A, &B, &C, &bias, &preact, &dact, &res, &ws}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } }
+};
+
+static Problem make_problem(const Case& c, int64_t M) {
+  Problem q; memset(&q.p, 0, sizeof(q.p));
+  const int64_t N = c.N, K = c.K;
+  q.A = dalloc((size_t)M * K * 2); q.B = dalloc((size_t)N * K * 2);
+  fill(q.A, 1u, 1.0f); fill(q.B, 2u, 0.06f);
+  dvla_gemm_params& p = q.p;
+  p.A = q.A.p; p.lda = c.at ? M : K; p.a_trans = c.at;
+  p.B = q.B.p; p.ldb = c.bt ? N : K; p.b_trans = c.bt;
+  p.M = M; p.N = N; p.K = K; p.split_k = c.split_k;
+  const bool f32 = c.epi == "f32";
+  q.C = dalloc((size_t)M * N * (f32 ? 4 : 2));
+  p.C = q.C.p; p.ldc = N; p.c_dtype = f32 ? DVLA_DT_F32 : DVLA_DT_BF16;
+  auto need_bias = [&]() { q.bias = dalloc((size_t)N * 2); fill(q.bias, 3u, 0.5f); p.bias = q.bias.p; p.bias_dtype = DVLA_DT_BF16; };
+  if (c.epi == "bias") need_bias();
+  if (c.epi == "gelu_erf") { need_bias(); p.act = 1; }
+  if (c.epi == "gelu_tanh_preact" || c.epi == "gelu_erf_preact") {
+    need_bias(); p.act = c.epi == "gelu_tanh_preact" ? 2 : 1;
+    q.preact = dalloc((size_t)M * N * 2); p.preact = q.preact.p; p.ld_preact = N;
+  }
+  if (c.epi == "drop_res" || c.epi == "res") {
+    need_bias();
+    q.res = dalloc((size_t)M * N * 2); fill(q.res, 4u, 1.0f); p.residual = q.res.p; p.ld_res = N;
+    if (c.epi == "drop_res") { p.dropout_p = 0.1f; p.seed_lo = 12345u; p.seed_hi = 777u; }
+  }
+  if (c.epi == "dact_tanh" || c.epi == "dact_erf") {
+    q.dact = dalloc((size_t)M * N * 2); fill(q.dact, 5u, 2.0f); p.dact_aux = q.dact.p; p.ld_dact = N; p.dact = c.epi == "dact_tanh" ? 2 : 1;
+  }
+  if (c.split_k > 1) { q.ws = dalloc((size_t)c.split_k * M * N * 4); p.workspace = q.ws.p; }
+  return q;
+}
+
+static std::vector<int> parse_list(const char* s) {
+  std::vector<int> v; std::string t(s); size_t pos = 0;
+  while (pos < t.size()) { size_t e = t.find(',', pos); if (e == std::string::npos) e = t.size(); v.push_back(atoi(t.substr(pos, e - pos).c_str())); pos = e + 1; }
+  return v;
+}
+
+// returns {max rel err (vs |ref| + atol scale), fraction of elements off by > tol}
+static void check_variant(const Case& c, int variant, int64_t Mchk) {
+  Problem q = make_problem(c, Mchk);
+  const int64_t MN = Mchk * c.N;
+  Buf ref = dalloc((size_t)MN * 4), pre = dalloc((size_t)MN * 4);
+  const float drop_scale = q.p.dropout_p > 0.f ? 1.f / (1.f - q.p.dropout_p) : 1.f;
+  const double thr = (double)q.p.dropout_p * 4294967296.0;
+  hipLaunchKernelGGL(ref_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, 0, q.p, drop_scale, (uint32_t)thr, (float*)ref.p, (float*)pre.p);
+  CK(hipMemset(q.C.p, 0xff, q.C.bytes));
+  if (q.preact.p) CK(hipMemset(q.preact.p, 0xff, q.preact.bytes));
+  dvla_set_gemm_variant(variant);
+  const int rc = dvla_gemm_bf16(&q.p, nullptr);
+  dvla_set_gemm_variant(0);
+  CK(hipDeviceSynchronize());
+  std::vector<float> h_ref(MN), h_pre(MN);
+  CK(hipMemcpy(h_ref.data(), ref.p, MN * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(h_pre.data(), pre.p, MN * 4, hipMemcpyDeviceToHost));
+  const bool f32 = q.p.c_dtype == DVLA_DT_F32;
+  std::vector<char> h_c(q.C.bytes);
+  CK(hipMemcpy(h_c.data(), q.C.p, q.C.bytes, hipMemcpyDeviceToHost));
+  std::vector<bf16_t> h_p;
+  if (q.preact.p) { h_p.resize(MN); CK(hipMemcpy(h_p.data(), q.preact.p, MN * 2, hipMemcpyDeviceToHost)); }
+  double num = 0, den = 0, max_abs = 0, ref_max = 0; int64_t bad = 0, badp = 0, first_bad = -1;
+  for (int64_t i = 0; i < MN; ++i) {
+    const float got = f32 ? ((const float*)h_c.data())[i] : bf2f(((const bf16_t*)h_c.data())[i]);
+    const float want = f32 ? h_ref[i] : bf2f(f2bf(h_ref[i]));
+    const double d = fabs((double)got - (double)want);
+    num += d * d; den += (double)want * want; max_abs = std::max(max_abs, d); ref_max = std::max(ref_max, (double)fabs(want));
+    // element-wise criterion: 2 bf16 ulps of the value (one rounding flip of an intermediate + the final rounding) plus an
+    // absolute floor for cancelling sums (branch + residual); a misplaced element is off by O(1)
+    const double tol = (f32 ? 2e-4 * fabs(want) + 2e-4 : 0.01 * fabs(want) + 0.012);
+    if (!(d <= tol)) { ++bad; if (first_bad < 0) first_bad = i; }
+    if (!h_p.empty()) {
+      const float gp = bf2f(h_p[i]), wp = bf2f(f2bf(h_pre[i]));
+      if (!(fabs(gp - wp) <= 0.0157 * fabs(wp) + 1e-3)) ++badp;
+    }
+  }
+  printf("{\"check\": \"%s\", \"epi\": \"%s\", \"M\": %lld, \"N\": %lld, \"K\": %lld, \"at\": %d, \"bt\": %d, \"split_k\": %d, \"variant\": %d, \"rc\": %d, "
+         "\"rel_l2\": %.3e, \"max_abs\": %.3e, \"ref_absmax\": %.3e, \"bad\": %lld, \"bad_preact\": %lld, \"first_bad\": %lld, \"ok\": %s}\n",
+         c.name.c_str(), c.epi.c_str(), (long long)Mchk, (long long)c.N, (long long)c.K, c.at, c.bt, c.split_k, variant, rc,
+         sqrt(num / (den > 0 ? den : 1)), max_abs, ref_max, (long long)bad, (long long)badp, (long long)first_bad,
+         (rc == 0 && bad == 0 && badp == 0) ? "true" : "false");
+  fflush(stdout);
+  (void)hipFree(ref.p); (void)hipFree(pre.p); q.release();
+}
+
+int main(int argc, char** argv) {
+  std::vector<int> variants = {0, 2, 4, 5, 6};
+  int iters = 7, rounds = 3; bool check_only = false, no_check = false; std::string which = "model";
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--variants") && i + 1 < argc) variants = parse_list(argv[++i]);
+    else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--rounds") && i + 1 < argc) rounds = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--check-only")) check_only = true;
+    else if (!strcmp(argv[i], "--no-check")) no_check = true;
+    else if (!strcmp(argv[i], "--cases") && i + 1 < argc) which = argv[++i];
+  }
+  std::vector<Case> cases;
+  if (which == "model" || which == "all") {
+    cases = {
+      {"trunk fc1 fwd", 20832, 4096, 1024, 0, 1, "gelu_tanh_preact", 1},
+      {"trunk fc1 dX", 20832, 4096, 1024, 0, 0, "dact_tanh", 1},          // dY[M,1024]... stated as M x N=4096 x K=1024 in the breakdown
+      {"trunk fc2 fwd", 20832, 1024, 4096, 0, 1, "drop_res", 1},
+      {"trunk fc2 dX", 20832, 1024, 4096, 0, 0, "plain", 1},
+      {"trunk c_attn fwd", 20832, 3072, 1024, 0, 1, "bias", 1},
+      {"trunk c_proj fwd", 20832, 1024, 1024, 0, 1, "drop_res", 1},
+      {"trunk c_attn dX", 20832, 1024, 3072, 0, 0, "plain", 1},
+      {"vit fc1", 88256, 3072, 768, 0, 0, "gelu_erf", 1},
+      {"vit fc2", 88256, 768, 3072, 0, 0, "res", 1},
+      {"vit qkv", 88256, 2304, 768, 0, 0, "bias", 1},
+      {"vit proj", 88256, 768, 768, 0, 0, "res", 1},
+      {"dec fc1 fwd", 91840, 4096, 1024, 0, 0, "gelu_erf_preact", 1},
+      {"dec fc1 dX", 91840, 4096, 1024, 0, 1, "dact_erf", 1},
+      {"dW fc1", 1024, 4096, 20832, 1, 1, "f32", 4},
+      {"dW fc2", 4096, 1024, 20832, 1, 1, "f32", 4},
+      {"dW c_attn", 1024, 3072, 20832, 1, 1, "f32", 6},
+      {"dW c_proj", 1024, 1024, 20832, 1, 1, "f32", 10},
+      {"square", 8192, 8192, 8192, 0, 0, "plain", 1},
+    };
+  } else if (which == "small") {
+    cases = {
+      {"trunk fc1 fwd", 20832, 4096, 1024, 0, 1, "gelu_tanh_preact", 1},
+      {"trunk fc1 dX", 20832, 4096, 1024, 0, 0, "dact_tanh", 1},
+      {"trunk fc2 fwd", 20832, 1024, 4096, 0, 1, "drop_res", 1},
+      {"vit fc1", 88256, 3072, 768, 0, 0, "gelu_erf", 1},
+      {"plain NT", 20832, 4096, 1024, 0, 0, "plain", 1},
+      {"dW fc1", 1024, 4096, 20832, 1, 1, "f32", 4},
+      {"square", 8192, 8192, 8192, 0, 0, "plain", 1},
+    };
+  }
+  // ---- correctness: every (case layout / epilogue, variant) at a reduced M (ragged: not a tile multiple) ----
+  if (!no_check) {
+    for (const Case& c : cases) {
+      Case cc = c;
+      int64_t Mchk = c.at ? c.M : 777;         // r-contiguous A needs whole row panels for the ring kernels; keep it as is
+      if (c.at) { cc.K = 2048; if (cc.split_k > 1) cc.split_k = 2; Mchk = c.M; }
+      else if (c.K > 1024) cc.K = 1024;
+      if (cc.N > 1024 && !c.at) cc.N = 1024;
+      for (int v : variants) check_variant(cc, v, Mchk);
+    }
+  }
+  if (check_only) return 0;
+  // ---- timing: variants interleaved, `rounds` rounds of `iters` launches each; median / min over rounds ----
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (const Case& c : cases) {
+    Problem q = make_problem(c, c.M);
+    std::vector<std::vector<double>> t(variants.size());
+    for (int r = 0; r < rounds + 1; ++r) {
+      for (size_t vi = 0; vi < variants.size(); ++vi) {
+        dvla_set_gemm_variant(variants[vi]);
+        (void)dvla_gemm_bf16(&q.p, nullptr);   // warm
+        CK(hipEventRecord(e0, 0));
+        for (int it = 0; it < iters; ++it) (void)dvla_gemm_bf16(&q.p, nullptr);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) t[vi].push_back(ms * 1e3 / iters);
+      }
+    }
+    dvla_set_gemm_variant(0);
+    printf("{\"time\": \"%s\", \"epi\": \"%s\", \"M\": %lld, \"N\": %lld, \"K\": %lld, \"at\": %d, \"bt\": %d, \"split_k\": %d", c.name.c_str(), c.epi.c_str(),
+           (long long)c.M, (long long)c.N, (long long)c.K, c.at, c.bt, c.split_k);
+    const double flop = 2.0 * c.M * c.N * c.K;
+    for (size_t vi = 0; vi < variants.size(); ++vi) {
+      std::sort(t[vi].begin(), t[vi].end());
+      const double med = t[vi][t[vi].size() / 2], mn = t[vi][0];
+      printf(", \"v%d\": {\"us\": %.1f, \"min_us\": %.1f, \"TF\": %.0f}", variants[vi], med, mn, flop / med / 1e6);
+    }
+    printf("}\n"); fflush(stdout);
+    q.release();
+  }
+  return 0;
+}
