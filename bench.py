@@ -117,10 +117,10 @@ def main():
     ap.add_argument("--seq", type=int, default=7)
     ap.add_argument("--heads", default="C", choices=sorted(HEAD_SETS))
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--tune-steps", type=int, default=11,
+    ap.add_argument("--tune-steps", type=int, default=13,
                     help="untimed steps BEFORE the warm-up in which dreamvla_amd.ops.GemmTuner tries each GEMM kernel "
                          "configuration once per problem shape and locks the fastest (setup, like building the extension); "
-                         "five candidates x GemmTuner.ROUNDS (2) trials: shapes that occur once per step need eleven steps to lock")
+                         "six candidates x GemmTuner.ROUNDS (2) trials: shapes that occur once per step need thirteen steps to lock")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true",
@@ -285,6 +285,9 @@ def main():
             cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
 
     eager = None
+    grad_exchange = "torch DDP" if reducer is None else "GradBucketReducer (flat bf16 buckets, async all-reduce)"
+    optimizer_name = ("FlatAdamW (HIP: dvla_sumsq_bf16 + dvla_adamw_bf16 on flat buffers)" if flat_opt is not None
+                      else "clip_grad_norm_ + torch.optim.AdamW(fused)")
     if rank == 0 and world == 1 and not args.no_eager_baseline:
         try:
             del model, ddp_model, reducer, flat_opt, opt, params
@@ -306,9 +309,7 @@ def main():
                                    f"{args.layers} layers / 16 heads, dropout 0.1 on, AdamW + clip 0.1",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "trainable_params_M": n_train / 1e6, "loss": loss_val,
-                       "grad_exchange": "torch DDP" if reducer is None else "GradBucketReducer (flat bf16 buckets, async all-reduce)",
-                       "optimizer": "FlatAdamW (HIP: dvla_sumsq_bf16 + dvla_adamw_bf16 on flat buffers)" if flat_opt is not None
-                                    else "clip_grad_norm_ + torch.optim.AdamW(fused)"},
+                       "grad_exchange": grad_exchange, "optimizer": optimizer_name},
             "roofline": roofline, "cpu_baseline": cpu, "eager_rocm_baseline": eager,
         }
         print(json.dumps(line), flush=True)

@@ -2,14 +2,16 @@
 // compiled one (configuration, operand layout) per translation unit in gemm_inst_*.hip so that the build runs in parallel).
 #include <stdlib.h>
 
-#include "gemm_impl.h"
+#include "gemm_phase.h"
 
 namespace dvla_gemm {
 #define DVLA_EXTERN_REG(CF, AT, BT, DBG) extern template void launch_one<CF, AT, BT, DBG>(const GemmKArgs&, int, hipStream_t);
-#define DVLA_EXTERN_RING(RC, AT, BT) extern template void launch_ring_one<RC, AT, BT>(const GemmKArgs&, int, hipStream_t);
+#define DVLA_EXTERN_RING(RC, AT, BT, EPI) extern template void launch_ring_one<RC, AT, BT, EPI>(const GemmKArgs&, int, hipStream_t);
+#define DVLA_EXTERN_PHASE(AT, BT, EPI, DBG) extern template void launch_phase_one<AT, BT, EPI, DBG>(const GemmKArgs&, int, hipStream_t);
 #include "gemm_inst_list.h"
 #undef DVLA_EXTERN_REG
 #undef DVLA_EXTERN_RING
+#undef DVLA_EXTERN_PHASE
 }  // namespace dvla_gemm
 
 using namespace dvla_gemm;
@@ -55,15 +57,51 @@ void launch_cfg(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
   }
 }
 
+template <class RC, bool AT, bool BT>
+void launch_ring_epi(const GemmKArgs& a, int split_k, hipStream_t stream) {
+  switch (epi_class(a)) {
+    case EPI_P0: launch_ring_one<RC, AT, BT, EPI_P0>(a, split_k, stream); break;
+    case EPI_P_ERF: launch_ring_one<RC, AT, BT, EPI_P_ERF>(a, split_k, stream); break;
+    case EPI_P_TANH: launch_ring_one<RC, AT, BT, EPI_P_TANH>(a, split_k, stream); break;
+    case EPI_A0: launch_ring_one<RC, AT, BT, EPI_A0>(a, split_k, stream); break;
+    case EPI_A_ERF: launch_ring_one<RC, AT, BT, EPI_A_ERF>(a, split_k, stream); break;
+    case EPI_A_TANH: launch_ring_one<RC, AT, BT, EPI_A_TANH>(a, split_k, stream); break;
+    case EPI_F32: launch_ring_one<RC, AT, BT, EPI_F32>(a, split_k, stream); break;
+    default: launch_ring_one<RC, AT, BT, EPI_GEN>(a, split_k, stream); break;
+  }
+}
 template <class RC>
 void launch_ring(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
   a.tiles_m = (int)((a.M + RC::BM - 1) / RC::BM);
   a.tiles_n = (int)((a.N + RC::BN - 1) / RC::BN);
   switch (combo) {
-    case 0: launch_ring_one<RC, false, false>(a, split_k, stream); break;
-    case 1: launch_ring_one<RC, false, true>(a, split_k, stream); break;
-    case 2: launch_ring_one<RC, true, false>(a, split_k, stream); break;
-    default: launch_ring_one<RC, true, true>(a, split_k, stream); break;
+    case 0: launch_ring_epi<RC, false, false>(a, split_k, stream); break;
+    case 1: launch_ring_epi<RC, false, true>(a, split_k, stream); break;
+    case 2: launch_ring_epi<RC, true, false>(a, split_k, stream); break;
+    default: launch_ring_epi<RC, true, true>(a, split_k, stream); break;
+  }
+}
+template <bool AT, bool BT>
+void launch_phase_epi(const GemmKArgs& a, int split_k, hipStream_t stream) {
+  switch (epi_class(a)) {
+    case EPI_P0: launch_phase_one<AT, BT, EPI_P0, 0>(a, split_k, stream); break;
+    case EPI_P_ERF: launch_phase_one<AT, BT, EPI_P_ERF, 0>(a, split_k, stream); break;
+    case EPI_P_TANH: launch_phase_one<AT, BT, EPI_P_TANH, 0>(a, split_k, stream); break;
+    case EPI_A0: launch_phase_one<AT, BT, EPI_A0, 0>(a, split_k, stream); break;
+    case EPI_A_ERF: launch_phase_one<AT, BT, EPI_A_ERF, 0>(a, split_k, stream); break;
+    case EPI_A_TANH: launch_phase_one<AT, BT, EPI_A_TANH, 0>(a, split_k, stream); break;
+    case EPI_F32: launch_phase_one<AT, BT, EPI_F32, 0>(a, split_k, stream); break;
+    default: launch_phase_one<AT, BT, EPI_GEN, 0>(a, split_k, stream); break;
+  }
+}
+void launch_phase(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
+  a.tiles_m = (int)((a.M + PCfg::BM - 1) / PCfg::BM);
+  a.tiles_n = (int)((a.N + PCfg::BN - 1) / PCfg::BN);
+  switch (combo) {
+    case 0: launch_phase_epi<false, false>(a, split_k, stream); break;
+    case 1: launch_phase_epi<false, true>(a, split_k, stream); break;
+    case 2: launch_phase_epi<true, false>(a, split_k, stream); break;
+    default: launch_phase_epi<true, true>(a, split_k, stream); break;
   }
 }
 template <class RC>
@@ -100,7 +138,6 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       return DVLA_ERR_ARG;
   }
   GemmKArgs a;
-  { static int ds = -1; if (ds < 0) { const char* e = getenv("DVLA_GEMM_DIRECT"); ds = e ? atoi(e) : 2; } a.direct_store = ds; }
   a.A = reinterpret_cast<const bf16_t*>(q->A); a.lda = q->lda;
   a.B = reinterpret_cast<const bf16_t*>(q->B); a.ldb = q->ldb;
   a.C = q->C; a.ldc = q->ldc; a.c_f32 = (q->c_dtype == DVLA_DT_F32);
@@ -137,18 +174,16 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
 
   const int combo = (q->a_trans ? 2 : 0) | (q->b_trans ? 1 : 0);
   int variant = gemm_variant();
-  if (variant >= 100) {   // A/B knob for measurements: 1xx = direct stores on, 2xx = off, xx = configuration
-    a.direct_store = (variant / 100 == 1) ? 1 : (variant / 100 == 3) ? 3 : 0;
-    variant %= 100;
-  }
+  if (variant >= 100) variant %= 100;   // (hundreds digit: reserved for A/B knobs of measurement builds)
   {
-    // Configuration choice: cheapest by a two-constant model per ring configuration, T = rounds * (fixed + stage * ns),
-    // rounds = ceil(work items / workgroup slots), ns = 32-wide K stages per item.  Constants in microseconds per
-    // round, measured on MI355X with tests/gpu_gemm_variants.py / the K sweep in profiles/r01_gemm_variants.txt:
-    // the 256^2 tile has the fastest main loop per flop (0.88 us per stage for twice the area of the others' 0.58)
-    // but the most expensive epilogue (18.7 us vs 5.9 / 5.7 per round).  The register-staged kernel is the fallback
-    // for shapes the ring kernels do not take (ragged N, unaligned operands, tiny problems).
-    int choice = 0;   // 0 = register-staged S (always valid), 1 = ring L, 2 = ring M, 3 = ring S
+    // Configuration choice: cheapest by a two-constant model per configuration, T = rounds * (fixed + stage * ns),
+    // rounds = ceil(work items / workgroup slots), ns = 32-wide K stages per item.  Constants in microseconds per round,
+    // measured on MI355X with tests/probes/gemm_probe.cpp (K sweep at 20832 x 4096, plain epilogue, round 2:
+    // profiles/r02_gemm_probe_final.txt): with the register-only epilogue the fixed cost per round is 2.9 / 3.6 / 5.8 / 6.6 us
+    // for 128^2 / 256x128 BK64 / 256^2 / phase (it was 5.7 / 5.9 / 18.7 with the LDS-patch epilogue of round 1), the slope per
+    // stage 0.58 / 0.49 / 0.85 / 0.775.  The online tuner (dreamvla_amd.ops.GemmTuner) refines this per problem key in-model.
+    // The register-staged kernel is the fallback for shapes the DMA kernels do not take (ragged N, unaligned operands, tiny).
+    int choice = 0;   // 0 = register-staged S (always valid), 1 = ring L, 3 = ring S, 4 = ring M64, 5 = phase
     if (variant == 0) {
       const double ns = (double)(a.k_per_split < a.K ? a.k_per_split : a.K) / 32.0;
       const int slots = num_cus();
@@ -159,20 +194,29 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
         const double t = (double)rounds * (fixed_us + stage_us * ns);
         if (t < best) { best = t; choice = c; }
       };
-      if (ring_ok<RCfgS>(a, combo)) consider(3, 128, 128, 2, 5.7, 0.58);
-      if (ring_ok<RCfgM>(a, combo)) consider(2, 256, 128, 1, 5.9, 0.58);
-      if (ring_ok<RCfgL>(a, combo)) consider(1, 256, 256, 1, 18.7, 0.88);
+      if (ring_ok<RCfgS>(a, combo)) consider(3, 128, 128, 2, 2.9, 0.58);
+      if (ring_ok<RCfgM64>(a, combo)) consider(4, 256, 128, 1, 3.6, 0.49);
+      if (ring_ok<RCfgL>(a, combo)) consider(1, 256, 256, 1, 5.8, 0.85);
+      if (ring_ok<PCfg>(a, combo)) consider(5, 256, 256, 1, 6.6, 0.775);
     } else if (variant == 4 && ring_ok<RCfgL>(a, combo)) choice = 1;
-    else if (variant == 5 && ring_ok<RCfgM>(a, combo)) choice = 2;
     else if (variant == 6 && ring_ok<RCfgS>(a, combo)) choice = 3;
     else if (variant == 7 && ring_ok<RCfgM64>(a, combo)) choice = 4;
-    else if (variant == 9 && ring_ok<RCfgL64>(a, combo)) choice = 5;
+    else if (variant == 8 && ring_ok<PCfg>(a, combo)) choice = 5;
+    else if (variant > 80 && variant < 90 && combo == 0 && ring_ok<PCfg>(a, combo)) choice = 80 + (variant - 80);
     switch (choice) {
       case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;
-      case 2: launch_ring<RCfgM>(a, combo, split_k, stream); break;
       case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
       case 4: launch_ring<RCfgM64>(a, combo, split_k, stream); break;
-      case 5: launch_ring<RCfgL64>(a, combo, split_k, stream); break;
+      case 5: launch_phase(a, combo, split_k, stream); break;
+      case 81: case 83: case 84: case 85: case 86:   // ablations (plain bf16 epilogue only): 81 no MFMA, 83 no MFMA + no reads, 84 no DMA, 85 no epilogue, 86 raw stores only
+        a.tiles_m = (int)((a.M + 255) / 256); a.tiles_n = (int)((a.N + 255) / 256);
+        if (epi_class(a) != EPI_P0) return DVLA_ERR_UNSUPPORTED;
+        if (choice == 81) launch_phase_one<false, false, 0, 1>(a, split_k, stream);
+        else if (choice == 83) launch_phase_one<false, false, 0, 3>(a, split_k, stream);
+        else if (choice == 84) launch_phase_one<false, false, 0, 4>(a, split_k, stream);
+        else if (choice == 85) launch_phase_one<false, false, 0, 16>(a, split_k, stream);
+        else launch_phase_one<false, false, 0, 32>(a, split_k, stream);
+        break;
       default: launch_cfg<CfgS>(a, combo, split_k, stream); break;
     }
   }

@@ -80,7 +80,6 @@ struct GemmKArgs {
   int split_k; int64_t k_per_split; float* workspace;
   int a_vec, b_vec, c_vec, aux_vec, epi_vec;
   int tiles_m, tiles_n;
-  int direct_store;  // plain bf16 epilogues store from the accumulator layout: 0 never, 1 always, 2 (default) 256x256 tile only; env DVLA_GEMM_DIRECT
 };
 
 // Row-major image of a k-contiguous operand: row r = 128 B = 8 slots of 16 B; k-octet o of row r lives in slot
@@ -411,10 +410,6 @@ __device__ __forceinline__ void tile_epilogue(const GemmKArgs& p, f32x16 (&acc)[
   });
 }
 
-template <int TM>
-__device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], int lane, int64_t m_base,
-                                             int64_t n_base, int split);
-
 template <class CF, bool A_T, bool B_T, int DBG = 0>
 __global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
   constexpr int BM = CF::BM, BN = CF::BN, TM = CF::TM, TN = CF::TN;
@@ -557,10 +552,8 @@ __global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
     }
   }
 
-  if (p.direct_store == 3 && p.c_vec && p.aux_vec && p.epi_vec && (p.N & 63) == 0)
-    reg_epilogue<TM>(p, acc, lane, m0 + wm * (TM * 32), n0 + wn * 64, split);
-  else
-    tile_epilogue<TM>(p, acc, smem, wave, lane, m0 + wm * (TM * 32), n0 + wn * 64, split);
+  // (the register-only epilogue of the ring kernels was measured here too: 264 VGPRs -> one workgroup per CU, 30-60 % slower)
+  tile_epilogue<TM>(p, acc, smem, wave, lane, m0 + wm * (TM * 32), n0 + wn * 64, split);
 }
 
 // ====================================================================================================
@@ -587,15 +580,16 @@ __global__ __launch_bounds__(CF::NT) void gemm_kernel(GemmKArgs p) {
 //                          with the hardware transpose ds_read_b64_tr_b16 (lane i of a 16-lane group receives 4 consecutive k
 //                          of row i; semantics probed on hardware: tests/probes/tr_probe.hip) -- so Conv1D weights and
 //                          the weight-gradient GEMMs need no register transpose either.
-//   epilogue             : bias / activation / dropout in the accumulator layout, then each 32 x 64 slab goes through a
-//                          4-KiB wave-private LDS patch OUTSIDE the ring (as bf16, or as two fp32 halves) so that a
-//                          lane stores 16 contiguous bytes; act'-multiply and residual are applied after the transpose
-//                          on the rounded value (which is what `dropout(linear(x))` then `x + y` do in the reference).
-//                          No workgroup barrier: the ring keeps streaming underneath.
+//   epilogue             : entirely in registers (reg_epilogue below): bias / activation / dropout / act' / residual in the
+//                          accumulator layout, a half-wave exchange (v_permlane32_swap) turns two column quads into 16
+//                          contiguous bytes per lane, stores and store-layout loads are 16 B wide.  No LDS, no waits, no
+//                          workgroup barrier: the ring keeps streaming underneath.  (Round 1 transposed every 32 x 64 slab
+//                          through a wave-private LDS patch: ds_write -> wait -> ds_read -> wait -> store chains that cost
+//                          120 us of a 335-us fused fc1 launch; profiles/r02_gemm_probe_*.txt.)
 // Requirements (host falls back to the register-staged kernel otherwise): 16-B-vectorisable operands / outputs,
 // K-range % 32 == 0, r-contiguous operands with rows % tile == 0.
 // ====================================================================================================
-template <int WM_, int WN_, int TM_, int TN_, int NS_, int WPE_, int GH_, int BKS_, int PROWS_>
+template <int WM_, int WN_, int TM_, int TN_, int NS_, int WPE_, int GH_, int BKS_>
 struct RCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVES = WM * WN, NT = NWAVES * 64;
@@ -604,24 +598,21 @@ struct RCfg {
   static constexpr int NS = NS_;             // NS ring stages: NS - 1 stages are in flight ahead of the one computed
   static constexpr int WPE = WPE_;           // waves per SIMD the register budget must allow
   static constexpr int GH = GH_;             // tile rows per raster group
-  static constexpr int PROWS = PROWS_;       // rows of the epilogue patch: 32 (4 KiB per wave) or 16 (2 KiB, two passes per slab)
   static constexpr int A_BYTES = BM * BKS * 2, B_BYTES = BN * BKS * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int RING_BYTES = NS * STAGE_BYTES, PATCH_BYTES = PROWS * 128;
-  static constexpr int SMEM_BYTES = RING_BYTES + NWAVES * PATCH_BYTES;
+  static constexpr int RING_BYTES = NS * STAGE_BYTES;
+  static constexpr int SMEM_BYTES = RING_BYTES;    // the epilogue runs in registers: the whole allocation is ring
   static constexpr int WG_PER_CU = (2 * SMEM_BYTES <= 160 * 1024) ? 2 : 1;
   static constexpr int A_CHUNKS = A_BYTES / 1024, B_CHUNKS = B_BYTES / 1024;
   static constexpr int CPW = (A_CHUNKS + B_CHUNKS) / NWAVES;   // DMA instructions per wave and stage
   static_assert((A_CHUNKS + B_CHUNKS) % NWAVES == 0, "chunks must divide evenly over the waves");
   static_assert(TN == 2, "epilogue slabs are 64 columns wide");
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
-  static_assert(NS >= 2 && NS <= 4 && (BKS == 32 || BKS == 64) && (PROWS == 32 || PROWS == 16), "supported shapes");
+  static_assert(NS >= 2 && NS <= 5 && (BKS == 32 || BKS == 64), "supported shapes");
   static_assert((NS - 1) * CPW <= 63, "vmcnt is a 6-bit counter");
 };
-using RCfgL = RCfg<2, 4, 4, 2, 4, 2, 4, 32, 32>;    // 256 x 256, BK 32, 8 waves of 128 x 64, 128 + 32 KiB, 1 workgroup / CU
-using RCfgM = RCfg<4, 2, 2, 2, 4, 2, 4, 32, 32>;    // 256 x 128, BK 32, 8 waves of  64 x 64,  96 + 32 KiB, 1 workgroup / CU
-using RCfgS = RCfg<2, 2, 2, 2, 4, 2, 8, 32, 32>;    // 128 x 128, BK 32, 4 waves of  64 x 64,  64 + 16 KiB, 2 workgroups / CU
-using RCfgM64 = RCfg<4, 2, 2, 2, 3, 2, 4, 64, 16>;  // 256 x 128, BK 64, 8 waves of  64 x 64, 144 + 16 KiB, 1 workgroup / CU
-using RCfgL64 = RCfg<2, 4, 4, 2, 2, 2, 4, 64, 32>;  // 256 x 256, BK 64 (whole 128-B lines of a k-contiguous operand), 2 stages, 128 + 32 KiB
+using RCfgL = RCfg<2, 4, 4, 2, 4, 2, 4, 32>;    // 256 x 256, BK 32, 8 waves of 128 x 64, 128 KiB ring, 1 workgroup / CU
+using RCfgS = RCfg<2, 2, 2, 2, 4, 2, 8, 32>;    // 128 x 128, BK 32, 4 waves of  64 x 64,  64 KiB ring, 2 workgroups / CU
+using RCfgM64 = RCfg<4, 2, 2, 2, 3, 2, 4, 64>;  // 256 x 128, BK 64 (whole 128-B lines of a k-contiguous operand), 144 KiB ring
 
 // per-lane global source address of chunk c of an operand tile at k0 (the LDS destination of lane l is chunk base + 16 l)
 template <bool TRANS, int ROWS, int BKS>
@@ -699,219 +690,6 @@ __device__ __forceinline__ RingItem ring_item(const GemmKArgs& p, int id) {
   return it;
 }
 
-// patch addressing (wave-private 4 KiB): bf16 image = 32 rows x 16 units of 8 B, unit u of row r at u ^ (r & 15);
-// fp32 half-slab image = 32 rows x 8 units of 16 B, unit u of row r at u ^ (r & 7).
-__device__ __forceinline__ int patch_bf16(int row, int unit) { return row * 128 + ((unit ^ (row & 15)) << 3); }
-__device__ __forceinline__ int patch_f32(int row, int unit) { return row * 128 + ((unit ^ (row & 7)) << 4); }
-
-// Epilogue of one wave: (TM*32) x 64 block at (m_base, n_base).  acc[i][j][r] = element (m = 32j + l31,
-// n = 32i + 8*(r>>2) + 4*g + (r&3)).  Requires c_vec / aux_vec / epi_vec and N % 64 == 0 (ring_ok): only rows beyond M
-// need guards.
-template <int TM, int PROWS>
-__device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], char* patch, int lane,
-                                              int64_t m_base, int64_t n_base, int split) {
-  constexpr int NH = 32 / PROWS, NIT = PROWS / 8;   // patch passes per 32-row slab, 8-row store groups per pass
-  const int l31 = lane & 31, g = lane >> 5;
-  const int cg = lane & 7, r8 = lane >> 3;
-  const int lrow = l31 & (PROWS - 1);               // this lane's row inside the patch
-  const bool split_out = p.split_k > 1;
-  const bool has_dact = p.dact_aux != nullptr, has_res = p.residual != nullptr;
-  if (n_base >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
-
-  const bool f32_out = split_out || p.c_f32;
-  static_for<TM>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    const int64_t m_acc = m_base + j * 32 + l31;           // this lane's row in the accumulator layout
-    const int64_t ms0 = m_base + j * 32 + r8;              // store layout: rows ms0 + PROWS*hh + 8*it
-    uint32_t rowkey = 0;
-    if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m_acc);
-
-    // ---- stage A (accumulator layout, fp32), evaluated per group of 4 columns right before it is written to the
-    // patch so that only four values are live: bias -> (round, if the pre-activation tensor is written) -> activation
-    // -> dropout ----
-    auto biased = [&](int i, int rq, float (&z)[4]) {
-      const int64_t n = n_base + 32 * i + 8 * rq + 4 * g;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) z[e] = acc[i][j][4 * rq + e];
-      if (!split_out && p.bias) {
-        if (p.bias_f32) {
-          const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n);
-          z[0] += b.x; z[1] += b.y; z[2] += b.z; z[3] += b.w;
-        } else {
-          const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.bias) + n);
-          z[0] += bf2f((bf16_t)(b.x & 0xffff)); z[1] += bf2f((bf16_t)(b.x >> 16));
-          z[2] += bf2f((bf16_t)(b.y & 0xffff)); z[3] += bf2f((bf16_t)(b.y >> 16));
-        }
-      }
-    };
-    auto finished = [&](int i, int rq, float (&z)[4]) {
-      biased(i, rq, z);
-      if (split_out) return;
-      if (p.preact) {   // the activation sees the stored (bf16) pre-activation
-#pragma unroll
-        for (int e = 0; e < 4; ++e) z[e] = bf2f(f2bf(z[e]));
-      }
-      act_fwd4(z, p.act);
-      if (p.has_drop) {
-        const uint32_t n = (uint32_t)(n_base + 32 * i + 8 * rq + 4 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t h = drop_hash_rk(rowkey, n + e);
-          z[e] = (h >= p.drop_thr) ? z[e] * p.drop_scale : 0.f;
-        }
-      }
-    };
-    if (!split_out && p.preact) {
-      // pre-activation tensor: same transposition as the bf16 output below
-#pragma unroll
-      for (int hh = 0; hh < NH; ++hh) {
-        if (PROWS == 32 || (l31 >> 4) == hh) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-              float z[4];
-              biased(i, rq, z);
-              *reinterpret_cast<uint2*>(patch + patch_bf16(lrow, 8 * i + 2 * rq + g)) =
-                  make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
-            }
-        }
-        wait_lds();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int R = it * 8 + r8;
-          const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
-          const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
-          const int64_t m = ms0 + hh * PROWS + 8 * it;
-          if (m < p.M) *reinterpret_cast<uint4*>(p.preact + m * p.ld_preact + n_base + 8 * cg) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-        wait_lds();
-      }
-    }
-
-    if (!f32_out && !has_res && !has_dact && (p.direct_store == 1 || (p.direct_store == 2 && TM == 4))) {
-      // ---- plain bf16 output of the 256x256 tile: 8-byte stores straight from the accumulator layout (32 rows x 16 B per
-      // instruction; the L2 merges the partial lines).  Measured on MI355X at 20832x4096: K = 64 launch 105.6 -> 75.3 us,
-      // K = 1024 265.5 -> 223.0 us for the 256x256 tile (whose 4 slabs per wave at 256 VGPRs make the patch path slow),
-      // but 60 -> 80 us for the 256x128 / 128x128 tiles, which therefore keep the transposition. ----
-      if (m_acc < p.M) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            float z[4];
-            finished(i, rq, z);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + m_acc * p.ldc + n_base + 32 * i + 8 * rq + 4 * g) =
-                make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
-          }
-      }
-    } else if (!f32_out) {
-      // ---- bf16 output: prefetch the store-layout operands, transpose the slab as bf16, finish, store 16 B / lane ----
-      uint4 pre[4];
-      if (has_res || has_dact) {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int64_t m = ms0 + (q4 / NIT) * PROWS + (q4 % NIT) * 8;
-          const int64_t mc = m < p.M ? m : p.M - 1;
-          if (has_res) {
-            const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
-            pre[q4] = *reinterpret_cast<const uint4*>(p.residual + rr * p.ld_res + n_base + 8 * cg);
-          } else {
-            pre[q4] = *reinterpret_cast<const uint4*>(p.dact_aux + mc * p.ld_dact + n_base + 8 * cg);
-          }
-        }
-      }
-#pragma unroll
-      for (int hh = 0; hh < NH; ++hh) {
-        if (PROWS == 32 || (l31 >> 4) == hh) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-              float z[4];
-              finished(i, rq, z);
-              *reinterpret_cast<uint2*>(patch + patch_bf16(lrow, 8 * i + 2 * rq + g)) =
-                  make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
-            }
-        }
-        wait_lds();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int R = it * 8 + r8;
-          const uint2 lo = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg));
-          const uint2 hi = *reinterpret_cast<const uint2*>(patch + patch_bf16(R, 2 * cg + 1));
-          uint4 out = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          const int64_t m = ms0 + hh * PROWS + 8 * it;
-          if (has_res || has_dact) {
-            float o[8], a[8];
-            unpack8f(out, o);
-            if (has_dact) {
-              uint4 au = pre[hh * NIT + it];
-              if (has_res) au = *reinterpret_cast<const uint4*>(p.dact_aux + (m < p.M ? m : p.M - 1) * p.ld_dact + n_base + 8 * cg);
-              unpack8f(au, a);
-              act_bwd8_mul(o, a, p.dact);
-            }
-            if (has_res) {
-              unpack8f(pre[hh * NIT + it], a);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o[e] += a[e];
-            }
-            out = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
-          }
-          if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n_base + 8 * cg) = out;
-        }
-        wait_lds();
-      }
-    } else {
-      // ---- fp32 output (fp32 C, accumulation, split-K partial sums): 32-column halves through the patch ----
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-          if (PROWS == 32 || (l31 >> 4) == hh) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-              float z[4];
-              finished(i, rq, z);
-              *reinterpret_cast<float4*>(patch + patch_f32(lrow, 2 * rq + g)) = make_float4(z[0], z[1], z[2], z[3]);
-            }
-          }
-          wait_lds();
-#pragma unroll
-          for (int it = 0; it < NIT; ++it) {
-            const int R = it * 8 + r8;
-            float4 o = *reinterpret_cast<const float4*>(patch + patch_f32(R, cg));
-            const int64_t m = m_base + j * 32 + hh * PROWS + R;
-            const int64_t n = n_base + 32 * i + 4 * cg;
-            if (m < p.M) {
-              if (split_out) {
-                *reinterpret_cast<float4*>(p.workspace + ((int64_t)split * p.M + m) * p.N + n) = o;
-              } else {
-                if (has_dact) {
-                  const uint2 a = *reinterpret_cast<const uint2*>(p.dact_aux + m * p.ld_dact + n);
-                  o.x *= act_bwd(bf2f((bf16_t)(a.x & 0xffff)), p.dact); o.y *= act_bwd(bf2f((bf16_t)(a.x >> 16)), p.dact);
-                  o.z *= act_bwd(bf2f((bf16_t)(a.y & 0xffff)), p.dact); o.w *= act_bwd(bf2f((bf16_t)(a.y >> 16)), p.dact);
-                }
-                if (has_res) {
-                  const int64_t rr = p.res_rows > 0 ? (m % p.res_rows) : m;
-                  const uint2 a = *reinterpret_cast<const uint2*>(p.residual + rr * p.ld_res + n);
-                  o.x += bf2f((bf16_t)(a.x & 0xffff)); o.y += bf2f((bf16_t)(a.x >> 16));
-                  o.z += bf2f((bf16_t)(a.y & 0xffff)); o.w += bf2f((bf16_t)(a.y >> 16));
-                }
-                float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n);
-                if (p.accumulate) { const float4 old = *c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-                *c = o;
-              }
-            }
-          }
-          wait_lds();
-        }
-      }
-    }
-  });
-}
-
-
 // ---- register-only epilogue (no LDS, no waits): the accumulator layout already holds 4 consecutive n per lane and
 // quad; one v_permlane32_swap per packed dword exchanges the quads of column groups (2q, 2q+1) between the two half-waves
 // so that a lane ends up with 8 consecutive bf16 (16 B) of its row:
@@ -921,74 +699,155 @@ __device__ __forceinline__ void ring_epilogue(const GemmKArgs& p, f32x16 (&acc)[
 // the accumulator layout, so bias / activation / dropout / act' / residual are all evaluated in registers.  fp32
 // outputs need no exchange at all (a quad is already 16 B).  One store instruction covers 32 rows x 32 B; the four
 // stores of a (32-row, 64-column) slab complete its 128-byte lines in the L2.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 __device__ __forceinline__ void swap_halves(uint32_t& lo_grp, uint32_t& hi_grp) {
   const auto r = __builtin_amdgcn_permlane32_swap(lo_grp, hi_grp, false, false);
   lo_grp = r[0]; hi_grp = r[1];
 }
 __device__ __forceinline__ void unpack2(uint32_t u, float& a, float& b) { a = bf2f((bf16_t)(u & 0xffff)); b = bf2f((bf16_t)(u >> 16)); }
 
-template <int TM>
+// The epilogue class is a COMPILE-TIME parameter of the kernels (the dispatcher picks the instantiation):
+//   EPI_P0 / P_ERF / P_TANH : bf16 output, no load after the first store; activation none / erf-GELU / tanh-GELU (+ bias,
+//                             pre-activation store, dropout)
+//   EPI_A0 / A_ERF / A_TANH : bf16 output with ONE store-layout operand: a residual (A0: no activation) or the act' operand
+//                             of a GELU (no forward activation); its vectors are requested per batch of 2 row slabs before
+//                             that batch's first store
+//   EPI_F32                 : fp32 C / split-K partial sums / accumulation (16-byte stores straight from the accumulator quads)
+//   EPI_GEN                 : everything else for bf16 outputs (ReLU / SiLU / QuickGELU heads, activation + residual, both
+//                             operands): activation codes are runtime switches
+// Why compile time and not `if (p.residual)` / `switch (p.act)` inside one body (both measured, profiles/r02_gemm_phase_ablation.txt):
+//  * hipcc's wait-count pass cannot know which side of a runtime branch ran, so in front of every store whose address / data
+//    temporaries were allocated to registers that ANOTHER path loads into it emits s_waitcnt vmcnt(0) -- on the hardware that
+//    drains every outstanding store and the LDS-DMA queue of the next tile, once per store: 85 us of a 275-us plain
+//    20832 x 4096 x 1024 launch (raw stores alone: 30 us);
+//  * a load issued after stores can only be waited for together with those stores (one in-order counter): load latency and
+//    store latency serialise per unit; with the loads in front of the stores the compiler's counted waits are exact;
+//  * an eight-way activation switch per 4 values, fully unrolled over 2 x TM x 4 groups, is ~25 000 instructions of
+//    epilogue per kernel: the fused fc1 epilogue spent more time fetching code than storing (+110 us at 20832 x 4096).
+enum { EPI_P0 = 0, EPI_P_ERF = 1, EPI_P_TANH = 2, EPI_A0 = 3, EPI_A_ERF = 4, EPI_A_TANH = 5, EPI_F32 = 6, EPI_GEN = 7, EPI_COUNT = 8 };
+constexpr bool epi_aux(int e) { return e == EPI_A0 || e == EPI_A_ERF || e == EPI_A_TANH || e == EPI_GEN; }
+constexpr int epi_act(int e) {    // forward activation: compile-time code, or -1 = read p.act
+  return (e == EPI_P0 || e == EPI_A0 || e == EPI_A_ERF || e == EPI_A_TANH) ? ACT_NONE : e == EPI_P_ERF ? ACT_GELU_ERF : e == EPI_P_TANH ? ACT_GELU_TANH : -1;
+}
+constexpr int epi_dact(int e) {   // act' operand: 0 = none, compile-time code, or -1 = runtime (p.dact_aux / p.dact)
+  return e == EPI_A_ERF ? ACT_GELU_ERF : e == EPI_A_TANH ? ACT_GELU_TANH : (e == EPI_GEN || e == EPI_F32) ? -1 : 0;
+}
+constexpr int epi_res(int e) {    // residual: 0 = none, 1 = present, -1 = runtime
+  return e == EPI_A0 ? 1 : (e == EPI_GEN || e == EPI_F32) ? -1 : 0;
+}
+inline int epi_class(const GemmKArgs& a) {
+  if (a.split_k > 1 || a.c_f32) return EPI_F32;
+  const bool dact = a.dact_aux != nullptr, res = a.residual != nullptr;
+  if (!dact && !res) return a.act == ACT_NONE ? EPI_P0 : a.act == ACT_GELU_ERF ? EPI_P_ERF : a.act == ACT_GELU_TANH ? EPI_P_TANH : EPI_GEN;
+  if (a.act != ACT_NONE || (dact && res)) return EPI_GEN;
+  if (res) return EPI_A0;
+  return a.dact == ACT_GELU_ERF ? EPI_A_ERF : a.dact == ACT_GELU_TANH ? EPI_A_TANH : EPI_GEN;
+}
+
+template <int ACT>
+__device__ __forceinline__ void act_fwd4_sel(float (&z)[4], int runtime_act) {
+  if constexpr (ACT >= 0) { if constexpr (ACT != ACT_NONE) act_fwd4_c<ACT>(z); } else act_fwd4(z, runtime_act);
+}
+template <int ACT>
+__device__ __forceinline__ void act_bwd8_mul_sel(float (&v)[8], const float (&a)[8], int runtime_act) {
+  if constexpr (ACT > 0) act_bwd8_mul_c<ACT>(v, a); else act_bwd8_mul(v, a, runtime_act);
+}
+
+template <int TM, int EPI>
 __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], int lane, int64_t m_base,
                                              int64_t n_base, int split) {
-  const int l31 = lane & 31, g = lane >> 5;
   if (n_base >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
-  const bool split_out = p.split_k > 1;
-  const bool f32_out = split_out || p.c_f32;
-  const bool has_dact = p.dact_aux != nullptr, has_res = p.residual != nullptr;
+  constexpr bool AUXV = epi_aux(EPI);            // store-layout operand vectors are prefetched (bf16 outputs)
+  constexpr bool AUX = AUXV || EPI == EPI_F32;   // the class may read an act' operand / a residual / old C values at all
+  const int l31 = lane & 31, g = lane >> 5;
+  const bool split_out = EPI == EPI_F32 && p.split_k > 1;
+  constexpr bool f32_out = EPI == EPI_F32;
+  const bool has_dact = epi_dact(EPI) > 0 || (epi_dact(EPI) < 0 && p.dact_aux != nullptr);
+  const bool has_res = epi_res(EPI) > 0 || (epi_res(EPI) < 0 && p.residual != nullptr);
   const bool has_bias = !split_out && p.bias != nullptr;
+  const bool two_aux = has_dact && has_res;   // none of the model's GEMMs has both: the act' operand is then read late
 
-  // bias of this lane's 32 columns, packed bf16 pairs (fp32 bias vectors are read per use: rare)
-  uint32_t bias_pk[2][4][2];
-  if (has_bias && !p.bias_f32) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+  // Store-layout operand vectors (EPI_AUX): requested per BATCH of JB = 2 row slabs (8 vectors = 32 VGPRs per lane) before
+  // that batch's first store.  A 128-row wave block (TM = 4) therefore has ONE point per tile where loads follow stores
+  // (all 16 vectors at once = 64 VGPRs next to the 128 accumulators made hipcc spill ~100 registers).
+  constexpr int JB = TM < 2 ? TM : 2, NB = TM / JB;
+  static_for<NB>([&](auto bc) {
+  constexpr int jb0 = decltype(bc)::value * JB;
+  u32x4 aux[AUXV ? 4 * JB : 1];   // [(2 i + q) * JB + (j - jb0)], compile-time indices only (plain vector type: registers)
+  if constexpr (AUXV) {
+    static_for<JB>([&](auto jc) {
+      constexpr int j = jb0 + decltype(jc)::value;
+      const int64_t m = m_base + j * 32 + l31;
+      const int64_t mc = m < p.M ? m : p.M - 1;
+      const int64_t rr = (has_res && p.res_rows > 0) ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
+      const bf16_t* src = has_res ? p.residual + rr * p.ld_res : p.dact_aux + mc * p.ld_dact;
+      static_for<4>([&](auto cc) {
+        constexpr int i = decltype(cc)::value >> 1, q = decltype(cc)::value & 1;
+        aux[(2 * i + q) * JB + (j - jb0)] = *reinterpret_cast<const u32x4*>(src + n_base + 32 * i + 16 * q + 8 * g);
+      });
+    });
+  }
+
+  // Work unit = one 32 x 32 accumulator tile (i, j); i (column group) is the OUTER loop so that only the 8 packed bias
+  // dwords of one column group are live; a sched_barrier closes every unit (keeps the scheduler from hoisting all the
+  // conversion work of the block to the top and spilling next to the 128 accumulators).
+  static_for<2>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    uint32_t bias_pk[4][2];
+    if (has_bias && !p.bias_f32) {
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
-        bias_pk[i][rq][0] = b.x; bias_pk[i][rq][1] = b.y;
+        bias_pk[rq][0] = b.x; bias_pk[rq][1] = b.y;
       }
-  }
-  static_for<TM>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    const int64_t m = m_base + j * 32 + l31;
-    const bool row_ok = m < p.M;
-    const int64_t mc = row_ok ? m : p.M - 1;
-    uint32_t rowkey = 0;
-    if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
+    }
+    float bias_f[4][4];
+    if (has_bias && p.bias_f32) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
+        bias_f[rq][0] = b.x; bias_f[rq][1] = b.y; bias_f[rq][2] = b.z; bias_f[rq][3] = b.w;
+      }
+    }
+    static_for<JB>([&](auto jc) {
+      constexpr int j = jb0 + decltype(jc)::value;
+      const int64_t m = m_base + j * 32 + l31;
+      const bool row_ok = m < p.M;
+      const int64_t mc = row_ok ? m : p.M - 1;
+      uint32_t rowkey = 0;
+      if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
 
-    auto biased = [&](int i, int rq, float (&z)[4]) {
+      auto biased = [&](int rq, float (&z)[4]) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) z[e] = acc[i][j][4 * rq + e];
-      if (has_bias) {
-        if (p.bias_f32) {
-          const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
-          z[0] += b.x; z[1] += b.y; z[2] += b.z; z[3] += b.w;
-        } else {
-          float b0, b1, b2, b3;
-          unpack2(bias_pk[i][rq][0], b0, b1); unpack2(bias_pk[i][rq][1], b2, b3);
-          z[0] += b0; z[1] += b1; z[2] += b2; z[3] += b3;
-        }
-      }
-    };
-    auto act_drop = [&](int i, int rq, float (&z)[4]) {
-      act_fwd4(z, p.act);
-      if (p.has_drop) {
-        const uint32_t n = (uint32_t)(n_base + 32 * i + 8 * rq + 4 * g);
+        for (int e = 0; e < 4; ++e) z[e] = acc[i][j][4 * rq + e];
+        if (has_bias) {
+          if (p.bias_f32) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t h = drop_hash_rk(rowkey, n + e);
-          z[e] = (h >= p.drop_thr) ? z[e] * p.drop_scale : 0.f;
+            for (int e = 0; e < 4; ++e) z[e] += bias_f[rq][e];
+          } else {
+            float b0, b1, b2, b3;
+            unpack2(bias_pk[rq][0], b0, b1); unpack2(bias_pk[rq][1], b2, b3);
+            z[0] += b0; z[1] += b1; z[2] += b2; z[3] += b3;
+          }
         }
-      }
-    };
+      };
+      auto act_drop = [&](int rq, float (&z)[4]) {
+        act_fwd4_sel<epi_act(EPI)>(z, p.act);
+        if (p.has_drop) {
+          const uint32_t n = (uint32_t)(n_base + 32 * i + 8 * rq + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t h = drop_hash_rk(rowkey, n + e);
+            z[e] = (h >= p.drop_thr) ? z[e] * p.drop_scale : 0.f;
+          }
+        }
+      };
 
-    if (f32_out) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
+      if constexpr (f32_out) {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           float z[4];
-          biased(i, rq, z);
+          biased(rq, z);
           const int64_t n = n_base + 32 * i + 8 * rq + 4 * g;
           if (split_out) {
             if (row_ok) *reinterpret_cast<float4*>(p.workspace + ((int64_t)split * p.M + m) * p.N + n) = make_float4(z[0], z[1], z[2], z[3]);
@@ -999,94 +858,86 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = bf2f(f2bf(z[e]));
           }
-          act_drop(i, rq, z);
-          if (has_dact) {
-            const uint2 a = *reinterpret_cast<const uint2*>(p.dact_aux + mc * p.ld_dact + n);
-            float a0, a1, a2, a3;
-            unpack2(a.x, a0, a1); unpack2(a.y, a2, a3);
-            z[0] *= act_bwd(a0, p.dact); z[1] *= act_bwd(a1, p.dact); z[2] *= act_bwd(a2, p.dact); z[3] *= act_bwd(a3, p.dact);
-          }
-          if (has_res) {
-            const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
-            const uint2 a = *reinterpret_cast<const uint2*>(p.residual + rr * p.ld_res + n);
-            float a0, a1, a2, a3;
-            unpack2(a.x, a0, a1); unpack2(a.y, a2, a3);
-            z[0] += a0; z[1] += a1; z[2] += a2; z[3] += a3;
+          act_drop(rq, z);
+          if constexpr (AUX) {
+            if (has_dact) {
+              const uint2 a = *reinterpret_cast<const uint2*>(p.dact_aux + mc * p.ld_dact + n);
+              float a0, a1, a2, a3;
+              unpack2(a.x, a0, a1); unpack2(a.y, a2, a3);
+              z[0] *= act_bwd(a0, p.dact); z[1] *= act_bwd(a1, p.dact); z[2] *= act_bwd(a2, p.dact); z[3] *= act_bwd(a3, p.dact);
+            }
+            if (has_res) {
+              const int64_t rr = p.res_rows > 0 ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
+              const uint2 a = *reinterpret_cast<const uint2*>(p.residual + rr * p.ld_res + n);
+              float a0, a1, a2, a3;
+              unpack2(a.x, a0, a1); unpack2(a.y, a2, a3);
+              z[0] += a0; z[1] += a1; z[2] += a2; z[3] += a3;
+            }
           }
           if (row_ok) {
             float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n);
             float4 o = make_float4(z[0], z[1], z[2], z[3]);
-            if (p.accumulate) { const float4 old = *c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+            if constexpr (AUX) {
+              if (p.accumulate) { const float4 old = *c; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+            }
             *c = o;
           }
         }
-      return;
-    }
-
-    // ---- bf16 output ----
-    // store-layout operands of this 32-row slab: requested up front (8 x 16 B per lane) so that their latency overlaps
-    // the activation arithmetic
-    uint4 aux[2][2];
-    const bool two_aux = has_dact && has_res;   // none of the model's GEMMs has both: the act' operand is then read late
-    if (has_res || has_dact) {
-      const int64_t rr = (has_res && p.res_rows > 0) ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
-      const bf16_t* src = has_res ? p.residual + rr * p.ld_res : p.dact_aux + mc * p.ld_dact;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) aux[i][q] = *reinterpret_cast<const uint4*>(src + n_base + 32 * i + 16 * q + 8 * g);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int64_t ncol = n_base + 32 * i + 16 * q + 8 * g;   // this lane's 16 bytes in the store layout
-        float z0[4], z1[4];
-        biased(i, 2 * q, z0);
-        biased(i, 2 * q + 1, z1);
-        if (p.preact) {
+      } else {
+        static_for<2>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const int64_t ncol = n_base + 32 * i + 16 * q + 8 * g;   // this lane's 16 bytes in the store layout
+          float z0[4], z1[4];
+          biased(2 * q, z0);
+          biased(2 * q + 1, z1);
+          if (p.preact) {
+            uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
+            // the activation sees the stored (bf16) pre-activation
+            unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
+            swap_halves(a0, b0); swap_halves(a1, b1);
+            if (row_ok) *reinterpret_cast<uint4*>(p.preact + m * p.ld_preact + ncol) = make_uint4(a0, a1, b0, b1);
+          }
+          act_drop(2 * q, z0);
+          act_drop(2 * q + 1, z1);
           uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
-          // the activation sees the stored (bf16) pre-activation
-          unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
-          swap_halves(a0, b0); swap_halves(a1, b1);
-          if (row_ok) *reinterpret_cast<uint4*>(p.preact + m * p.ld_preact + ncol) = make_uint4(a0, a1, b0, b1);
-        }
-        act_drop(i, 2 * q, z0);
-        act_drop(i, 2 * q + 1, z1);
-        uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
-        if (has_res || has_dact) {
-          // act' / residual are applied to the ROUNDED branch value (the reference materialises it as a bf16 tensor)
-          unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
-          if (has_dact) {
-            uint4 u = aux[i][q];
-            if (two_aux) u = *reinterpret_cast<const uint4*>(p.dact_aux + mc * p.ld_dact + ncol);
-            swap_halves(u.x, u.z); swap_halves(u.y, u.w);   // -> accumulator layout: (x, y) = quad 2q, (z, w) = quad 2q+1
-            float x0[4], x1[4];
-            unpack2(u.x, x0[0], x0[1]); unpack2(u.y, x0[2], x0[3]); unpack2(u.z, x1[0], x1[1]); unpack2(u.w, x1[2], x1[3]);
-            float v8[8] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3]};
-            const float a8[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            act_bwd8_mul(v8, a8, p.dact);
+          if constexpr (AUXV) {
+            // act' / residual are applied to the ROUNDED branch value (the reference materialises it as a bf16 tensor)
+            unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
+            if (has_dact) {
+              u32x4 u = aux[(2 * i + q) * JB + (j - jb0)];
+              if (two_aux) u = *reinterpret_cast<const u32x4*>(p.dact_aux + mc * p.ld_dact + ncol);
+              uint32_t ux = u.x, uy = u.y, uz = u.z, uw = u.w;
+              swap_halves(ux, uz); swap_halves(uy, uw);   // -> accumulator layout: (x, y) = quad 2q, (z, w) = quad 2q+1
+              float a8[8];
+              unpack2(ux, a8[0], a8[1]); unpack2(uy, a8[2], a8[3]); unpack2(uz, a8[4], a8[5]); unpack2(uw, a8[6], a8[7]);
+              float v8[8] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3]};
+              act_bwd8_mul_sel<epi_dact(EPI)>(v8, a8, p.dact);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { z0[e] = v8[e]; z1[e] = v8[4 + e]; }
+              for (int e = 0; e < 4; ++e) { z0[e] = v8[e]; z1[e] = v8[4 + e]; }
+            }
+            if (has_res) {
+              const u32x4 u = aux[(2 * i + q) * JB + (j - jb0)];
+              uint32_t ux = u.x, uy = u.y, uz = u.z, uw = u.w;
+              swap_halves(ux, uz); swap_halves(uy, uw);
+              float r0, r1;
+              unpack2(ux, r0, r1); z0[0] += r0; z0[1] += r1;
+              unpack2(uy, r0, r1); z0[2] += r0; z0[3] += r1;
+              unpack2(uz, r0, r1); z1[0] += r0; z1[1] += r1;
+              unpack2(uw, r0, r1); z1[2] += r0; z1[3] += r1;
+            }
+            a0 = pack2bf(z0[0], z0[1]); a1 = pack2bf(z0[2], z0[3]); b0 = pack2bf(z1[0], z1[1]); b1 = pack2bf(z1[2], z1[3]);
           }
-          if (has_res) {
-            uint4 u = aux[i][q];
-            swap_halves(u.x, u.z); swap_halves(u.y, u.w);
-            float r0, r1;
-            unpack2(u.x, r0, r1); z0[0] += r0; z0[1] += r1;
-            unpack2(u.y, r0, r1); z0[2] += r0; z0[3] += r1;
-            unpack2(u.z, r0, r1); z1[0] += r0; z1[1] += r1;
-            unpack2(u.w, r0, r1); z1[2] += r0; z1[3] += r1;
-          }
-          a0 = pack2bf(z0[0], z0[1]); a1 = pack2bf(z0[2], z0[3]); b0 = pack2bf(z1[0], z1[1]); b1 = pack2bf(z1[2], z1[3]);
-        }
-        swap_halves(a0, b0); swap_halves(a1, b1);
-        if (row_ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + ncol) = make_uint4(a0, a1, b0, b1);
+          swap_halves(a0, b0); swap_halves(a1, b1);
+          if (row_ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + ncol) = make_uint4(a0, a1, b0, b1);
+        });
       }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
   });
 }
 
-template <class RC, bool A_T, bool B_T>
+template <class RC, bool A_T, bool B_T, int EPI>
 __global__ __launch_bounds__(RC::NT) __attribute__((amdgpu_waves_per_eu(RC::WPE, RC::WPE)))
 void gemm_ring_kernel(GemmKArgs p) {
   constexpr int BM = RC::BM, BN = RC::BN, TM = RC::TM, TN = RC::TN, CPW = RC::CPW, NS = RC::NS, PD = RC::NS - 1;
@@ -1154,7 +1005,6 @@ void gemm_ring_kernel(GemmKArgs p) {
 #pragma unroll
   for (int d = 0; d < PD; ++d) issue_next();
 
-  char* patch = smem + RC::RING_BYTES + wave * RC::PATCH_BYTES;
   int cslot = 0;
   for (int it = 0;; ++it) {
     const int id = item_of(it);
@@ -1196,8 +1046,7 @@ void gemm_ring_kernel(GemmKArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       cslot = (cslot + 1 == NS) ? 0 : cslot + 1;
     }
-    if (p.direct_store == 3) reg_epilogue<TM>(p, acc, lane, w.m0 + wm * (TM * 32), w.n0 + wn * 64, w.split);
-    else ring_epilogue<TM, RC::PROWS>(p, acc, patch, lane, w.m0 + wm * (TM * 32), w.n0 + wn * 64, w.split);
+    reg_epilogue<TM, EPI>(p, acc, lane, w.m0 + wm * (TM * 32), w.n0 + wn * 64, w.split);
   }
 }
 
@@ -1224,10 +1073,10 @@ void launch_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
   hipLaunchKernelGGL(kern, grid, block, CF::SMEM_BYTES, stream, a);
 }
 
-template <class RC, bool A_T, bool B_T>
+template <class RC, bool A_T, bool B_T, int EPI>
 void launch_ring_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = &gemm_ring_kernel<RC, A_T, B_T>;
+  auto kern = &gemm_ring_kernel<RC, A_T, B_T, EPI>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RC::SMEM_BYTES);
     attr_set = true;

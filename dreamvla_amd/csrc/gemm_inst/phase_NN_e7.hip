@@ -1,0 +1,2 @@
+#include "../gemm_phase.h"
+namespace dvla_gemm { template void launch_phase_one<false, false, 7, 0>(const GemmKArgs&, int, hipStream_t); }

@@ -1,0 +1,2 @@
+#include "../gemm_impl.h"
+namespace dvla_gemm { template void launch_ring_one<RCfgL, true, true, 6>(const GemmKArgs&, int, hipStream_t); }

@@ -1,0 +1,2 @@
+#include "../gemm_impl.h"
+namespace dvla_gemm { template void launch_ring_one<RCfgS, true, false, 0>(const GemmKArgs&, int, hipStream_t); }

@@ -1,0 +1,265 @@
+// gemm_phase.h -- "phase" GEMM: 256 x 256 tile, K-tile 64, two wave groups in ping-pong on every SIMD.
+//
+//   C[M,N] = epilogue( A[M,K] . B[N,K]^T ), same parameter block / operand layouts / epilogue as the ring kernels.
+//
+// Why another structure (profiles/r02_gemm_probe_*.txt): every ring configuration ends up at the same 520-860 TFLOP/s on
+// the model's shapes -- one barrier per 32-wide stage with all eight waves reading fragments, then all eight multiplying,
+// leaves the matrix pipe idle while LDS is read and LDS idle while the pipe runs; 64-byte LDS rows fetch half cache lines;
+// and a K-tile of 64 does not fit a 3-deep stage ring at 256 x 256 (3 x 64 KiB).  This kernel keeps TWO 64-KiB K-tile
+// buffers and gets its look-ahead from refilling each operand image as soon as ITS last fragment read has retired:
+//
+//   waves 0-3 (group 0: rows 0-127 of the tile) and waves 4-7 (group 1: rows 128-255) sit pairwise on the four SIMDs and
+//   run the same segment sequence one barrier apart, so that a SIMD always has one wave multiplying and one loading:
+//
+//     per K-tile u (buffer u & 1):    LOAD1 | MFMA1 | LOAD2 | MFMA2        (| = s_barrier; group 1 is one segment behind)
+//       LOAD1: fragments a-lo (rows 0-63 of the wave's 128) x 4 k-steps and all B fragments (64 columns x 4 k-steps)
+//       MFMA1: 16 x v_mfma_f32_32x32x16_bf16 (a-lo x B); between them this wave's 4 DMA pieces of the A image of tile u+1
+//              (buffer (u+1)&1: last read in LOAD2(u-1))
+//       LOAD2: fragments a-hi into the a-lo registers
+//       MFMA2: 16 MFMAs (a-hi x B, B fragments still in registers); between them 4 DMA pieces of the B image of tile u+2
+//              (buffer u&1: its B fragments were all read in LOAD1(u), by both groups, two / three segments ago)
+//     every ds_read of a segment is waited for (lgkmcnt(0)) BEFORE the barrier that ends the segment -- the wait is hidden
+//     under the partner's MFMA segment -- so "read in segment s" means "retired by the end of s", which is what the refill
+//     rule above needs.  RAW: at the end of MFMA2(u) every wave waits vmcnt(4): all of its pieces except the 4 B(u+2) pieces
+//     it issued last have landed, i.e. A(u+1) and B(u+1); group 1 (whose MFMA2(u) ends one slot after group 0 starts reading
+//     tile u+1) additionally waits for its B(u+1) pieces at the end of its LOAD2(u).  The barriers publish; A runs one tile
+//     ahead, B two.
+//   The DMA stream never stops at an output-tile boundary (two cursors walk the work-item list ahead of the multiply); at a
+//   boundary the groups re-align with one extra barrier, run the register-only epilogue at the same time and re-stagger.
+//
+// Requirements (dispatcher falls back otherwise): as ring_ok with BKS = 64: 16-B-vectorisable operands / outputs,
+// K-range % 64 == 0, N % 64 == 0, M >= 256, N >= 256, r-contiguous operands with rows % 256 == 0.
+#pragma once
+#include "gemm_impl.h"
+
+namespace dvla_gemm {
+
+struct PCfg {
+  static constexpr int BM = 256, BN = 256, BKS = 64, GH = 4, NT = 512, TM = 4, TN = 2;
+  static constexpr int A_BYTES = BM * BKS * 2, B_BYTES = BN * BKS * 2, BUF_BYTES = A_BYTES + B_BYTES;
+  static constexpr int SMEM_BYTES = 2 * BUF_BYTES;   // 128 KiB
+  static constexpr int WG_PER_CU = 1;
+  static constexpr int CPW = 4;                      // DMA pieces (1 KiB each) per wave and operand image
+};
+
+// DBG (ablation builds, results are garbage by design; variants 81..86 of the NT layout): 1 = no MFMAs, 2 = no fragment
+// reads, 4 = no DMA, 8 = no barriers inside the K loop
+template <bool A_T, bool B_T, int EPI, int DBG = 0>
+__global__ __launch_bounds__(PCfg::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_phase_kernel(GemmKArgs p) {
+  constexpr int BM = PCfg::BM, BN = PCfg::BN, BKS = PCfg::BKS, CPW = PCfg::CPW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, wc = wave & 3;    // group = row half of the tile, wc = 64-column quarter
+
+  const int nitems = p.tiles_m * p.tiles_n * p.split_k;
+  const int grid = gridDim.x;
+  const int perm = (grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  auto item_of = [&](int it) -> int {
+    const int id = it * grid + perm;
+    return id < nitems ? id : -1;
+  };
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- DMA cursors: cursor X walks the K-tiles of the work-item list for operand X; this wave owns pieces
+  // 4*wave .. 4*wave+3 of every 32-piece operand image.  nA / nB = number of tiles issued so far (buffer = n & 1). ----
+  const bf16_t* srcA[CPW];
+  const bf16_t* srcB[CPW];
+  int itA = 0, ktA = 0, nkA = 0, nA = 0; bool liveA = false;
+  int itB = 0, ktB = 0, nkB = 0, nB = 0; bool liveB = false;
+  const int64_t stepA = A_T ? (int64_t)BKS * p.lda : (int64_t)BKS;
+  const int64_t stepB = B_T ? (int64_t)BKS * p.ldb : (int64_t)BKS;
+  auto openA = [&](int it) {
+    const int id = item_of(it);
+    liveA = id >= 0;
+    if (!liveA) return;
+    const RingItem w = ring_item<PCfg>(p, id);
+    nkA = w.ns; ktA = 0;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) srcA[i] = dma_src<A_T, BM, BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, wave * CPW + i, lane);
+  };
+  auto openB = [&](int it) {
+    const int id = item_of(it);
+    liveB = id >= 0;
+    if (!liveB) return;
+    const RingItem w = ring_item<PCfg>(p, id);
+    nkB = w.ns; ktB = 0;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) srcB[i] = dma_src<B_T, BN, BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, wave * CPW + i, lane);
+  };
+  // one DMA piece (i = 0..3) of the next A / B image; *_done advances the cursor after the 4th.  Split like this so that
+  // the pieces can be issued BETWEEN the MFMAs of a multiply segment: an LDS-DMA issue (M0 write + VMEM issue) costs
+  // 100-185 cycles inside a fragment-read segment but hides in the shadow of a 32-cycle MFMA (the first version issued
+  // them in the LOAD segments: those then took ~900 cycles against the partner's 512-cycle MFMA segment and paced the loop).
+  auto pieceA = [&](int i) {
+    const uint32_t dst = smem_base + (uint32_t)((nA & 1) * PCfg::BUF_BYTES + wave * (CPW * 1024) + i * 1024);
+    glds16(srcA[i], __builtin_amdgcn_readfirstlane(dst));
+    srcA[i] += stepA;
+  };
+  auto doneA = [&]() { ++nA; if (++ktA == nkA) openA(++itA); };
+  auto pieceB = [&](int i) {
+    const uint32_t dst = smem_base + (uint32_t)((nB & 1) * PCfg::BUF_BYTES + PCfg::A_BYTES + wave * (CPW * 1024) + i * 1024);
+    glds16(srcB[i], __builtin_amdgcn_readfirstlane(dst));
+    srcB[i] += stepB;
+  };
+  auto doneB = [&]() { ++nB; if (++ktB == nkB) openB(++itB); };
+  auto issueA = [&]() -> bool {
+    if (!liveA) return false;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) pieceA(i);
+    doneA();
+    return true;
+  };
+  auto issueB = [&]() -> bool {
+    if (!liveB) return false;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) pieceB(i);
+    doneB();
+    return true;
+  };
+
+  // ---- prologue: A(0), B(0), B(1); everything but B(1) must have landed before the first fragment read ----
+  openA(0); openB(0);
+  issueA();
+  issueB();
+  const bool b1 = issueB();
+  if (b1) wait_vmcnt<CPW>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  int u = 0;   // global K-tile counter of the multiply
+  for (int it = 0;; ++it) {
+    const int id = item_of(it);
+    if (id < 0) break;
+    const RingItem w = ring_item<PCfg>(p, id);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one segment behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int kt = 0; kt < w.ns; ++kt, ++u) {
+      const char* bufA = smem + (u & 1) * PCfg::BUF_BYTES;
+      const char* bufB = bufA + PCfg::A_BYTES;
+      bf16x8 fa[2][4], fb[2][4];   // [sub-tile][k16-step]
+      if (DBG & 2) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y) { fa[x][y] = bf16x8{1, 2, 3, 4, 5, 6, 7, (short)lane}; fb[x][y] = bf16x8{1, 2, 3, 4, 5, 6, 7, (short)kt}; }
+      }
+
+      // ---------------- LOAD1 ----------------
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) if (!(DBG & 2)) fb[i][ks] = ring_frag<B_T, BN, BKS>(bufB, wc * 64 + i * 32, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + j * 32, ks, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lds();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
+      // ---------------- MFMA1 (+ the 4 pieces of A(u+1), one behind every 4th MFMA) ----------------
+      const bool ia = liveA;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (!(DBG & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][ks], fa[j][ks], acc[i][j], 0, 0, 0);
+            else asm volatile("" :: "v"(fb[i][ks]), "v"(fa[j][ks]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (ia && !(DBG & 4)) pieceA(ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (ia) doneA();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
+      // ---------------- LOAD2 ----------------
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + 64 + j * 32, ks, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      // group 1 sits one segment behind: its B(u+1) pieces (issued in ITS MFMA2(u-1), one slot after group 0's) must have
+      // landed before group 0 reads tile u+1 in the next slot; its 4 youngest pieces are A(u+1) (only group 1 itself reads
+      // those when A is k-contiguous: rows 128-255; an r-contiguous A image is shared, so then everything is waited for)
+      if (grp == 1) { if (ia && !A_T) wait_vmcnt<CPW>(); else wait_vmcnt<0>(); }
+      wait_lds();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
+      // ---------------- MFMA2 (+ the 4 pieces of B(u+2)) ----------------
+      const bool ib = liveB;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (!(DBG & 1)) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][ks], fa[j][ks], acc[i][2 + j], 0, 0, 0);
+            else asm volatile("" :: "v"(fb[i][ks]), "v"(fa[j][ks]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (ib && !(DBG & 4)) pieceB(ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (ib) doneB();
+      __builtin_amdgcn_sched_barrier(0);
+      // everything but the B(u+2) pieces just issued has landed: A(u+1) (and, for group 0, B(u+1))
+      if (ib) wait_vmcnt<CPW>(); else wait_vmcnt<0>();
+      if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align: both groups run the epilogue together
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG & 16) {        // no epilogue at all (keep the accumulators alive)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else if (DBG & 32) { // stores only: 16 x 16 B per lane straight from accumulator registers (no conversion, no exchange)
+      const int l31 = lane & 31, g = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t m = w.m0 + grp * 128 + j * 32 + l31;
+        if (m < p.M) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + w.n0 + wc * 64 + 16 * q + 8 * g) =
+                make_uint4(__float_as_uint(acc[q >> 1][j][4 * (q & 1)]), __float_as_uint(acc[q >> 1][j][4 * (q & 1) + 1]),
+                           __float_as_uint(acc[q >> 1][j][4 * (q & 1) + 2]), __float_as_uint(acc[q >> 1][j][4 * (q & 1) + 3]));
+        }
+      }
+    } else {
+      reg_epilogue<4, EPI>(p, acc, lane, w.m0 + grp * 128, w.n0 + wc * 64, w.split);
+    }
+  }
+}
+
+template <bool A_T, bool B_T, int EPI, int DBG = 0>
+void launch_phase_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = &gemm_phase_kernel<A_T, B_T, EPI, DBG>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PCfg::SMEM_BYTES);
+    attr_set = true;
+  }
+  const int64_t items = (int64_t)a.tiles_m * a.tiles_n * split_k;
+  const int64_t slots = (int64_t)num_cus();
+  dim3 grid((unsigned)(items < slots ? items : slots), 1, 1), block(PCfg::NT, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, PCfg::SMEM_BYTES, stream, a);
+}
+
+}  // namespace dvla_gemm

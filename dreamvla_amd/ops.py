@@ -134,7 +134,8 @@ class GemmTuner:
     """Online choice of the GEMM kernel configuration per problem key (like a convolution autotuner).
 
     include/dvla.h exposes the configurations of the hand-written kernels through `dvla_set_gemm_variant` (0 = the
-    library's cost model, 2 = register-staged 128x128, 4 / 5 / 6 = LDS-DMA ring 256x256 / 256x128 / 128x128; they differ
+    library's cost model, 2 = register-staged 128x128, 4 / 6 / 7 = LDS-DMA ring 256x256 / 128x128 / 256x128 BK64, 8 = phase
+    kernel 256x256 BK64; they differ
     only in fp32 summation order).  Which one is fastest depends on more than (M, N, K): the epilogue, what the
     neighbouring kernels left in L2 / Infinity Cache, the clocks.  So the first calls of every key run the candidates IN
     TURN -- each real call is executed exactly once, with one candidate, bracketed by two events that are read back later
@@ -143,7 +144,7 @@ class GemmTuner:
     library, so every trial is valid.  Disable with DVLA_GEMM_AUTOTUNE=0 (the cost model is then used for every call).
     Every candidate is a hand-written HIP kernel of libdvla_hip.so: no vendor GEMM library is linked or offered (the
     hipBLASLt yardstick lives in libdvla_cmp.so and is driven only by tests/library_yardstick.py)."""
-    CANDIDATES = tuple(int(v) for v in os.environ.get("DVLA_GEMM_CANDIDATES", "0,4,5,6,2").split(","))
+    CANDIDATES = tuple(int(v) for v in os.environ.get("DVLA_GEMM_CANDIDATES", "0,4,6,7,8,2").split(","))
     ROUNDS = int(os.environ.get("DVLA_GEMM_TUNE_ROUNDS", "2"))
     enabled = os.environ.get("DVLA_GEMM_AUTOTUNE", "1") != "0" and os.environ.get("DVLA_GEMM_VARIANT") is None
     table = {}      # key -> locked variant

@@ -265,11 +265,79 @@ def amp_deviation(name, runs=2):
     print(name, [None if w is None else round(w["rel_l2"], 5) for w in worst])
 
 
+def grad_fixture(name):
+    """Gradients of the REAL reference (its own autograd, fp32) for the scalar  sum_o <o, w_o>  (w_o seeded, one per
+    output; tests/model_checks.py::output_weights builds the same) on the fixture's inputs: per trainable tensor its
+    norm and a strided sample, plus the reference's own amp-bf16 (autocast) gradient deviation rel-L2 from them.
+    tests/golden/grads_<name>.pt pins the oracle's autograd (CPU test) and sets the per-tensor tolerance of the GPU
+    gradient check (max(floor, 2 x the reference's own deviation))."""
+    path = os.path.join(GOLD, f"dreamvla_{name}.pt")
+    fx = torch.load(path, map_location="cpu")
+    cfg = fx["cfg"]
+    m = build_reference_model(cfg)
+    B, S = fx["B"], fx["S"]
+    b = weights.synthetic_batch(B, S, window=fx["window"], seed=fx["seed"])
+    for k in ("image_primary", "image_wrist", "state", "text_token"):
+        b[k] = b[k][:, :S]
+    if "state" in fx:
+        b["state"] = fx["state"]
+    real = {k: getattr(torch, k) for k in ("randn_like", "randint", "randn")}
+    if cfg["use_dit_head"]:
+        noise, tstep = fx["dit_noise"], fx["dit_timestep"]
+        torch.randn_like = lambda x, **k: noise.clone()
+        torch.randint = lambda *a, **k: tstep.clone()
+
+    def run(amp):
+        m.zero_grad(set_to_none=True)
+        if amp:
+            with torch.autocast("cpu", dtype=BF):
+                out = m(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], action=None,
+                        action_label=fx["action_label"], mode="train")
+        else:
+            out = m(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], action=None,
+                    action_label=fx["action_label"], mode="train")
+        g = torch.Generator().manual_seed(5)
+        seen, loss = set(), 0.0
+        for o in out:
+            if o is None:
+                continue
+            w = torch.randn(o.shape, generator=g).to(BF).float()
+            if id(o) in seen:          # DiT training returns the same loss tensor in slots 0 and 1: count it once
+                continue
+            seen.add(id(o))
+            loss = loss + (o.float() * w).sum()
+        loss.backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+    try:
+        g32 = run(False)
+        g16 = run(True)
+    finally:
+        for k, v in real.items():
+            setattr(torch, k, v)
+    entries = {}
+    for k, g in g32.items():
+        n = float(g.norm())
+        if n == 0.0:
+            continue
+        flat = g.flatten()
+        idx = torch.linspace(0, flat.numel() - 1, min(flat.numel(), 512)).long()
+        dev = float((g16[k].float() - g).norm() / n) if k in g16 else None
+        entries[k] = dict(norm=n, idx=idx, vals=flat[idx].clone(), amp_rel_l2=dev, absmax=float(g.abs().max()))
+    torch.save(dict(entries=entries, source="real reference autograd (fp32) + its own autocast-bf16 deviation; oracle/make_golden.py grads"),
+               os.path.join(GOLD, f"grads_{name}.pt"))
+    devs = sorted((e["amp_rel_l2"] for e in entries.values() if e["amp_rel_l2"] is not None))
+    print(name, len(entries), "tensors; reference amp-bf16 gradient deviation median %.4f max %.4f" % (devs[len(devs) // 2], devs[-1]))
+
+
 def main(only=()):
     """`python -m oracle.make_golden E` regenerates only the named full-model fixture(s)"""
     assert ref_loader.available(), "needs /root/reference"
     os.makedirs(GOLD, exist_ok=True)
     src = "generated by oracle/make_golden.py from the REAL reference modules under /root/reference"
+    if only and only[0] == "grads":
+        for name in only[1:]:
+            grad_fixture(name)
+        return
     if only and only[0] == "amp":
         for name in only[1:]:
             amp_deviation(name)

@@ -41,12 +41,33 @@ def oracle_module_outputs(fx):
     return out
 
 
-def compare_outputs(got, want_list, tol, tag):
-    """got: 10-tuple of tensors/None; want_list: golden list (tensors, None or sampled dicts) -> list of metric dicts"""
-    names = ["arm_action", "gripper_action", "image_pred", "arm_state", "gripper_state", "loss_arm", "depth_pred",
-             "traj_pred", "dino_pred", "sam_pred"]
+OUTPUT_NAMES = ["arm_action", "gripper_action", "image_pred", "arm_state", "gripper_state", "loss_arm", "depth_pred",
+                "traj_pred", "dino_pred", "sam_pred"]
+TOL_FLOOR = 1e-3        # north_star: "within 1e-3 rel bf16"
+
+
+def output_tolerances(fx, fallback):
+    """per-output (rel-L2 tolerance, max-abs tolerance): max(1e-3, 2 x the REAL reference's own autocast-bf16 deviation
+    from its fp32 result on the same inputs) -- recorded per output in the fixture by oracle/make_golden.py `amp`
+    (fx["ref_amp_bf16_deviation"]).  The reference's bf16 mode is the only meaningful floor for a bf16 implementation of
+    a multi-layer pipeline: every op boundary rounds.  `fallback` is used only for fixtures without the record."""
+    dev = fx.get("ref_amp_bf16_deviation")
+    out = []
+    for i in range(len(OUTPUT_NAMES)):
+        d = dev[i] if dev is not None and i < len(dev) else None
+        if d is None:
+            out.append((fallback, None))
+        else:
+            out.append((max(TOL_FLOOR, 2.0 * d["rel_l2"]), max(2.0 * d["max_abs"], 4.0 * 2.0 ** -8 * d["absmax"])))
+    return out
+
+
+def compare_outputs(got, want_list, tol, tag, fx=None):
+    """got: 10-tuple of tensors/None; want_list: golden list (tensors, None or sampled dicts) -> list of metric dicts.
+    With `fx` the tolerance of each output comes from the fixture (output_tolerances); `tol` is the fallback."""
+    tols = output_tolerances(fx, tol) if fx is not None else [(tol, None)] * len(OUTPUT_NAMES)
     res = []
-    for nm, g, w in zip(names, got, want_list):
+    for nm, g, w, (t_rel, t_abs) in zip(OUTPUT_NAMES, got, want_list, tols):
         if w is None:
             assert g is None, f"{tag}.{nm}: expected None"
             continue
@@ -54,11 +75,19 @@ def compare_outputs(got, want_list, tol, tag):
         if isinstance(w, dict):
             assert list(g.shape) == w["shape"], f"{tag}.{nm}: shape {list(g.shape)} vs {w['shape']}"
             gv = g.detach().float().cpu().flatten()[w["idx"]]
-            r = rel_l2(gv, w["vals"])
+            wv = w["vals"]
         else:
             assert tuple(g.shape) == tuple(w.shape), f"{tag}.{nm}: shape {tuple(g.shape)} vs {tuple(w.shape)}"
-            r = rel_l2(g, w)
-        res.append({"name": f"{tag}.{nm}", "rel_l2": r, "tol": tol, "ok": r <= tol})
+            gv, wv = g.detach().float().cpu().flatten(), w.detach().float().flatten()
+        if gv.numel() == 1:      # scalar outputs (the DiT loss) are judged by the action-MSE rule of the caller
+            r = float((gv - wv).abs() / max(float(wv.abs()), 1e-12))
+            st = t_rel if fx is None else max(t_rel, 3e-3)
+            res.append({"name": f"{tag}.{nm}", "rel_l2": r, "tol": st, "ok": r <= st})
+            continue
+        r = rel_l2(gv, wv)
+        max_abs = float((gv - wv).abs().max())
+        ok = r <= t_rel and (t_abs is None or max_abs <= t_abs)
+        res.append({"name": f"{tag}.{nm}", "rel_l2": r, "tol": t_rel, "max_abs": max_abs, "max_abs_tol": t_abs, "ok": bool(ok)})
     return res
 
 
@@ -101,7 +130,7 @@ def smoke_checks():
 # HIP modules vs golden module fixtures (GPU)
 # ---------------------------------------------------------------------------------------------------
 TOL_MODULE = 1e-2   # 2-layer bf16 pipelines vs the fp32 reference: every op boundary rounds to bf16
-TOL_MODEL = 3e-2    # whole model (ViT-B 12 layers + resampler + trunk + heads) in bf16 vs fp32 reference
+TOL_MODEL = 3e-2    # fallback only (outputs without a recorded reference bf16 deviation: the DDIM test path)
 
 
 def _dev(sd):
@@ -167,7 +196,7 @@ def hip_full_model_checks(name):
         if fx["cfg"]["use_dit_head"]:
             m.action_model._injected = (fx["dit_noise"].to("cuda", BF), fx["dit_timestep"].to("cuda"))
         out = m(*args, action_label=fx["action_label"].to("cuda", BF), mode="train")
-        res += compare_outputs(out, fx["train"], TOL_MODEL, f"hip.{name}.train")
+        res += compare_outputs(out, fx["train"], TOL_MODEL, f"hip.{name}.train", fx=fx)
         if fx["cfg"]["use_dit_head"]:
             want, got = float(fx["train"][0]), float(out[0])
             # north_star: action-MSE parity within 1e-3 (relative once the loss exceeds 1) -- or, where the REAL reference's
@@ -219,10 +248,53 @@ def hip_text_sharing_checks():
     return res
 
 
-def hip_grad_checks():
-    """whole-model backward on config A (dream heads + MLP action head) vs oracle autograd in fp32: per-parameter
-    gradient cosine similarity for the trainable tensors that receive gradient."""
-    fx = load("dreamvla_A.pt")
+def output_weights(outs, seed=5):
+    """seeded weight per output for the scalar  sum_o <o, w_o>  (same stream as oracle/make_golden.py grad_fixture);
+    an output object that appears twice (DiT training: slots 0 and 1 are one tensor) is counted once"""
+    g = torch.Generator().manual_seed(seed)
+    ws, seen = [], set()
+    for o in outs:
+        if o is None:
+            ws.append(None)
+            continue
+        w = torch.randn(o.shape, generator=g).to(BF).float()
+        if id(o) in seen:
+            ws.append(None)
+            continue
+        seen.add(id(o))
+        ws.append(w)
+    return ws
+
+
+def oracle_grads(fx, sd32):
+    """oracle autograd (fp32, CPU) of sum_o <o, w_o> on the fixture's inputs -> ({param: grad}, outputs, weights)"""
+    cfg = fx["cfg"]
+    inp = golden_inputs(fx)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd32.items()
+              if torch.is_floating_point(v) and not k.startswith(("clip_model.", "vision_encoder.")) and k != "attention_mask"
+              and "decoder_position_embedding" not in k}
+    sdr = dict(sd32); sdr.update(leaves)
+    kw = {}
+    if cfg["use_dit_head"]:
+        kw = dict(dit_noise=fx["dit_noise"], dit_timestep=fx["dit_timestep"])
+    out_r = M.dreamvla_forward(sdr, cfg, inp["image_primary"], inp["image_wrist"], inp["state"], inp["text_token"],
+                               action_label=fx["action_label"], mode="train", **kw)
+    ws = output_weights(out_r)
+    loss_r = sum((o.float() * w).sum() for o, w in zip(out_r, ws) if w is not None)
+    loss_r.backward()
+    return {k: v.grad for k, v in leaves.items() if v.grad is not None}, out_r, ws
+
+
+GRAD_TOL_FLOOR = 4e-3    # single-kernel gradient tolerance (gpu_checks.TOL_GRAD): bf16 P / dS fragments
+
+
+def hip_grad_checks(name="A"):
+    """whole-model backward (dream heads + action head) vs oracle autograd in fp32, per trainable tensor, by rel-L2.
+    Tolerance per tensor = max(4e-3, 2 x the REAL reference's own autocast-bf16 gradient deviation on the same inputs)
+    (tests/golden/grads_<name>.pt, oracle/make_golden.py `grads`); the oracle's autograd itself is pinned against the
+    real reference's gradients in tests/test_golden_oracle.py."""
+    fx = load(f"dreamvla_{name}.pt")
+    gfx = load(f"grads_{name}.pt")["entries"]
     cfg = fx["cfg"]
     m = build_hip_model(cfg)
     sd32 = f32(m.state_dict())
@@ -230,39 +302,32 @@ def hip_grad_checks():
     m._init_model_type()
     m.eval()
     inp = golden_inputs(fx)
-    g = torch.Generator().manual_seed(5)
-    # oracle: trainable leaves = everything except clip / vision encoder / tables
-    leaves = {k: v.clone().requires_grad_(True) for k, v in sd32.items()
-              if torch.is_floating_point(v) and not k.startswith(("clip_model.", "vision_encoder.")) and k != "attention_mask"
-              and "decoder_position_embedding" not in k}
-    sdr = dict(sd32); sdr.update(leaves)
-    out_r = M.dreamvla_forward(sdr, cfg, inp["image_primary"], inp["image_wrist"], inp["state"], inp["text_token"],
-                               action_label=fx["action_label"], mode="train")
-    ws = [torch.randn(o.shape, generator=g).to(BF).float() if o is not None else None for o in out_r]
-    loss_r = sum((o * w).sum() for o, w in zip(out_r, ws) if o is not None)
-    loss_r.backward()
+    ref_grads, out_r, ws = oracle_grads(fx, sd32)
+    if cfg["use_dit_head"]:
+        m.action_model._injected = (fx["dit_noise"].to("cuda", BF), fx["dit_timestep"].to("cuda"))
     out = m(inp["image_primary"].to("cuda", BF), inp["image_wrist"].to("cuda", BF), inp["state"].to("cuda", BF),
             inp["text_token"].to("cuda"), action_label=fx["action_label"].to("cuda", BF), mode="train")
-    loss = sum((o.float() * w.to("cuda")).sum() for o, w in zip(out, ws) if o is not None)
+    loss = sum((o.float() * w.to("cuda")).sum() for o, w in zip(out, ws) if w is not None)
     loss.backward()
     res = []
     params = dict(m.named_parameters())
-    worst = (1.0, "")
+    worst = (0.0, "", 0.0)
     n_checked = 0
-    for k, leaf in leaves.items():
-        if leaf.grad is None or float(leaf.grad.norm()) == 0.0:
+    for k, gr in ref_grads.items():
+        if float(gr.norm()) == 0.0:
             continue
         p = params.get(k)
         if p is None or p.grad is None:
             res.append({"name": f"grad.{k}", "rel_l2": 1.0, "tol": 0.0, "ok": False, "error": "no gradient on the HIP side"})
             continue
-        a, b = p.grad.detach().float().cpu().flatten(), leaf.grad.flatten()
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        dev = (gfx.get(k) or {}).get("amp_rel_l2")
+        tol = max(GRAD_TOL_FLOOR, 2.0 * dev) if dev is not None else 2e-2
+        r = rel_l2(p.grad, gr)
         n_checked += 1
-        if cos < worst[0]:
-            worst = (cos, k)
-        if cos < 0.98:
-            res.append({"name": f"grad.{k}", "rel_l2": 1 - cos, "tol": 0.02, "ok": False})
-    res.append({"name": f"grad cosine over {n_checked} parameter tensors (worst {worst[1]})", "rel_l2": 1 - worst[0], "tol": 0.02,
-                "ok": worst[0] >= 0.98 and n_checked > 50})
+        if r / tol > worst[0]:
+            worst = (r / tol, k, r)
+        if r > tol:
+            res.append({"name": f"grad.{name}.{k}", "rel_l2": r, "tol": tol, "ok": False})
+    res.append({"name": f"grad.{name} rel-L2 over {n_checked} parameter tensors (worst vs its tolerance: {worst[1]} {worst[2]:.2e})",
+                "rel_l2": worst[0], "tol": 1.0, "ok": worst[0] <= 1.0 and n_checked > 50})
     return res

@@ -222,6 +222,18 @@ int main(int argc, char** argv) {
       {"dW c_proj", 1024, 1024, 20832, 1, 1, "f32", 10},
       {"square", 8192, 8192, 8192, 0, 0, "plain", 1},
     };
+  } else if (which == "plain") {
+    cases = {
+      {"NT plain", 20832, 4096, 1024, 0, 0, "plain", 1},
+      {"NT plain", 20832, 1024, 4096, 0, 0, "plain", 1},
+      {"NT plain", 88256, 3072, 768, 0, 0, "plain", 1},
+      {"NT plain K64", 20832, 4096, 64, 0, 0, "plain", 1},
+      {"NT plain K256", 20832, 4096, 256, 0, 0, "plain", 1},
+      {"NT plain K2048", 20832, 4096, 2048, 0, 0, "plain", 1},
+      {"NT fused K64", 20832, 4096, 64, 0, 0, "gelu_tanh_preact", 1},
+      {"NT fused", 20832, 4096, 1024, 0, 0, "gelu_tanh_preact", 1},
+      {"square", 8192, 8192, 8192, 0, 0, "plain", 1},
+    };
   } else if (which == "small") {
     cases = {
       {"trunk fc1 fwd", 20832, 4096, 1024, 0, 1, "gelu_tanh_preact", 1},

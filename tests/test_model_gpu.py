@@ -16,8 +16,10 @@ def test_hip_modules_vs_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["A", "B", "E"])
+@pytest.mark.parametrize("name", ["A", "B", "E", "C"])
 def test_hip_full_model_vs_golden(name):
+    """C = the benchmarked configuration (S = 7, 24 layers, head set C, L = 651 with key compaction 651 -> 378), B = 1;
+    per-output tolerance = max(1e-3, 2 x the real reference's own autocast-bf16 deviation) recorded in the fixture"""
     _assert_all(C.hip_full_model_checks(name))
 
 
@@ -27,8 +29,9 @@ def test_text_tower_shared_over_time():
 
 
 @pytest.mark.gpu
-def test_hip_whole_model_gradients_vs_oracle():
-    _assert_all(C.hip_grad_checks())
+@pytest.mark.parametrize("name", ["A", "C"])
+def test_hip_whole_model_gradients_vs_oracle(name):
+    _assert_all(C.hip_grad_checks(name))
 
 
 @pytest.mark.gpu
