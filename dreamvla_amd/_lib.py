@@ -59,6 +59,12 @@ class AttnParams(C.Structure):
     ]
 
 
+class MaskRule(C.Structure):
+    _fields_ = [("K", C.c_int32), ("num_A", C.c_int32), ("num_B", C.c_int32), ("num_obs", C.c_int32),
+                ("action_pred_steps", C.c_int32), ("atten_goal", C.c_int32), ("atten_goal_state", C.c_int32),
+                ("atten_only_obs", C.c_int32), ("attn_robot_proprio_state", C.c_int32), ("n_drop", C.c_int32)]
+
+
 class TokenSrc(C.Structure):
     _fields_ = [("base", C.c_void_p), ("stride_b", C.c_int64), ("stride_s", C.c_int64), ("tok_begin", C.c_int32),
                 ("tok_count", C.c_int32)]
@@ -90,6 +96,7 @@ SYMBOLS = {
     "dvla_cast_bf16_to_f32": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
     "dvla_assemble_tokens": (C.c_int, [C.POINTER(TokenSrc), _I32, _P, _I64, _P, _I32, _I32, _I32, _I32, _P]),
+    "dvla_mask_tables": (C.c_int, [C.POINTER(MaskRule), _P, _P, _P, _P, _P, _P]),
     "dvla_loss_partial_len": (C.c_int64, []),
     "dvla_patch_mse_fwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _P, _I64, _P, _P, _P]),
     "dvla_patch_mse_bwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _P, _I64, _P, C.POINTER(FrameView), _P]),

@@ -775,6 +775,7 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
   constexpr int jb0 = decltype(bc)::value * JB;
   u32x4 aux[AUXV ? 4 * JB : 1];   // [(2 i + q) * JB + (j - jb0)], compile-time indices only (plain vector type: registers)
   if constexpr (AUXV) {
+    if (has_res || has_dact)          // (EPI_GEN also serves activation-only epilogues: nothing to prefetch then)
     static_for<JB>([&](auto jc) {
       constexpr int j = jb0 + decltype(jc)::value;
       const int64_t m = m_base + j * 32 + l31;

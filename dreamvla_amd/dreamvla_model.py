@@ -304,6 +304,22 @@ class DreamVLA(nn.Module):
             attn_robot_proprio_state=self.attn_robot_proprio_state, mask_l_obs_ratio=self.mask_l_obs_ratio,
             num_obs_token=nq, action_pred_steps=self.action_pred_steps)
 
+    def _mask_rule(self):
+        nq = self._num_query_tokens()
+        return dict(K=self.sequence_length, num_A=1 + 1 + self.NUM_RESAMPLER_QUERY * 2 + 1 * 2, num_B=nq + self.action_pred_steps,
+                    atten_goal=self.atten_goal, atten_goal_state=self.atten_goal_state, atten_only_obs=self.atten_only_obs,
+                    attn_robot_proprio_state=self.attn_robot_proprio_state, num_obs_token=nq,
+                    action_pred_steps=self.action_pred_steps)
+
+    def _pretrain_mask_tables(self, device):
+        """Pretrain phase (dreamvla_model.py:610-628): a new mask every training step.  The random part -- which obs-token
+        columns `mask_l_obs_ratio` hides -- is drawn on the host with numpy's RNG exactly as generate_attention_mask draws
+        it; the kernels' tables are then computed on the device from the rule (ops.build_mask_tables_device): no (L, L)
+        tensor, no upload of one, no device -> host copy.  `self.attention_mask` (a state_dict entry) keeps its value."""
+        r = self._mask_rule()
+        drop = ops.draw_mask_drop(r["K"], r["num_obs_token"], r["action_pred_steps"], r["atten_only_obs"], self.mask_l_obs_ratio)
+        return ops.build_mask_tables_device(device, drop=drop, **r)
+
     def _fill_decoder_pos(self, param, n_obs, n_mask):
         obs = get_2d_sincos_pos_embed(self.hidden_dim, int(n_obs ** .5), cls_token=False)
         msk = get_2d_sincos_pos_embed(self.hidden_dim, int(n_mask ** .5), cls_token=False)
@@ -360,8 +376,9 @@ class DreamVLA(nn.Module):
 
     def forward(self, image_primary, image_wrist, state, text_token, action=None, track_infos=None, action_label=None,
                 mode='train'):
+        self._step_mask_tables = None
         if self.training and self.phase == "pretrain":
-            self.attention_mask = nn.Parameter(self._make_mask().to(self.attention_mask.device), requires_grad=False)
+            self._step_mask_tables = self._pretrain_mask_tables(self.attention_mask.device)
         parts = self.encode_frames(image_primary, image_wrist, state, text_token)
         return self.decode_tokens(parts, action_label=action_label, mode=mode)
 
@@ -458,7 +475,8 @@ class DreamVLA(nn.Module):
 
         # trunk                                                                              (762-790)
         transformer_input = self.embedding_layer_norm(transformer_input)
-        transformer_output = self.transformer_backbone(inputs_embeds=transformer_input, attention_mask=self.attention_mask)
+        transformer_output = self.transformer_backbone(inputs_embeds=transformer_input, attention_mask=self.attention_mask,
+                                                       mask_tables=getattr(self, "_step_mask_tables", None))
         transformer_output = transformer_output.view(B, S, -1, H)
 
         # dream heads (training only)                                                        (792-911)

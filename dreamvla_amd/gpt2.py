@@ -122,11 +122,11 @@ class GPT2Model(nn.Module):
             if name == "c_proj.weight":
                 p.data.normal_(mean=0.0, std=(std / math.sqrt(2 * self.config.n_layer)))
 
-    def forward(self, attention_mask=None, inputs_embeds=None):
+    def forward(self, attention_mask=None, inputs_embeds=None, mask_tables=None):
         """inputs_embeds (B, L, H); attention_mask: additive 0/-inf mask, (L, L) or the (B,1,L,L) expansion the
         reference's sdpa branch builds (dreamvla_model.py:769-775) -- the batch copies are identical, row 0 is used."""
-        mt = None
-        if attention_mask is not None:
+        mt = mask_tables      # tables built on the device from the mask rule (pretrain phase): `attention_mask` is then unused
+        if mt is None and attention_mask is not None:
             m2 = attention_mask
             while m2.dim() > 2:
                 m2 = m2[0]

@@ -440,19 +440,97 @@ def build_mask_tables(mask, device=None, compact_keys=True):
                       float(vis.mean()))
 
 
+def draw_mask_drop(K, num_obs_token, action_pred_steps, atten_only_obs, mask_l_obs_ratio):
+    """The obs-token columns that `mask_l_obs_ratio` hides from the action rows of every window step, drawn with numpy's
+    global RNG in the order generate_attention_mask draws them (dreamvla_model.py:49-59: one np.random.choice per window
+    step, only when the atten_only_obs branch is taken).  -> int32 array (K, count), count = int(ratio * num_obs)."""
+    import numpy as np
+    draws = bool(num_obs_token > 0 and atten_only_obs and action_pred_steps and mask_l_obs_ratio > 0)
+    count = int(mask_l_obs_ratio * num_obs_token) if draws else 0
+    out = np.zeros((K, count), dtype=np.int32)
+    if draws:       # also when count == 0: np.random.choice(..., size=0, replace=False) still advances the stream
+        for i in range(K):
+            out[i] = np.random.choice(range(num_obs_token), size=count, replace=False)
+    return out
+
+
+def mask_rule_visible(K, num_A, num_B, atten_goal, atten_goal_state, atten_only_obs, attn_robot_proprio_state, num_obs_token,
+                      action_pred_steps, drop):
+    """Host mirror (numpy, boolean (L, L)) of the predicate csrc/masks.hip evaluates on the device -- documentation and the
+    CPU test's subject (tests/test_mask.py pins it bit for bit against the reference's generate_attention_mask)."""
+    import numpy as np
+    blk = num_A + num_B
+    L = K * blk
+    r = np.arange(L)[:, None]
+    c = np.arange(L)[None, :]
+    i, ro, j, co = r // blk, r % blk, c // blk, c % blk
+    has_act = num_obs_token > 0 and action_pred_steps > 0
+    act_row = has_act & (ro >= num_A + num_obs_token) & (ro < num_A + num_obs_token + action_pred_steps)
+    obs_col = (co >= num_A) & (co < num_A + num_obs_token)
+    base = ((j <= i) & (co < num_A)) | (act_row & (j == i) & obs_col)
+    if atten_only_obs and has_act:
+        dropped = np.zeros((K, max(num_obs_token, 1)), dtype=bool)
+        for s in range(K):
+            dropped[s, np.asarray(drop[s], dtype=np.int64)] = True
+        is_dropped = dropped[np.broadcast_to(i, (L, L)), np.clip(np.broadcast_to(co, (L, L)) - num_A, 0, max(num_obs_token, 1) - 1)] & obs_col
+        only = (j == i) & (((co >= 2) & (co < num_A)) | (obs_col & ~is_dropped) | (bool(attn_robot_proprio_state) & (co == 1)))
+        vis = np.where(act_row, only, base)
+    else:
+        vis = base
+    if num_obs_token > 0 and atten_goal and atten_goal_state:
+        obs_row = (ro >= num_A) & (ro < num_A + num_obs_token)
+        vis = vis | (obs_row & (i < K - atten_goal) & (c == (i + atten_goal) * blk + 1))
+    return vis
+
+
+def build_mask_tables_device(device, *, K, num_A, num_B, atten_goal=0, atten_goal_state=False, atten_only_obs=False,
+                             attn_robot_proprio_state=False, num_obs_token=0, action_pred_steps=0, drop=None):
+    """MaskTables of generate_attention_mask(K, num_A, num_B, ...) computed ON THE DEVICE from the rule (csrc/masks.hip):
+    no (L, L) tensor, no device -> host copy, no synchronisation.  `drop` = draw_mask_drop(...) (host numpy, (K, count))."""
+    import numpy as np
+    lib = _lib.load()
+    has_act = num_obs_token > 0 and action_pred_steps > 0
+    n_drop = 0 if (drop is None or not (atten_only_obs and has_act)) else int(drop.shape[1])
+    blk = num_A + num_B
+    L = K * blk
+    per_step = num_A + ((num_obs_token - n_drop) if has_act else 0)
+    Lk = K * per_step
+    nqt, nkt = (L + 31) // 32, (Lk + 31) // 32
+    rule = _lib.MaskRule(K, num_A, num_B, num_obs_token, action_pred_steps, int(atten_goal), int(bool(atten_goal_state)),
+                         int(bool(atten_only_obs)), int(bool(attn_robot_proprio_state)), n_drop)
+    drop_dev = None
+    if n_drop > 0:
+        drop_dev = torch.from_numpy(np.ascontiguousarray(drop, dtype=np.int32)).to(device, non_blocking=True)
+    key_index = torch.empty(Lk, dtype=torch.int32, device=device)
+    bits_q = torch.empty((L, nkt), dtype=torch.int32, device=device)
+    bits_k = torch.empty((Lk, nqt), dtype=torch.int32, device=device)
+    tile_map = torch.empty((nqt, nkt), dtype=torch.uint8, device=device)
+    check(lib.dvla_mask_tables(C.byref(rule), _ptr(drop_dev), key_index.data_ptr(), bits_q.data_ptr(), bits_k.data_ptr(),
+                               tile_map.data_ptr(), _stream()), "dvla_mask_tables")
+    mt = MaskTables(L, L, Lk, key_index if Lk < L else None, bits_q, bits_k, tile_map, float("nan"))
+    mt._keep = drop_dev     # the kernels above read it asynchronously
+    return mt
+
+
 _MASK_CACHE = {}
 
 
 def mask_tables_for(mask):
-    """Cached build_mask_tables keyed on the mask tensor's storage + version (the reference keeps the mask as an
-    nn.Parameter and regenerates it only in the pretrain phase, dreamvla_model.py:286-298,610-628)."""
-    key = (mask.data_ptr(), mask._version, tuple(mask.shape), str(mask.device))
-    mt = _MASK_CACHE.get(key)
-    if mt is None:
-        if len(_MASK_CACHE) > 16:
-            _MASK_CACHE.clear()
-        mt = build_mask_tables(mask)
-        _MASK_CACHE[key] = mt
+    """Cached build_mask_tables for a mask TENSOR OBJECT (the reference keeps the mask as an nn.Parameter,
+    dreamvla_model.py:286-298).  The cache entry holds a weak reference to the tensor and is valid only for that very object
+    at that version: a freed mask's storage address can be handed to the next mask of the same size by the caching
+    allocator, so (data_ptr, shape) alone would return the tables of a mask that no longer exists (round-1 ADVICE)."""
+    import weakref
+    key = id(mask)
+    ent = _MASK_CACHE.get(key)
+    if ent is not None:
+        ref, version, mt = ent
+        if ref() is mask and version == mask._version:
+            return mt
+    for k in [k for k, (r, _, _) in _MASK_CACHE.items() if r() is None]:
+        del _MASK_CACHE[k]
+    mt = build_mask_tables(mask)
+    _MASK_CACHE[key] = (weakref.ref(mask), mask._version, mt)
     return mt
 
 

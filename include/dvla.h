@@ -216,6 +216,24 @@ int dvla_silog_loss_fwd(const dvla_frame_view* pred, const dvla_frame_view* dept
 int dvla_silog_loss_bwd(const dvla_frame_view* pred, const dvla_frame_view* depth, int64_t n_frames, float lambd, const float* out2,
                         const float* grad_out, const dvla_frame_view* dpred, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Attention-mask tables from the block-mask RULE, on the device.
+ * Replaces the per-step host regeneration + upload of the (L, L) additive mask in the pretrain phase
+ * (models/dreamvla_model.py:610-628 calling generate_attention_mask, 25-66) and the host-side derivation of the
+ * kernels' tables from it.  `rule` are generate_attention_mask's own arguments; `drop` (device, [K][n_drop] int32) are
+ * the obs-token indices that `mask_l_obs_ratio` drew for each window step with numpy's RNG on the host (n_drop =
+ * int(ratio * num_obs); the draw stays on the host so the stream is consumed exactly as the reference consumes it).
+ * Outputs (device, caller-allocated): key_index (Lk int32), bits_q (L x ceil(Lk/32) uint32), bits_k (Lk x ceil(L/32)),
+ * tile_map (ceil(L/32) x ceil(Lk/32) uint8), where L = K (num_A + num_B) and Lk = K (num_A + kept obs columns) --
+ * exactly the tables dvla_attn_fwd / dvla_attn_bwd take.  No host synchronisation, capturable. */
+typedef struct dvla_mask_rule {
+  int32_t K, num_A, num_B, num_obs, action_pred_steps;
+  int32_t atten_goal, atten_goal_state, atten_only_obs, attn_robot_proprio_state;
+  int32_t n_drop;
+} dvla_mask_rule;
+int dvla_mask_tables(const dvla_mask_rule* rule, const int32_t* drop, int32_t* key_index, uint32_t* bits_q, uint32_t* bits_k,
+                     uint8_t* tile_map, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

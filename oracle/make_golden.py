@@ -213,6 +213,18 @@ def full_fixture(name):
     return fx
 
 
+def _patch_q_sample(m):
+    """The reference's DiT loss cannot run under `--precision bf16` as written: GaussianDiffusion.q_sample multiplies by
+    float32 schedule tensors, so x_t reaches the bf16 DiT as float32 and F.linear raises (action_model.py:57-66; the
+    shipped scripts use --precision fp32).  For the bf16-cast DEVIATION records only (tolerance floors, never golden
+    values) x_t is cast to the noise's dtype -- the one-line fix any bf16 run of the reference would need."""
+    am = getattr(m, "action_model", None)
+    if am is None or not hasattr(am, "diffusion"):
+        return
+    orig = am.diffusion.q_sample
+    am.diffusion.q_sample = lambda x, t, noise=None: orig(x, t, noise).to(x.dtype)
+
+
 def _out_rel(a, b):
     a, b = a.detach().float().flatten(), b.detach().float().flatten()
     return float((a - b).norm() / max(float(b.norm()), 1e-12))
@@ -261,8 +273,29 @@ def amp_deviation(name, runs=2):
             worst.append(dict(rel_l2=max(d[i]["rel_l2"] for d in devs), max_abs=max(d[i]["max_abs"] for d in devs),
                               absmax=devs[0][i]["absmax"]))
     fx["ref_amp_bf16_deviation"] = worst
+    # the reference's `--precision bf16` mode proper (train.py:122-123: model.bfloat16(), inputs cast by the loop): every
+    # parameter, the residual stream and the normalisations in bf16 -- the mode the HIP path implements
+    real = {k: getattr(torch, k) for k in ("randn_like", "randint", "randn")}
+    if cfg["use_dit_head"]:
+        noise, tstep = fx["dit_noise"], fx["dit_timestep"]
+        torch.randn_like = lambda x, **k: noise.clone().to(x.dtype)
+        torch.randint = lambda *a, **k: tstep.clone()
+    try:
+        m16 = m.bfloat16()
+        m16._init_model_type()
+        _patch_q_sample(m16)
+        with torch.no_grad():
+            o16 = m16(b["image_primary"].to(BF), b["image_wrist"].to(BF), b["state"].to(BF), b["text_token"], action=None,
+                      action_label=fx["action_label"].to(BF), mode="train")
+    finally:
+        for k, v in real.items():
+            setattr(torch, k, v)
+    fx["ref_bf16_cast_deviation"] = [None if r is None else
+                                     dict(rel_l2=_out_rel(o, r), max_abs=float((o.float() - r).abs().max()), absmax=float(r.abs().max()))
+                                     for o, r in zip(o16, ref)]
     torch.save(fx, path)
-    print(name, [None if w is None else round(w["rel_l2"], 5) for w in worst])
+    print(name, "autocast", [None if w is None else round(w["rel_l2"], 5) for w in worst])
+    print(name, "bf16 cast", [None if w is None else round(w["rel_l2"], 5) for w in fx["ref_bf16_cast_deviation"]])
 
 
 def grad_fixture(name):
@@ -311,6 +344,16 @@ def grad_fixture(name):
     try:
         g32 = run(False)
         g16 = run(True)
+        # `--precision bf16` proper: the whole module cast (parameters, residual stream, normalisations in bf16)
+        if cfg["use_dit_head"]:
+            torch.randn_like = lambda x, **k: noise.clone().to(x.dtype)
+        m.bfloat16()
+        m._init_model_type()
+        _patch_q_sample(m)
+        for k in ("image_primary", "image_wrist", "state"):
+            b[k] = b[k].to(BF)
+        fx["action_label"] = fx["action_label"].to(BF)
+        gcast = run(False)
     finally:
         for k, v in real.items():
             setattr(torch, k, v)
@@ -322,11 +365,14 @@ def grad_fixture(name):
         flat = g.flatten()
         idx = torch.linspace(0, flat.numel() - 1, min(flat.numel(), 512)).long()
         dev = float((g16[k].float() - g).norm() / n) if k in g16 else None
-        entries[k] = dict(norm=n, idx=idx, vals=flat[idx].clone(), amp_rel_l2=dev, absmax=float(g.abs().max()))
+        devc = float((gcast[k].float() - g).norm() / n) if k in gcast else None
+        entries[k] = dict(norm=n, idx=idx, vals=flat[idx].clone(), amp_rel_l2=dev, cast_rel_l2=devc, absmax=float(g.abs().max()))
     torch.save(dict(entries=entries, source="real reference autograd (fp32) + its own autocast-bf16 deviation; oracle/make_golden.py grads"),
                os.path.join(GOLD, f"grads_{name}.pt"))
     devs = sorted((e["amp_rel_l2"] for e in entries.values() if e["amp_rel_l2"] is not None))
     print(name, len(entries), "tensors; reference amp-bf16 gradient deviation median %.4f max %.4f" % (devs[len(devs) // 2], devs[-1]))
+    devs = sorted((e["cast_rel_l2"] for e in entries.values() if e["cast_rel_l2"] is not None))
+    print(name, "reference bf16-cast gradient deviation median %.4f max %.4f" % (devs[len(devs) // 2], devs[-1]))
 
 
 def main(only=()):

@@ -197,6 +197,14 @@ def check_self_attention(B, H, L, mask_kind="none", dropout_p=0.0, grad=True, se
         mask = make_block_mask(L, 19, 12)
     elif mask_kind == "causal":
         mask = torch.full((L, L), -float("inf")).triu(1)
+    elif mask_kind.startswith("dreamvla"):
+        # the REAL trunk mask of the benchmarked head set (obs + depth + sam dream heads: 54 query tokens + 3 action tokens per
+        # window step, 36 conditioning tokens): L = 93 S; S = 7 is the training window (L = 651, key compaction 651 -> 378),
+        # S = 10 the evaluation window (L = 930).  The generator is pinned bit for bit against the reference (tests/test_mask.py).
+        from dreamvla_amd.dreamvla_model import generate_attention_mask
+        S = L // 93
+        assert L == 93 * S
+        mask = generate_attention_mask(S, 36, 57, 0, False, False, False, 0.0, 54, 3)
     qd = qkv.to(DEV, BF).requires_grad_(grad)
     mt = ops.build_mask_tables(mask, device=DEV) if mask is not None else None
     from dreamvla_amd.ops import _Seeds
@@ -421,6 +429,11 @@ def all_checks(quick=False):
         (check_self_attention, dict(B=2, H=2, L=77, mask_kind="causal")),
         (check_self_attention, dict(B=2, H=2, L=133, mask_kind="block", dropout_p=0.1)),
         (check_self_attention, dict(B=1, H=1, L=64, dropout_p=0.25)),
+        # the benchmarked configuration's attention problem: real generate_attention_mask, 16 heads, forward + backward
+        (check_self_attention, dict(B=2, H=16, L=651, mask_kind="dreamvla")),
+        (check_self_attention, dict(B=2, H=16, L=651, mask_kind="dreamvla", dropout_p=0.1)),
+        (check_self_attention, dict(B=2, H=16, L=930, mask_kind="dreamvla")),
+        (check_self_attention, dict(B=2, H=16, L=930, mask_kind="dreamvla", dropout_p=0.1)),
         (check_cross_attention, dict(B=3, H=8, Lq=16, Lk=212)),
         (check_cross_attention, dict(B=2, H=2, Lq=40, Lk=33)),
     ]

@@ -121,6 +121,8 @@ static Problem make_problem(const Case& c, int64_t M) {
   auto need_bias = [&]() { q.bias = dalloc((size_t)N * 2); fill(q.bias, 3u, 0.5f); p.bias = q.bias.p; p.bias_dtype = DVLA_DT_BF16; };
   if (c.epi == "bias") need_bias();
   if (c.epi == "gelu_erf") { need_bias(); p.act = 1; }
+  if (c.epi == "relu") { need_bias(); p.act = 3; }
+  if (c.epi == "silu_res") { need_bias(); p.act = 4; q.res = dalloc((size_t)M * N * 2); fill(q.res, 4u, 1.0f); p.residual = q.res.p; p.ld_res = N; }
   if (c.epi == "gelu_tanh_preact" || c.epi == "gelu_erf_preact") {
     need_bias(); p.act = c.epi == "gelu_tanh_preact" ? 2 : 1;
     q.preact = dalloc((size_t)M * N * 2); p.preact = q.preact.p; p.ld_preact = N;
@@ -221,6 +223,8 @@ int main(int argc, char** argv) {
       {"dW c_attn", 1024, 3072, 20832, 1, 1, "f32", 6},
       {"dW c_proj", 1024, 1024, 20832, 1, 1, "f32", 10},
       {"square", 8192, 8192, 8192, 0, 0, "plain", 1},
+      {"generic relu", 20832, 1024, 1024, 0, 0, "relu", 1},
+      {"generic silu+res", 20832, 1024, 1024, 0, 1, "silu_res", 1},
     };
   } else if (which == "plain") {
     cases = {

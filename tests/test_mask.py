@@ -62,3 +62,64 @@ def test_mask_tables(compact):
             want = 1 if blk.all() else (0 if not blk.any() else 2)
             assert tm[qt, kt] == want
     assert abs(mt.visible_fraction - V.mean()) < 1e-6
+
+
+def _rule_kw(kw):
+    return dict(K=kw["K"], num_A=kw["num_A"], num_B=kw["num_B"], atten_goal=kw["atten_goal"], atten_goal_state=kw["atten_goal_state"],
+                atten_only_obs=kw["atten_only_obs"], attn_robot_proprio_state=kw["attn_robot_proprio_state"],
+                num_obs_token=kw["num_obs_token"], action_pred_steps=kw["action_pred_steps"])
+
+
+@pytest.mark.parametrize("kw", COMBOS)
+def test_mask_rule_mirror_bit_exact(kw):
+    """the closed-form visibility rule that csrc/masks.hip evaluates on the device (its host mirror
+    ops.mask_rule_visible) against generate_attention_mask for every flag combination, with the mask_l_obs_ratio columns
+    drawn from numpy's stream in the reference's order (ops.draw_mask_drop) -- and the stream must end in the same state."""
+    from dreamvla_amd import ops
+    np.random.seed(123)
+    m = generate_attention_mask(**kw)
+    after_ref = np.random.random()
+    np.random.seed(123)
+    drop = ops.draw_mask_drop(kw["K"], kw["num_obs_token"], kw["action_pred_steps"], kw["atten_only_obs"], kw["mask_l_obs_ratio"])
+    after_ours = np.random.random()
+    assert after_ref == after_ours
+    vis = ops.mask_rule_visible(drop=drop, **_rule_kw(kw))
+    assert vis.shape == tuple(m.shape) and np.array_equal(vis, (m == 0).numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", COMBOS)
+def test_mask_tables_on_device_bit_identical(kw):
+    """dvla_mask_tables (device, from the rule) == build_mask_tables(generate_attention_mask(...)) (host, from the (L, L)
+    tensor): key_index, both bit tables and the tile map, bit for bit."""
+    from dreamvla_amd import ops
+    np.random.seed(123)
+    want = ops.build_mask_tables(generate_attention_mask(**kw), device="cpu")
+    np.random.seed(123)
+    drop = ops.draw_mask_drop(kw["K"], kw["num_obs_token"], kw["action_pred_steps"], kw["atten_only_obs"], kw["mask_l_obs_ratio"])
+    got = ops.build_mask_tables_device("cuda", drop=drop, **_rule_kw(kw))
+    torch.cuda.synchronize()
+    assert (got.Lq, got.Lk_full, got.Lk) == (want.Lq, want.Lk_full, want.Lk)
+    wk = torch.arange(want.Lk_full, dtype=torch.int32) if want.key_index is None else want.key_index
+    gk = torch.arange(got.Lk_full, dtype=torch.int32) if got.key_index is None else got.key_index.cpu()
+    assert torch.equal(gk, wk)
+    assert torch.equal(got.bits_q.cpu(), want.bits_q) and torch.equal(got.bits_k.cpu(), want.bits_k)
+    assert torch.equal(got.tile_map.cpu(), want.tile_map)
+
+
+def test_mask_table_cache_is_per_tensor_object():
+    """round-1 ADVICE: the cache must not serve the tables of a freed mask whose storage address was recycled"""
+    from dreamvla_amd import ops
+    a = generate_attention_mask(3, 36, 21, 0, False, False, False, 0.0, 18, 3)
+    ta = ops.mask_tables_for(a)
+    assert ops.mask_tables_for(a) is ta
+    b = a.clone()
+    b[:, :5] = -float("inf")
+    tb = ops.mask_tables_for(b)
+    assert tb is not ta and tb.Lk == ta.Lk - 5
+    ident = id(a)
+    del a
+    ops._MASK_CACHE[ident] = ops._MASK_CACHE.get(ident, (lambda: None, 0, ta))   # a dead entry under a recyclable id
+    c = generate_attention_mask(3, 36, 21, 0, False, True, True, 0.0, 18, 3)
+    tc = ops.mask_tables_for(c)
+    assert tc is not ta
