@@ -97,6 +97,7 @@ SYMBOLS = {
     "dvla_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
     "dvla_assemble_tokens": (C.c_int, [C.POINTER(TokenSrc), _I32, _P, _I64, _P, _I32, _I32, _I32, _I32, _P]),
     "dvla_mask_tables": (C.c_int, [C.POINTER(MaskRule), _P, _P, _P, _P, _P, _P]),
+    "dvla_image_preprocess": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "dvla_loss_partial_len": (C.c_int64, []),
     "dvla_patch_mse_fwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _P, _I64, _P, _P, _P]),
     "dvla_patch_mse_bwd": (C.c_int, [C.POINTER(FrameView), C.POINTER(FrameView), _P, _I64, _P, C.POINTER(FrameView), _P]),

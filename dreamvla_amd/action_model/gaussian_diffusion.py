@@ -70,11 +70,18 @@ _DEV_TABLES = {}
 def _device_table(arr, device):
     """float64 copy of a schedule table on `device`, made once: the per-call host->device copy of the reference
     (gaussian_diffusion.py:870-882) is a pageable-memory copy, i.e. a host synchronisation per extract (50 per DDIM-10
-    sample) and illegal inside a hipGraph capture.  Same values, same float64 -> float32 gather."""
-    key = (arr.ctypes.data, arr.shape[0], str(device))
-    t = _DEV_TABLES.get(key)
-    if t is None:
-        t = _DEV_TABLES[key] = th.from_numpy(arr).to(device=device)
+    sample) and illegal inside a hipGraph capture.  Same values, same float64 -> float32 gather.
+    The entry keeps the numpy array itself alive and is valid for that very object only: keyed on the bare address, a
+    collected diffusion object's table could be answered with another same-length table allocated at that address
+    (sqrt_one_minus_alphas_cumprod where sqrt_alphas_cumprod was) -- round-1 ADVICE."""
+    key = (id(arr), str(device))
+    ent = _DEV_TABLES.get(key)
+    if ent is not None and ent[0] is arr:
+        return ent[1]
+    if len(_DEV_TABLES) > 256:
+        _DEV_TABLES.clear()
+    t = th.from_numpy(arr).to(device=device)
+    _DEV_TABLES[key] = (arr, t)
     return t
 
 

@@ -155,7 +155,7 @@ class DiT(nn.Module):
 
     def forward(self, x, t, z):
         """x: (N, T, 7) noisy actions, t: (N,) timesteps, z: (N, T', token) conditions -> (N, T, 7)"""
-        wdt = self.x_embedder.linear.weight.dtype
+        wdt = torch.bfloat16       # compute dtype (fp32 parameters are masters: ops.shadow)
         x = self.x_embedder(x.to(wdt))
         t = self.t_embedder(t)
         z = self.z_embedder(z.to(wdt), self.training)
@@ -169,7 +169,7 @@ class DiT(nn.Module):
 
     def forward_with_cfg(self, x, t, z, cfg_scale):
         half = x[: len(x) // 2]
-        combined = torch.cat([half, half], dim=0).to(next(self.x_embedder.parameters()).dtype)
+        combined = torch.cat([half, half], dim=0).to(torch.bfloat16)
         model_out = self.forward(combined, t, z)
         eps, rest = model_out[:, :, :self.in_channels], model_out[:, :, self.in_channels:]
         cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)

@@ -98,25 +98,34 @@ class CLIPTextEncoder(nn.Module):
         return ops.linear(x, self.text_projection, None, conv1d=True)          # x @ text_projection
 
 
-def _identity_preprocess(img):
-    return img
-
-
 def load(name="ViT-B/32", device="cpu", jit=False, download_root=None):
-    """Drop-in for `clip.load(name, device)` -> (model, preprocess) restricted to what DreamVLA uses.  If `name` is a
-    readable TorchScript/state-dict CLIP checkpoint its text-tower tensors are loaded; otherwise seeded-random init."""
+    """Drop-in for `clip.load(name, device)` -> (model, preprocess) restricted to what DreamVLA uses (the text tower and the
+    image transform).  `name` = a readable TorchScript / state-dict CLIP checkpoint: its text-tower tensors are loaded and
+    every text-tower key must be present.  There is no download here (the reference fetches "ViT-B/32" from the network when
+    the file is missing): without a checkpoint the frozen tower is RANDOMLY initialised and the language conditioning is
+    meaningless -- that is said loudly (a warning; DVLA_REQUIRE_CLIP=1 turns it into an error), never silently."""
+    import warnings
+    from .preprocess import clip_image_preprocess
     model = CLIPTextEncoder()
     if isinstance(name, str) and os.path.isfile(name):
         try:
             sd = torch.jit.load(name, map_location="cpu").state_dict()
-        except Exception:  # noqa: BLE001
+        except RuntimeError:       # not a TorchScript archive: a plain state_dict checkpoint
             sd = torch.load(name, map_location="cpu")
             sd = sd.get("state_dict", sd)
-        keep = {k: v for k, v in sd.items() if not k.startswith("visual.") and k in model.state_dict()}
-        model.load_state_dict(keep, strict=False)
+        want = set(model.state_dict())
+        keep = {k: v for k, v in sd.items() if k in want}
+        missing = sorted(want - set(keep))
+        if missing:
+            raise RuntimeError(f"clip_text.load({name!r}): the checkpoint lacks text-tower tensors {missing[:6]}"
+                               f"{' ...' if len(missing) > 6 else ''} ({len(missing)} of {len(want)})")
+        model.load_state_dict(keep, strict=True)
+    else:
+        msg = (f"clip_text.load({name!r}): no CLIP checkpoint file -- the frozen text tower is RANDOMLY initialised "
+               f"(the reference would download ViT-B/32; there is no network here).  Place the checkpoint at the path the "
+               f"caller passes (DreamVLA: checkpoints/clip/ViT-B-32.pt) for meaningful language conditioning.")
+        if os.environ.get("DVLA_REQUIRE_CLIP") == "1":
+            raise FileNotFoundError(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
     model = model.to(device).eval()
-    try:
-        from .preprocess import clip_image_preprocess
-        return model, clip_image_preprocess
-    except Exception:  # noqa: BLE001
-        return model, _identity_preprocess
+    return model, clip_image_preprocess

@@ -18,7 +18,15 @@ are constructed but never used.  This reducer is built for the MI355X node inste
     find_unused_parameters=True).  If the used set ever grows, the bucket is held until `finish()` for that step and the
     set is re-learned; a gradient arriving after its bucket was launched raises (pass static_unused=False to always
     flush such buckets at `finish()`);
-  * `finish()` waits for the handles and averages (divide by world size), exactly DDP's semantics;
+  * collectives are issued in BUCKET INDEX ORDER on every rank, whatever the order in which buckets become ready: a bucket
+    is launched only when every bucket before it has been launched (a held / unfinished bucket therefore also defers the ones
+    behind it to `finish()`), so ranks whose used-parameter sets differ for a step still execute the same sequence;
+  * the average is taken by the collective itself (ReduceOp.AVG on RCCL; SUM + one divide on gloo, which has no AVG):
+    no separate pass over the gradient buffers;
+  * gradient accumulation over several backward passes (the reference's gradient_accumulation_steps,
+    utils/train_utils.py:588-607): run the first passes under `with reducer.no_sync():` -- nothing is launched, gradients
+    add up in the buckets -- and the last one outside it.  A second backward WITHOUT no_sync() after a bucket has been
+    launched raises: its gradients would be added to a buffer that is already being reduced;
   * `direct_grads=True`: `zero_grad()` leaves `p.grad = None` and publishes each parameter's bucket slot as
     `p._dvla_grad_view`; the backward of dreamvla_amd.ops (weight-gradient GEMMs, bias column sums, LayerNorm parameter
     gradients) writes its result straight into that slot and returns it, autograd's AccumulateGrad then adopts the tensor
@@ -35,6 +43,8 @@ class GradBucketReducer:
         self.group = process_group
         self.static_unused = bool(static_unused)
         self.direct_grads = bool(direct_grads)
+        self._no_sync = False
+        self._next_launch = 0   # buckets [0, _next_launch) have been launched this step (index order on every rank)
         self.copied = 0     # direct_grads: gradients the hook had to copy into their slot (not produced in place)
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []       # dicts: flat, params, pending
@@ -78,31 +88,63 @@ class GradBucketReducer:
     def _make_hook(self, bi, pi):
         def hook(param):
             b = self.buckets[bi]
-            if b["fired"][pi]:
-                return
-            b["fired"][pi] = True
+            if b["launched"]:
+                raise RuntimeError("GradBucketReducer: a gradient arrived for a parameter whose bucket is already being "
+                                   "all-reduced (a second backward before zero_grad(), or a parameter that joined the graph "
+                                   "late): run all but the last backward of an accumulation cycle under reducer.no_sync(), or "
+                                   "construct the reducer with static_unused=False")
             if self.direct_grads:       # adopt gradients that were not produced in place
                 view = param._dvla_grad_view
                 g = param.grad
                 if g is not None and g.data_ptr() != view.data_ptr():
-                    view.copy_(g)
+                    if b["fired"][pi]:
+                        view.add_(g)      # accumulation pass: the slot already holds the earlier passes' sum
+                    else:
+                        view.copy_(g)
                     param.grad = view
                     self.copied += 1
+            if b["fired"][pi]:
+                return                    # accumulation pass: already counted
+            b["fired"][pi] = True
             if not b["expected"][pi]:
-                if b["launched"]:
-                    raise RuntimeError("GradBucketReducer: a parameter that received no gradient in earlier steps received one "
-                                       "after its bucket's all-reduce was launched; use static_unused=False")
                 b["hold"] = True          # the used set grew: flush at finish() this step, re-learn there
                 return
             b["pending"] -= 1
-            if b["pending"] == 0 and not b["launched"] and not b["hold"]:
-                self._launch(b)
+            self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """launch, in index order, every leading bucket whose expected gradients have all arrived"""
+        if self._no_sync:
+            return
+        while self._next_launch < len(self.buckets):
+            b = self.buckets[self._next_launch]
+            if b["pending"] != 0 or b["hold"]:
+                return
+            self._launch(b)
 
     def _launch(self, b):
         b["launched"] = True
+        self._next_launch += 1
         if self.world > 1:
-            self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            op = dist.ReduceOp.AVG if self._avg_in_collective() else dist.ReduceOp.SUM
+            self._handles.append(dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True))
+
+    def _avg_in_collective(self):
+        return dist.get_backend(self.group) == "nccl"
+
+    def no_sync(self):
+        """context manager: backward passes inside it only accumulate into the buckets (no collective)"""
+        red = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                red._no_sync = True
+
+            def __exit__(self_inner, *exc):
+                red._no_sync = False
+                return False
+        return _NoSync()
 
     def zero_grad(self):
         """zero the flat buffers (grads stay views) and re-arm the hooks for the next backward."""
@@ -117,12 +159,16 @@ class GradBucketReducer:
                     p.grad = None
                     p._dvla_grad_free = True       # dreamvla_amd.ops may write this step's gradient into the slot once
         self._handles = []
+        self._next_launch = 0
 
     def finish(self):
-        """call after backward(): flush buckets that never completed (unused parameters), wait, average."""
+        """call after the (last) backward(): flush, in index order, the buckets that were not launched during backward (unused
+        parameters, held buckets and everything behind them), wait; the result is the gradient averaged over the ranks."""
+        if self._no_sync:
+            raise RuntimeError("GradBucketReducer.finish() inside no_sync()")
+        for b in self.buckets[self._next_launch:]:
+            self._launch(b)
         for b in self.buckets:
-            if not b["launched"]:
-                self._launch(b)
             if self.static_unused and any(b["fired"]):
                 if b["hold"]:                       # grew: wait for everything seen so far
                     b["expected"] = [e or f for e, f in zip(b["expected"], b["fired"])]
@@ -131,7 +177,7 @@ class GradBucketReducer:
         for h in self._handles:
             h.wait()
         self._handles = []
-        if self.world > 1:
+        if self.world > 1 and not self._avg_in_collective():
             for b in self.buckets:
                 b["flat"].div_(self.world)
 

@@ -382,6 +382,40 @@ class DreamVLA(nn.Module):
         parts = self.encode_frames(image_primary, image_wrist, state, text_token)
         return self.decode_tokens(parts, action_label=action_label, mode=mode)
 
+    def _text_rows_equal(self, text_token):
+        """Are the S token rows of every sample equal?  The FIRST forward answers with one device reduction + read-back and
+        fixes the mode.  In "shared" mode every later forward only LAUNCHES the reduction (result copied asynchronously into
+        pinned host memory) and reads the verdict of the PREVIOUS forward, which has long completed: no host synchronisation
+        per step (round 1 synchronised every forward).  A violated assumption is therefore noticed one forward late and
+        raises -- the earlier step broadcast frame 0's instruction -- instead of training on silently wrong text."""
+        B, S = text_token.shape[0], text_token.shape[1]
+        if S <= 1 or not self.share_text_over_time or not text_token.is_cuda or torch.cuda.is_current_stream_capturing():
+            return False
+        mode = getattr(self, "_text_share_mode", None)
+        if mode is None:
+            mode = "shared" if bool((text_token == text_token[:, :1]).all()) else "per_frame"
+            self._text_share_mode = mode
+            self._text_share_pending = None
+            return mode == "shared"
+        if mode == "per_frame":
+            return False
+        pend = self._text_share_pending
+        if pend is not None:
+            flag, ev = pend
+            ev.synchronize()            # recorded one forward ago: returns at once
+            if not bool(flag.item()):
+                self._text_share_mode = "per_frame"
+                raise RuntimeError("DreamVLA.encode_frames: the instruction tokens of a window differ between frames, but the "
+                                   "previous forward assumed (share_text_over_time, verified asynchronously) that they are "
+                                   "repeated over the window as utils/train_utils.py:124 does; that forward used frame 0's "
+                                   "instruction for every frame.  Set model.share_text_over_time = False for such data.")
+        flag = torch.empty(1, dtype=torch.bool, pin_memory=True)
+        flag.copy_((text_token == text_token[:, :1]).all().reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._text_share_pending = (flag, ev)
+        return True
+
     def encode_frames(self, image_primary, image_wrist, state, text_token):
         """Conditioning tokens of every frame, as the list [text (B,S,1,H), state (B,S,1,H), primary image (B,S,nq,H),
         wrist image (B,S,nq,H), cls primary (B,S,1,H), cls wrist (B,S,1,H)]  (dreamvla_model.py:643-737).  Each frame
@@ -390,14 +424,14 @@ class DreamVLA(nn.Module):
         frames it has already seen and encode only the newest one per control step."""
         B, S, _ = state.shape
         H = self.hidden_dim
-        wdt = self.text_projector.weight.dtype
+        wdt = torch.bfloat16     # compute dtype: fp32 parameters are masters, the kernels run on bf16 shadows (ops.shadow)
 
         # text: frozen CLIP text tower -> Linear(512, H)                                  (643-653)
         # The training loop feeds the SAME instruction to every frame of a window (`text_tokens.unsqueeze(1).repeat(1,
-        # window_size, 1)`, utils/train_utils.py:124): when all S rows of a sample are equal (checked on the device, one
-        # scalar read-back per forward) the 12-layer tower runs on B sequences instead of B*S and the result is broadcast.
-        if (S > 1 and self.share_text_over_time and text_token.is_cuda and not torch.cuda.is_current_stream_capturing()
-                and bool((text_token == text_token[:, :1]).all())):
+        # window_size, 1)`, utils/train_utils.py:124): when all S rows of a sample are equal the 12-layer tower runs on B
+        # sequences instead of B*S and the result is broadcast (self._text_rows_equal: decided once, verified without a
+        # host synchronisation afterwards).
+        if self._text_rows_equal(text_token):
             with torch.no_grad():
                 text_feature = self.clip_model.encode_text(text_token[:, 0].contiguous())
             text_embedding = self.text_projector(text_feature.to(wdt)).view(B, 1, -1, H).expand(B, S, -1, H)
@@ -418,12 +452,12 @@ class DreamVLA(nn.Module):
         state_embedding = self.state_projector(torch.cat((arm_state_feature, gripper_state_feature), dim=1)).view(B, S, -1, H)
 
         # vision: frozen MAE ViT-B/16 over both views as one batch                        (667-673, 705-713)
-        vdt = next(self.vision_encoder.parameters()).dtype
+        vdt = torch.bfloat16
         n = B * S
         with torch.no_grad():
             imgs = torch.cat((image_primary.flatten(0, 1), image_wrist.flatten(0, 1)), dim=0).to(vdt)
             feats, _, _ = self.vision_encoder.forward_encoder(imgs, mask_ratio=0.0)       # (2n, 197, 768)
-        feats = feats.to(next(self.perceiver_resampler.parameters()).dtype)
+        feats = feats.to(torch.bfloat16)
         cls_tok = feats[:, :1, :]
         patches = feats[:, 1:, :]
         # perceiver resampler (shared weights, both views batched)                        (716-717)
@@ -448,7 +482,7 @@ class DreamVLA(nn.Module):
         B, S = parts[0].shape[:2]
         n = B * S
         H = self.hidden_dim
-        wdt = self.text_projector.weight.dtype
+        wdt = torch.bfloat16     # compute dtype: fp32 parameters are masters, the kernels run on bf16 shadows (ops.shadow)
         image_pred = depth_pred = traj_pred = dino_pred = sam_pred = None
         arm_pred_action = gripper_pred_action = None
         arm_pred_state = gripper_pred_state = None

@@ -29,8 +29,9 @@ def _req(t, name, dtype=BF16):
     if not t.is_cuda:
         raise _lib.DvlaError(f"{name}: tensor is on {t.device}; the DreamVLA HIP path has no CPU fallback")
     if dtype is not None and t.dtype != dtype:
-        raise TypeError(f"{name}: expected {dtype}, got {t.dtype} (round-1 kernels compute in bf16: cast the module "
-                        f"with .bfloat16(), i.e. the reference's --precision bf16)")
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype} (the kernels compute in bf16; fp32 parameters / activations "
+                        f"are accepted by the module-level operators -- linear, mlp, layer_norm, attention -- which keep "
+                        f"fp32 masters and run on bf16 shadows)")
     return t
 
 
@@ -594,6 +595,67 @@ def attn_bwd_raw(q, k, v, o, lse, dout, dq, dk, dv, *, scale, mask_tables=None, 
 # ---------------------------------------------------------------------------------------------------
 # autograd Functions
 # ---------------------------------------------------------------------------------------------------
+# fp32 masters, bf16 compute (the shipped scripts: `--precision fp32 --bf16_module vision_encoder`,
+# scripts/CALVIN_ABC_D/DreamVLA/finetune.sh:13,22 -> train.py:122-163: trainable modules stay fp32).  gfx950 has no TF32: an
+# fp32 GEMM runs at 1/16 of the bf16 MFMA rate, so the module-level operators below keep the caller's fp32 parameters as the
+# MASTERS (the optimizer, state_dict and `.grad` are fp32, exactly what train.py builds) and multiply on bf16 SHADOWS:
+#   weights      : _Shadow -- one dvla_cast_f32_to_bf16 per weight and parameter version (frozen weights: once); the gradient
+#                  the backward kernels produce for the shadow is widened back to fp32 for the master
+#   activations  : _ToCompute / results stay bf16 inside the model; fp32 inputs are narrowed once where they enter
+#   biases / LayerNorm affine parameters: read as fp32 by the kernels, gradients written as fp32 (param_dtype codes)
+# ---------------------------------------------------------------------------------------------------
+class _Shadow(torch.autograd.Function):
+    cache = {}       # id(master) -> (weakref(master), version, bf16 shadow)
+
+    @staticmethod
+    def forward(ctx, w):
+        import weakref
+        ent = _Shadow.cache.get(id(w))
+        if ent is not None and ent[0]() is w and ent[1] == w._version:
+            return ent[2]
+        sh = cast_to(w.detach(), BF16)
+        if len(_Shadow.cache) > 4096:
+            _Shadow.cache.clear()
+        _Shadow.cache[id(w)] = (weakref.ref(w), w._version, sh)
+        return sh
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast_to(g.contiguous(), torch.float32) if g.dtype == BF16 else g.float()
+
+
+class _ToCompute(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return cast_to(x, BF16)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast_to(g.contiguous(), torch.float32) if g.dtype == BF16 else g.float()
+
+
+def shadow(w):
+    """bf16 compute copy of a weight (identity for bf16 weights); differentiable: the master receives an fp32 gradient"""
+    if w is None or w.dtype == BF16:
+        return w
+    if w.dtype != torch.float32:
+        raise TypeError(f"weight dtype {w.dtype}: bf16 or fp32 (master) only")
+    if not w.is_cuda:
+        raise _lib.DvlaError(f"weight is on {w.device}; the DreamVLA HIP path has no CPU fallback")
+    return _Shadow.apply(w)
+
+
+def to_compute(x):
+    """activation in the compute dtype (bf16); fp32 activations are narrowed by the HIP cast kernel, differentiably"""
+    if x is None or x.dtype == BF16:
+        return x
+    if x.dtype != torch.float32:
+        raise TypeError(f"activation dtype {x.dtype}: bf16 or fp32 only")
+    if not x.is_cuda:
+        raise _lib.DvlaError(f"tensor is on {x.device}; the DreamVLA HIP path has no CPU fallback")
+    return _ToCompute.apply(x)
+
+
 def _grad_dest(param, dtype=None):
     """The slot a gradient reducer published for this parameter's gradient (dreamvla_amd.ddp.GradBucketReducer with
     direct_grads=True), if nothing has been written there in this step -- the backward kernels then produce the gradient
@@ -667,8 +729,8 @@ class _Linear(torch.autograd.Function):
 def linear(x, w, b=None, *, act="none", conv1d=False, residual=None, dropout_p=0.0, res_rows=0):
     """res_rows > 0: `residual` is a (res_rows, N) table added to output row m at row m % res_rows (e.g. a fixed
     position embedding shared by every image of the batch); it receives no gradient."""
-    return _Linear.apply(x, w, b, residual, ACT[act] if isinstance(act, str) else int(act), bool(conv1d),
-                         float(dropout_p), int(res_rows))
+    return _Linear.apply(to_compute(x), shadow(w), b, to_compute(residual), ACT[act] if isinstance(act, str) else int(act),
+                         bool(conv1d), float(dropout_p), int(res_rows))
 
 
 class _Mlp(torch.autograd.Function):
@@ -731,8 +793,8 @@ class _Mlp(torch.autograd.Function):
 
 
 def mlp(x, w1, b1, w2, b2, *, act, conv1d=False, residual=None, dropout_p=0.0):
-    return _Mlp.apply(x, w1, b1, w2, b2, residual, ACT[act] if isinstance(act, str) else int(act), bool(conv1d),
-                      float(dropout_p))
+    return _Mlp.apply(to_compute(x), shadow(w1), b1, shadow(w2), b2, to_compute(residual),
+                      ACT[act] if isinstance(act, str) else int(act), bool(conv1d), float(dropout_p))
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -767,7 +829,7 @@ class _LayerNorm(torch.autograd.Function):
 
 
 def layer_norm(x, weight, bias, eps):
-    return _LayerNorm.apply(x, weight, bias, float(eps))
+    return _LayerNorm.apply(to_compute(x), weight, bias, float(eps))
 
 
 class _LayerNormFork(torch.autograd.Function):
@@ -814,6 +876,7 @@ class _LayerNormFork(torch.autograd.Function):
 
 def layer_norm_fork(x, weight, bias, eps):
     """-> (x as the residual operand, LayerNorm(x)); see _LayerNormFork.  Without autograd it is layer_norm."""
+    x = to_compute(x)
     if not (torch.is_grad_enabled() and (x.requires_grad or (weight is not None and weight.requires_grad))):
         return x, _LayerNorm.apply(x, weight, bias, float(eps))
     return _LayerNormFork.apply(x, weight, bias, float(eps))
@@ -859,7 +922,7 @@ class _SelfAttention(torch.autograd.Function):
 
 def self_attention(qkv, num_heads, *, scale=None, mask_tables=None, dropout_p=0.0):
     scale = (1.0 / math.sqrt(64.0)) if scale is None else scale
-    return _SelfAttention.apply(qkv, int(num_heads), float(scale), mask_tables, float(dropout_p))
+    return _SelfAttention.apply(to_compute(qkv), int(num_heads), float(scale), mask_tables, float(dropout_p))
 
 
 class _CrossAttention(torch.autograd.Function):
@@ -898,7 +961,7 @@ class _CrossAttention(torch.autograd.Function):
 
 def cross_attention(q, kv, num_heads, *, scale=None):
     scale = (1.0 / math.sqrt(64.0)) if scale is None else scale
-    return _CrossAttention.apply(q, kv, int(num_heads), float(scale))
+    return _CrossAttention.apply(to_compute(q), to_compute(kv), int(num_heads), float(scale))
 
 
 class _AssembleTokens(torch.autograd.Function):
@@ -952,7 +1015,7 @@ def assemble_tokens(parts, pos=None):
     """(B, S, sum t_k, H) = cat(parts, dim=2) + pos"""
     if len(parts) > 16:
         raise ValueError("assemble_tokens: at most 16 parts")
-    return _AssembleTokens.apply(pos, *parts)
+    return _AssembleTokens.apply(to_compute(pos), *[to_compute(t) for t in parts])
 
 
 class _Dropout(torch.autograd.Function):
@@ -971,7 +1034,7 @@ class _Dropout(torch.autograd.Function):
 def dropout(x, p, training):
     if not training or p <= 0.0:
         return x
-    return _Dropout.apply(x, float(p))
+    return _Dropout.apply(to_compute(x), float(p))
 
 
 class _Act(torch.autograd.Function):
@@ -991,4 +1054,4 @@ class _Act(torch.autograd.Function):
 
 
 def activation(x, act):
-    return _Act.apply(x, ACT[act] if isinstance(act, str) else int(act))
+    return _Act.apply(to_compute(x), ACT[act] if isinstance(act, str) else int(act))

@@ -234,6 +234,17 @@ typedef struct dvla_mask_rule {
 int dvla_mask_tables(const dvla_mask_rule* rule, const int32_t* drop, int32_t* key_index, uint32_t* bits_q, uint32_t* bits_k,
                      uint8_t* tile_map, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Camera-frame input pipeline on the device: uint8 HWC frames (already resized to the model's
+ * resolution on the host) -> ToTensor (/255) -> CLIP Normalize (mean3 / std3, fp32, torch's operation order) ->
+ * RandomShiftsAug as the integer-shift gather it is -> bf16 CHW.  Replaces, per frame, clip's `_transform` tail
+ * (ToTensor + Normalize: utils/data_utils.py:175-178 via image_processor), RandomShiftsAug.forward / forward_traj
+ * (utils/data_utils.py:326-383, applied by the collaters at 1337-1353) and the fp32 upload + cast of
+ * utils/train_utils.py:118-123.  src: (n, H, W, 3) uint8; shift: (n, 2) int32 (sx, sy) in [0, 2 pad] or NULL (no
+ * augmentation); out: (n, 3, H, W) bf16, 16-byte aligned; W % 8 == 0. */
+int dvla_image_preprocess(const uint8_t* src, const int32_t* shift, void* out, int64_t n, int32_t height, int32_t width,
+                          int32_t pad, const float* mean3, const float* std3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -244,6 +244,8 @@ def hip_text_sharing_checks():
         res.append({"name": "text tower shared over time == per frame", "rel_l2": r, "tol": 2e-3, "ok": r <= 2e-3})
         tt = inp["text_token"].clone()
         tt[:, 1, 3] = (tt[:, 1, 3] + 1) % 49000          # rows differ -> the shared path must NOT be taken
+        # (1) a model whose FIRST batch has unequal rows decides "per frame" for good
+        m._text_share_mode = None
         m.share_text_over_time = True
         a = m.encode_frames(args[0], args[1], args[2], tt)[0]
         m.share_text_over_time = False
@@ -251,7 +253,20 @@ def hip_text_sharing_checks():
         r = rel_l2(a, b)
         differs = not torch.equal(a[:, 0], a[:, 1])       # frame 1 got its own text embedding, not frame 0's broadcast
         res.append({"name": "unequal token rows fall back to per-frame encoding", "rel_l2": r, "tol": 2e-3,
-                    "ok": r <= 2e-3 and differs})
+                    "ok": r <= 2e-3 and differs and m._text_share_mode == "per_frame"})
+        # (2) a model in "shared" mode (decided on an equal batch) that is later fed unequal rows: no host sync per forward,
+        #     the violation is detected by the asynchronous verdict at the next forward and raises
+        m._text_share_mode = None
+        m.share_text_over_time = True
+        m.encode_frames(*args)                            # decides "shared"
+        m.encode_frames(*args)                            # steady state: launches the asynchronous check only
+        m.encode_frames(args[0], args[1], args[2], tt)    # wrong assumption: goes unnoticed in this call ...
+        raised = False
+        try:
+            m.encode_frames(*args)                        # ... and raises here
+        except RuntimeError as e:
+            raised = "share_text_over_time" in str(e)
+        res.append({"name": "violated text-sharing assumption raises at the next forward", "rel_l2": 0.0, "tol": 0.0, "ok": raised})
     return res
 
 

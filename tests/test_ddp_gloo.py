@@ -69,6 +69,32 @@ def _worker(rank, world, port, q, direct):
         assert not early[0][i] and early[1][i] and early[2][i], (early, i)
     for i in ub:                                    # step 3: the used set grew -> held until finish(); step 4: re-learned
         assert not early[3][i] and early[4][i], (early, i)
+    # gradient accumulation (utils/train_utils.py:588-607): two half-batches under no_sync() + outside == one full pass
+    m.use_extra = False
+    red.zero_grad()
+    with red.no_sync():
+        ((m(xs[:2]) - ys[:2]) ** 2).mean().mul(0.5).backward()
+        assert not any(b["launched"] for b in red.buckets)
+    ((m(xs[2:]) - ys[2:]) ** 2).mean().mul(0.5).backward()
+    red.finish()
+    acc = {n: red.grad_of(p).clone() for n, p in m.named_parameters()}
+    red.zero_grad()
+    ((m(xs) - ys) ** 2).mean().backward()
+    red.finish()
+    for n, p in m.named_parameters():
+        assert torch.allclose(acc[n], red.grad_of(p), atol=1e-6), n
+    # a second backward without no_sync() after the exchange started must raise instead of silently diverging the ranks
+    red.zero_grad()
+    ((m(xs) - ys) ** 2).mean().backward()
+    raised = False
+    try:
+        ((m(xs) - ys) ** 2).mean().backward()
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    assert raised
+    red.finish()
+    # collectives are issued in bucket-index order whatever the readiness order
+    assert red._next_launch == len(red.buckets)
     if rank == 0:
         q.put({it: {k: v.numpy() for k, v in d.items()} for it, d in out.items()})
     dist.barrier()
@@ -104,3 +130,69 @@ def test_bucket_reducer_matches_full_batch_gradients(direct):
             for p in m.parameters():
                 if p.grad is not None:
                     p -= 0.1 * p.grad
+
+
+def test_bf16_sum_over_eight_ranks_error_is_stated():
+    """the buckets are bf16 and RCCL reduces in the buffer dtype: what does an 8-rank bf16 ring sum cost against an fp32
+    sum?  (simulated on CPU: sequential bf16 accumulation in ring order, the worst case of the rounding points).  The
+    relative L2 error stays below 1 % of the bf16 rounding the averaged gradient gets anyway is NOT guaranteed -- the number
+    is recorded here so that DESIGN.md can state it: ~4e-3 rel-L2, i.e. one bf16 ulp, for i.i.d. gradients."""
+    torch.manual_seed(0)
+    g = [torch.randn(1 << 16).mul(1e-3).to(torch.bfloat16) for _ in range(8)]
+    acc = g[0].clone()
+    for t in g[1:]:
+        acc = (acc + t)            # bf16 + bf16 -> bf16: one rounding per hop
+    ring = (acc / 8).float()
+    exact = torch.stack([t.float() for t in g]).sum(0) / 8
+    rel = float((ring - exact).norm() / exact.norm())
+    assert rel < 8e-3, rel
+    one_round = float((exact.to(torch.bfloat16).float() - exact).norm() / exact.norm())
+    assert rel < 4 * one_round + 1e-3, (rel, one_round)
+
+
+def _rccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from dreamvla_amd.ddp import GradBucketReducer
+    torch.manual_seed(0)
+    m = Tiny().cuda()
+    red = GradBucketReducer(m.parameters(), bucket_bytes=1500)
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 16, generator=g).cuda(), torch.randn(8, 8, generator=g).cuda()
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    red.zero_grad()
+    ((m(xs) - ys) ** 2).mean().backward()
+    red.finish()
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put({n: red.grad_of(p).cpu().numpy() for n, p in m.named_parameters()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bucket_reducer_over_rccl_two_ranks():
+    """the same reducer over RCCL (backend "nccl": ReduceOp.AVG inside the collective); needs two GPUs, skips otherwise"""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    m = Tiny()
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    ((m(X) - Y) ** 2).mean().backward()
+    for n, p in m.named_parameters():
+        want = torch.zeros_like(p) if p.grad is None else p.grad
+        assert torch.allclose(torch.from_numpy(got[n]), want, atol=1e-5), n
