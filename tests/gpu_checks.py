@@ -580,4 +580,36 @@ def check_flat_adamw(seed=0):
         got = torch.cat([p.detach().float().cpu().reshape(-1) for p in params])
         ref = torch.cat([q.float().reshape(-1) for q in mine])
         out.append(metrics(f"flat_adamw step{step} params", got, ref, 1e-3 if step > 1 else 1e-6, round_ref=False))
+    # --- checkpoint / resume (the reference saves optimizer_state_dict): state_dict -> step -> restore -> same step again
+    sd = opt.state_dict()
+    snap = [s["p"].clone() for s in opt.flat]
+    gr = [(torch.randn(s, generator=g) * 2.0).to(BF) for s in shapes]
+
+    def one_step():
+        red.zero_grad()
+        for p, t in zip(params, gr):
+            p.grad.copy_(t.to(DEV))
+        opt.step()
+        return torch.cat([p.detach().float().cpu().reshape(-1) for p in params])
+    first = one_step()
+    for s_, keep in zip(opt.flat, snap):
+        s_["p"].copy_(keep)
+    opt.load_state_dict(sd)
+    again = one_step()
+    out.append({"name": "flat_adamw state_dict round trip reproduces the step bit for bit", "rel_l2": rel_l2(again, first), "tol": 0.0,
+                "ok": bool(torch.equal(again, first)) and opt.step_count == sd["step"] + 1})
+    # --- a torch LR scheduler drives it (train.py attaches one to its AdamW)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 0.25)
+    out.append({"name": "flat_adamw accepts a torch LR scheduler", "rel_l2": 0.0, "tol": 0.0,
+                "ok": abs(opt.param_groups[0]["lr"] - 0.25e-2) < 1e-12 and sched is not None})
+    # --- parameters the reducer learned to be unused are left alone (torch AdamW skips p.grad is None): no decay
+    bi = next(i for i, b in enumerate(red.buckets) if len(b["params"]) > 1)
+    red.buckets[bi]["expected"][0] = False
+    victim = red.buckets[bi]["params"][0]
+    before = victim.detach().clone()
+    others_before = params[0].detach().clone() if params[0] is not victim else params[1].detach().clone()
+    one_step()
+    other = params[0] if params[0] is not victim else params[1]
+    out.append({"name": "flat_adamw leaves never-used parameters untouched", "rel_l2": 0.0, "tol": 0.0,
+                "ok": bool(torch.equal(victim.detach(), before)) and not torch.equal(other.detach(), others_before)})
     return out

@@ -100,7 +100,10 @@ def test_fp32_master_forward_matches_bf16_module():
             assert b is None
             continue
         r = C.rel_l2(a, b)
-        assert r <= 4e-3, r
+        assert r <= 1.5e-2, r      # two bf16 runs that round at different points: ~2x the fixture's bf16 deviation (6e-3)
+    for outs_ in outs:             # and each of them sits inside the fixture's per-output tolerance against the fp32 reference
+        for res in C.compare_outputs(outs_, fx["train"], 3e-2, "precision", fx=fx):
+            assert res["ok"], res
 
 
 @pytest.mark.gpu
