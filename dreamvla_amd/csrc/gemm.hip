@@ -208,14 +208,15 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
       case 4: launch_ring<RCfgM64>(a, combo, split_k, stream); break;
       case 5: launch_phase(a, combo, split_k, stream); break;
-      case 81: case 83: case 84: case 85: case 86:   // ablations (plain bf16 epilogue only): 81 no MFMA, 83 no MFMA + no reads, 84 no DMA, 85 no epilogue, 86 raw stores only
+      case 81: case 83: case 84: case 85: case 86: case 89:   // ablations (plain bf16 epilogue only): 81 no MFMA, 83 no MFMA + no reads, 84 no DMA, 85 no epilogue, 86 raw stores only
         a.tiles_m = (int)((a.M + 255) / 256); a.tiles_n = (int)((a.N + 255) / 256);
         if (epi_class(a) != EPI_P0) return DVLA_ERR_UNSUPPORTED;
         if (choice == 81) launch_phase_one<false, false, 0, 1>(a, split_k, stream);
         else if (choice == 83) launch_phase_one<false, false, 0, 3>(a, split_k, stream);
         else if (choice == 84) launch_phase_one<false, false, 0, 4>(a, split_k, stream);
         else if (choice == 85) launch_phase_one<false, false, 0, 16>(a, split_k, stream);
-        else launch_phase_one<false, false, 0, 32>(a, split_k, stream);
+        else if (choice == 86) launch_phase_one<false, false, 0, 32>(a, split_k, stream);
+        else launch_phase_one<false, false, 0, 64>(a, split_k, stream);   // 89: s_memtime stamps into p.workspace
         break;
       default: launch_cfg<CfgS>(a, combo, split_k, stream); break;
     }

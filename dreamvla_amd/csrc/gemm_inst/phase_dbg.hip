@@ -6,4 +6,5 @@ template void launch_phase_one<false, false, 0, 3>(const GemmKArgs&, int, hipStr
 template void launch_phase_one<false, false, 0, 4>(const GemmKArgs&, int, hipStream_t);
 template void launch_phase_one<false, false, 0, 16>(const GemmKArgs&, int, hipStream_t);
 template void launch_phase_one<false, false, 0, 32>(const GemmKArgs&, int, hipStream_t);
+template void launch_phase_one<false, false, 0, 64>(const GemmKArgs&, int, hipStream_t);
 }

@@ -5,25 +5,27 @@
 // Why another structure (profiles/r02_gemm_probe_*.txt): every ring configuration ends up at the same 520-860 TFLOP/s on
 // the model's shapes -- one barrier per 32-wide stage with all eight waves reading fragments, then all eight multiplying,
 // leaves the matrix pipe idle while LDS is read and LDS idle while the pipe runs; 64-byte LDS rows fetch half cache lines;
-// and a K-tile of 64 does not fit a 3-deep stage ring at 256 x 256 (3 x 64 KiB).  This kernel keeps TWO 64-KiB K-tile
-// buffers and gets its look-ahead from refilling each operand image as soon as ITS last fragment read has retired:
+// and a K-tile of 64 does not fit a 3-deep stage ring at 256 x 256 (3 x 64 KiB).  This kernel keeps 32-KiB operand IMAGES
+// (three of A, two of B) and gets its look-ahead from refilling each image as soon as ITS last fragment read has retired:
 //
 //   waves 0-3 (group 0: rows 0-127 of the tile) and waves 4-7 (group 1: rows 128-255) sit pairwise on the four SIMDs and
 //   run the same segment sequence one barrier apart, so that a SIMD always has one wave multiplying and one loading:
 //
 //     per K-tile u (buffer u & 1):    LOAD1 | MFMA1 | LOAD2 | MFMA2        (| = s_barrier; group 1 is one segment behind)
 //       LOAD1: fragments a-lo (rows 0-63 of the wave's 128) x 4 k-steps and all B fragments (64 columns x 4 k-steps)
-//       MFMA1: 16 x v_mfma_f32_32x32x16_bf16 (a-lo x B); between them this wave's 4 DMA pieces of the A image of tile u+1
-//              (buffer (u+1)&1: last read in LOAD2(u-1))
+//       MFMA1: 16 x v_mfma_f32_32x32x16_bf16 (a-lo x B)
 //       LOAD2: fragments a-hi into the a-lo registers
-//       MFMA2: 16 MFMAs (a-hi x B, B fragments still in registers); between them 4 DMA pieces of the B image of tile u+2
-//              (buffer u&1: its B fragments were all read in LOAD1(u), by both groups, two / three segments ago)
+//       MFMA2: 16 MFMAs (a-hi x B, B fragments still in registers)
+//     and, spread over the four segments so that none of them paces the slot, this wave's 4 DMA pieces of the A image of
+//     tile u+1 (buffer (u+1)&1: last read in LOAD2(u-1)) and 4 of the B image of tile u+2 (buffer u&1: its B fragments were
+//     all read in LOAD1(u), by both groups -- hence from LOAD2 on): LOAD1: A0 | MFMA1: A1 A2 | LOAD2: A3 B0 B1 | MFMA2: B2 B3
 //     every ds_read of a segment is waited for (lgkmcnt(0)) BEFORE the barrier that ends the segment -- the wait is hidden
 //     under the partner's MFMA segment -- so "read in segment s" means "retired by the end of s", which is what the refill
-//     rule above needs.  RAW: at the end of MFMA2(u) every wave waits vmcnt(4): all of its pieces except the 4 B(u+2) pieces
-//     it issued last have landed, i.e. A(u+1) and B(u+1); group 1 (whose MFMA2(u) ends one slot after group 0 starts reading
-//     tile u+1) additionally waits for its B(u+1) pieces at the end of its LOAD2(u).  The barriers publish; A runs one tile
-//     ahead, B two.
+//     rule above needs.  RAW: at the end of MFMA2(u) every wave waits vmcnt(8): all of its pieces except the eight it issued
+//     during tile u (A(u+2), B(u+2)) have landed, i.e. A(u+1) and B(u+1); group 1 (whose MFMA2(u) ends one slot after group 0
+//     starts reading tile u+1) waits for the same pieces at the end of its LOAD2(u) (vmcnt(5): A0..A3, B0 of tile u are
+//     younger).  The barriers publish.  Both operands run two tiles ahead: three A images (tile u in slot u % 3) and two B
+//     images (whose fragments are all read in LOAD1 and which are therefore free again from LOAD2 on): 160 KiB of LDS.
 //   The DMA stream never stops at an output-tile boundary (two cursors walk the work-item list ahead of the multiply); at a
 //   boundary the groups re-align with one extra barrier, run the register-only epilogue at the same time and re-stagger.
 //
@@ -36,8 +38,10 @@ namespace dvla_gemm {
 
 struct PCfg {
   static constexpr int BM = 256, BN = 256, BKS = 64, GH = 4, NT = 512, TM = 4, TN = 2;
-  static constexpr int A_BYTES = BM * BKS * 2, B_BYTES = BN * BKS * 2, BUF_BYTES = A_BYTES + B_BYTES;
-  static constexpr int SMEM_BYTES = 2 * BUF_BYTES;   // 128 KiB
+  static constexpr int A_BYTES = BM * BKS * 2, B_BYTES = BN * BKS * 2;
+  static constexpr int NA = 3, NB = 2;               // A images: tile u in slot u % 3 (two tiles of look-ahead); B images: u % 2
+  static constexpr int B_BASE = NA * A_BYTES;
+  static constexpr int SMEM_BYTES = NA * A_BYTES + NB * B_BYTES;   // 160 KiB: the whole LDS of a CU
   static constexpr int WG_PER_CU = 1;
   static constexpr int CPW = 4;                      // DMA pieces (1 KiB each) per wave and operand image
 };
@@ -67,7 +71,7 @@ void gemm_phase_kernel(GemmKArgs p) {
   // 4*wave .. 4*wave+3 of every 32-piece operand image.  nA / nB = number of tiles issued so far (buffer = n & 1). ----
   const bf16_t* srcA[CPW];
   const bf16_t* srcB[CPW];
-  int itA = 0, ktA = 0, nkA = 0, nA = 0; bool liveA = false;
+  int itA = 0, ktA = 0, nkA = 0, nA = 0; bool liveA = false;   // nA = slot (mod 3) of the next A image to issue
   int itB = 0, ktB = 0, nkB = 0, nB = 0; bool liveB = false;
   const int64_t stepA = A_T ? (int64_t)BKS * p.lda : (int64_t)BKS;
   const int64_t stepB = B_T ? (int64_t)BKS * p.ldb : (int64_t)BKS;
@@ -94,13 +98,13 @@ void gemm_phase_kernel(GemmKArgs p) {
   // 100-185 cycles inside a fragment-read segment but hides in the shadow of a 32-cycle MFMA (the first version issued
   // them in the LOAD segments: those then took ~900 cycles against the partner's 512-cycle MFMA segment and paced the loop).
   auto pieceA = [&](int i) {
-    const uint32_t dst = smem_base + (uint32_t)((nA & 1) * PCfg::BUF_BYTES + wave * (CPW * 1024) + i * 1024);
+    const uint32_t dst = smem_base + (uint32_t)(nA * PCfg::A_BYTES + wave * (CPW * 1024) + i * 1024);
     glds16(srcA[i], __builtin_amdgcn_readfirstlane(dst));
     srcA[i] += stepA;
   };
-  auto doneA = [&]() { ++nA; if (++ktA == nkA) openA(++itA); };
+  auto doneA = [&]() { nA = nA == PCfg::NA - 1 ? 0 : nA + 1; if (++ktA == nkA) openA(++itA); };
   auto pieceB = [&](int i) {
-    const uint32_t dst = smem_base + (uint32_t)((nB & 1) * PCfg::BUF_BYTES + PCfg::A_BYTES + wave * (CPW * 1024) + i * 1024);
+    const uint32_t dst = smem_base + (uint32_t)(PCfg::B_BASE + (nB & 1) * PCfg::B_BYTES + wave * (CPW * 1024) + i * 1024);
     glds16(srcB[i], __builtin_amdgcn_readfirstlane(dst));
     srcB[i] += stepB;
   };
@@ -120,15 +124,27 @@ void gemm_phase_kernel(GemmKArgs p) {
     return true;
   };
 
-  // ---- prologue: A(0), B(0), B(1); everything but B(1) must have landed before the first fragment read ----
+  // ---- prologue: A(0), B(0), A(1), B(1) in this order; the first two must have landed before the first fragment read ----
   openA(0); openB(0);
   issueA();
   issueB();
+  const bool a1 = issueA();
   const bool b1 = issueB();
-  if (b1) wait_vmcnt<CPW>(); else wait_vmcnt<0>();
+  if (a1 && b1) wait_vmcnt<2 * CPW>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  int u = 0;   // global K-tile counter of the multiply
+  // DBG & 64: waves 0 and 4 of workgroup 0 record s_memtime at the eight segment edges of their first 32 K-tiles into
+  // p.workspace (as uint64[2][32][8]) -- the timeline the schedule is tuned against (tests/probes/gemm_probe.cpp --stamps)
+  uint64_t* stamps = nullptr;
+  if constexpr ((DBG & 64) != 0) {
+    if (blockIdx.x == 0 && (wave == 0 || wave == 4) && p.workspace) stamps = reinterpret_cast<uint64_t*>(p.workspace) + (wave >> 2) * 256;
+  }
+  auto stamp = [&](int kt_global, int e) {
+    if constexpr ((DBG & 64) != 0) {
+      if (stamps && kt_global < 32 && lane == 0) stamps[kt_global * 8 + e] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  int u = 0, ua = 0;   // global K-tile counter of the multiply, and u % 3
   for (int it = 0;; ++it) {
     const int id = item_of(it);
     if (id < 0) break;
@@ -145,9 +161,9 @@ void gemm_phase_kernel(GemmKArgs p) {
     if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one segment behind group 0
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int kt = 0; kt < w.ns; ++kt, ++u) {
-      const char* bufA = smem + (u & 1) * PCfg::BUF_BYTES;
-      const char* bufB = bufA + PCfg::A_BYTES;
+    for (int kt = 0; kt < w.ns; ++kt, ++u, ua = (ua == PCfg::NA - 1 ? 0 : ua + 1)) {
+      const char* bufA = smem + ua * PCfg::A_BYTES;                         // ua = u % 3
+      const char* bufB = smem + PCfg::B_BASE + (u & 1) * PCfg::B_BYTES;
       bf16x8 fa[2][4], fb[2][4];   // [sub-tile][k16-step]
       if (DBG & 2) {
 #pragma unroll
@@ -156,7 +172,17 @@ void gemm_phase_kernel(GemmKArgs p) {
           for (int y = 0; y < 4; ++y) { fa[x][y] = bf16x8{1, 2, 3, 4, 5, 6, 7, (short)lane}; fb[x][y] = bf16x8{1, 2, 3, 4, 5, 6, 7, (short)kt}; }
       }
 
+      // DMA piece placement (measured with the s_memtime stamps of variant 89, profiles/r02_gemm_phase_timeline.txt): one
+      // LDS-DMA issue costs the issuing wave ~95 cycles between MFMAs and ~210 behind the ds_reads of a fragment-read
+      // segment, and it is NOT hidden by the matrix pipe (the 8 pieces of a K-tile are 750-1700 cycles per wave against 1024
+      // of MFMA work: the reason the loop sits at ~55 % matrix-pipe busy).  Spread as
+      //     LOAD1: A0 | MFMA1: A1 A2 | LOAD2: A3 B0 | MFMA2: B1 B2 B3
+      // the four segments are ~650-800 cycles each.  Both operands run TWO tiles ahead (A(u+2) and B(u+2) are issued during
+      // tile u; three A images make that possible), so the counted waits below name pieces issued a whole tile earlier and do
+      // not stall (with A one tile ahead they cost ~300 cycles per K-tile and group).
       // ---------------- LOAD1 ----------------
+      stamp(u, 0);
+      const bool ia = liveA;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -165,11 +191,14 @@ void gemm_phase_kernel(GemmKArgs p) {
         for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + j * 32, ks, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (ia && !(DBG & 4)) pieceA(0);
+      __builtin_amdgcn_sched_barrier(0);
       wait_lds();
       __builtin_amdgcn_sched_barrier(0);
+      stamp(u, 1);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
-      // ---------------- MFMA1 (+ the 4 pieces of A(u+1), one behind every 4th MFMA) ----------------
-      const bool ia = liveA;
+      stamp(u, 2);
+      // ---------------- MFMA1 (+ pieces A1, A2 of A(u+1)) ----------------
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -179,29 +208,36 @@ void gemm_phase_kernel(GemmKArgs p) {
           for (int j = 0; j < 2; ++j)
             if (!(DBG & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][ks], fa[j][ks], acc[i][j], 0, 0, 0);
             else asm volatile("" :: "v"(fb[i][ks]), "v"(fa[j][ks]));
-        __builtin_amdgcn_sched_barrier(0);
-        if (ia && !(DBG & 4)) pieceA(ks);
-        __builtin_amdgcn_sched_barrier(0);
+        if (ks & 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (ia && !(DBG & 4)) pieceA(1 + (ks >> 1));
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       __builtin_amdgcn_s_setprio(0);
-      if (ia) doneA();
       __builtin_amdgcn_sched_barrier(0);
+      stamp(u, 3);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
-      // ---------------- LOAD2 ----------------
+      stamp(u, 4);
+      // ---------------- LOAD2 (+ pieces A3, B0, B1) ----------------
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + 64 + j * 32, ks, lane);
       __builtin_amdgcn_sched_barrier(0);
-      // group 1 sits one segment behind: its B(u+1) pieces (issued in ITS MFMA2(u-1), one slot after group 0's) must have
-      // landed before group 0 reads tile u+1 in the next slot; its 4 youngest pieces are A(u+1) (only group 1 itself reads
-      // those when A is k-contiguous: rows 128-255; an r-contiguous A image is shared, so then everything is waited for)
-      if (grp == 1) { if (ia && !A_T) wait_vmcnt<CPW>(); else wait_vmcnt<0>(); }
+      if (ia) { if (!(DBG & 4)) pieceA(3); doneA(); }
+      const bool ib = liveB;
+      if (ib && !(DBG & 4)) pieceB(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // group 1 sits one segment behind group 0, which reads tile u+1 in the next slot: group 1's pieces of A(u+1) / B(u+1)
+      // (issued during ITS tile u-1) must have landed by now.  Younger than those: this tile's A0..A3 and B0.
+      if (grp == 1) { if (ia && ib) wait_vmcnt<5>(); else wait_vmcnt<0>(); }
       wait_lds();
       __builtin_amdgcn_sched_barrier(0);
+      stamp(u, 5);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
-      // ---------------- MFMA2 (+ the 4 pieces of B(u+2)) ----------------
-      const bool ib = liveB;
+      stamp(u, 6);
+      // ---------------- MFMA2 (+ pieces B2, B3 of B(u+2)) ----------------
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -211,15 +247,18 @@ void gemm_phase_kernel(GemmKArgs p) {
           for (int j = 0; j < 2; ++j)
             if (!(DBG & 1)) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][ks], fa[j][ks], acc[i][2 + j], 0, 0, 0);
             else asm volatile("" :: "v"(fb[i][ks]), "v"(fa[j][ks]));
-        __builtin_amdgcn_sched_barrier(0);
-        if (ib && !(DBG & 4)) pieceB(ks);
-        __builtin_amdgcn_sched_barrier(0);
+        if (ks >= 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (ib && !(DBG & 4)) pieceB(ks);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       __builtin_amdgcn_s_setprio(0);
       if (ib) doneB();
       __builtin_amdgcn_sched_barrier(0);
-      // everything but the B(u+2) pieces just issued has landed: A(u+1) (and, for group 0, B(u+1))
-      if (ib) wait_vmcnt<CPW>(); else wait_vmcnt<0>();
+      // everything but this tile's eight pieces (A(u+2), B(u+2)) has landed: A(u+1), B(u+1)
+      if (ia && ib) wait_vmcnt<2 * CPW>(); else wait_vmcnt<0>();
+      stamp(u, 7);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align: both groups run the epilogue together

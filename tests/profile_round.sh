@@ -1,0 +1,33 @@
+#!/bin/bash
+# The round's committed rocprofv3 evidence, produced on the GPU box:   bash tests/profile_round.sh <tag>
+# Writes gpurun_out/<tag>_*: kernel-trace step summary + stats of the bench command, PMC passes (separate runs, --kernel-trace
+# only, as gpurun requires): GEMM FETCH_SIZE / WRITE_SIZE over one un-tuned training step, attention MFMA-busy, LayerNorm
+# FETCH / WRITE on a working set larger than the Infinity Cache.  Copy what is to be judged into profiles/.
+set -u
+TAG=${1:-r02}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-eager-baseline"
+# 1. kernel trace + stats of the bench command (3 timed steps)
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_step -f csv -- $BENCH --steps 3 --warmup 1 --no-roofline > $OUT/${TAG}_bench_under_rocprof.log 2>&1
+python $REPO/tests/prof_summary.py $OUT/${TAG}_prof_step $OUT/${TAG}_step_summary.txt > /dev/null 2>&1
+cp $(find $OUT/${TAG}_prof_step -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null
+# 2. GEMM traffic: one step with the cost-model configuration (no tuner trials), FETCH and WRITE in separate passes
+for C in FETCH_SIZE WRITE_SIZE; do
+  DVLA_GEMM_AUTOTUNE=0 rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$C -f csv -- $BENCH --steps 1 --warmup 0 --tune-steps 0 --no-roofline > $OUT/${TAG}_pmc_$C.log 2>&1
+  python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_$C $OUT/${TAG}_pmc_$C.json > $OUT/${TAG}_pmc_$C.txt 2>&1
+done
+# 3. attention: matrix-pipe busy per kernel
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_attn -f csv -- python $REPO/tests/gpu_pmc_attn.py > $OUT/${TAG}_pmc_attn.log 2>&1
+python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_attn $OUT/${TAG}_pmc_attn.json > $OUT/${TAG}_pmc_attn.txt 2>&1
+# 4. LayerNorm: HBM bytes on > 256 MiB working sets
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_ln_$C -f csv -- python $REPO/tests/gpu_pmc_ln.py > $OUT/${TAG}_pmc_ln_$C.log 2>&1
+  python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_ln_$C $OUT/${TAG}_pmc_ln_$C.json > $OUT/${TAG}_pmc_ln_$C.txt 2>&1
+done
+# keep the merge small: drop the raw traces
+rm -rf $OUT/${TAG}_prof_step $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_attn $OUT/${TAG}_pmc_ln_FETCH_SIZE $OUT/${TAG}_pmc_ln_WRITE_SIZE
+ls -la $OUT | head -40
