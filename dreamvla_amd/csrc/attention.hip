@@ -299,7 +299,7 @@ __host__ __device__ inline size_t fa_smem_bytes(int nkt, int Lk, bool has_index,
   return (size_t)FA_RING + fa_pad16(nkt) + (has_index ? (size_t)fa_pad16(Lk * 4) : 0) + (has_bits ? (size_t)128 * nkt * 4 : 0);
 }
 
-__global__ __launch_bounds__(AT_THREADS) void attn_fwd_ring_kernel(AttnKArgs p) {
+__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_ring_kernel(AttnKArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -788,7 +788,7 @@ __device__ __forceinline__ bf16x8 fa_frag_tr(const char* tile, int db, int mm, i
   return u.v;
 }
 
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_ring_kernel(AttnKArgs p) {
+__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dq_ring_kernel(AttnKArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
