@@ -83,14 +83,25 @@ def next_seed():
 # ---------------------------------------------------------------------------------------------------
 # raw kernel launchers (no autograd)
 # ---------------------------------------------------------------------------------------------------
-def auto_split_k(M, N, K):
-    """weight-gradient GEMMs: small output, very long contraction.  Aim at >= ~1000 workgroups (256 CUs x 2 resident
-    x 2 waves of blocks) while keeping >= 2048 of K per slice."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 768 or K < 4096:
+def auto_split_k(M, N, K, cus=256):
+    """weight-gradient GEMMs: small output (M x N), very long contraction (K = tokens).  The kernels that run them tile the
+    output in 256 x 256 (persistent, one workgroup per CU), so the number of work items tiles * split_k should land just
+    under a multiple of the CU count: 1024 x 3072 is 48 tiles -> 5 slices = 240 items = one 94 %-full round (round 1 took
+    6 = 288 items = two rounds, the second 12 % full: 632 TFLOP/s where its 4-slice siblings reach 960-1000).  Cheapest
+    by (1 + 1 % per slice) / round efficiency, slices of at least ~1.3 k of K, at most 16."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles >= (3 * cus) // 4 or K < 4096:
         return 1
-    s = min(16, -(-1024 // tiles), K // 2048)
-    return max(1, s)
+    best_s, best_cost = 1, float("inf")
+    for sk in range(1, 17):
+        if K // sk < 1280:
+            break
+        items = tiles * sk
+        eff = items / float(cus * -(-items // cus))
+        cost = (1.0 + 0.01 * sk) / eff          # every slice adds M x N x 4 B of partial sums to write and reduce
+        if cost < best_cost:
+            best_s, best_cost = sk, cost
+    return best_s
 
 
 class GemmProfiler:

@@ -215,7 +215,7 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> h(512);
     CK(hipMemcpy(h.data(), q.ws.p, 512 * 8, hipMemcpyDeviceToHost));
     const unsigned long long t0 = h[0];
-    printf("# s_memtime ticks (100 MHz constant clock on gfx9: 1 tick = 10 ns) relative to wave 0's first stamp; edges: 0 LOAD1 start, 1 reads retired, "
+    printf("# s_memtime ticks (shader cycles, MI355X_MICROARCH.md) relative to wave 0's first stamp; edges: 0 LOAD1 start, 1 reads retired, "
            "2 after barrier (MFMA1 start), 3 MFMA1 done, 4 after barrier (LOAD2 start), 5 reads retired, 6 after barrier (MFMA2 start), 7 MFMA2 done + vmcnt\n");
     for (int g = 0; g < 2; ++g)
       for (int kt = 0; kt < 32; ++kt) {
