@@ -16,7 +16,8 @@
 //   (statement for statement what the loop at dreamvla_model.py:31-65 leaves behind; pinned bit for bit against
 //   build_mask_tables(generate_attention_mask(...)) for the eight flag combinations of tests/test_mask.py).
 //   Key compaction: a column is kept iff anybody can see it: co < num_A, or an obs column (when act rows exist) that is not
-//   dropped for its step (the goal column has co == 1 < num_A).
+//   dropped for its step (the goal column has co == 1 < num_A).  Kept keys are listed leading columns first, obs columns
+//   last (key_col below): the gather list may permute keys freely, and this order makes most 32 x 32 tiles uniform.
 //
 // One C-ABI call, three tiny launches: key_index, the two bit tables, the tile map.
 #include "common.h"
@@ -38,12 +39,19 @@ __device__ __forceinline__ bool dropped(const MaskRule& m, int step, int obs) {
     if (m.drop[step * m.n_drop + t] == obs) return true;
   return false;
 }
-// compacted key k -> original column
+// compacted key k -> original column.  Order: the num_A leading columns of every window step first (step by step), then the
+// undropped obs columns (step by step): columns with the same audience share 32-key tiles (see ops.build_mask_tables).
 __device__ __forceinline__ int key_col(const MaskRule& m, int k) {
   const int blk = m.num_A + m.num_B;
-  const int j = k / m.per_step, ko = k - j * m.per_step;
-  if (ko < m.num_A) return j * blk + ko;
-  int want = ko - m.num_A;    // the want-th obs column of step j that is not dropped
+  const int n_lead = m.K * m.num_A;
+  if (k < n_lead) {
+    const int j = k / m.num_A;
+    return j * blk + (k - j * m.num_A);
+  }
+  const int per_obs = m.per_step - m.num_A;   // > 0 here
+  const int ko = k - n_lead;
+  const int j = ko / per_obs;
+  int want = ko - j * per_obs;                // the want-th obs column of step j that is not dropped
   for (int o = 0; o < m.num_obs; ++o) {
     if (dropped(m, j, o)) continue;
     if (want == 0) return j * blk + m.num_A + o;

@@ -413,9 +413,10 @@ class MaskTables:
         self.visible_fraction = visible_fraction
 
 
-def build_mask_tables(mask, device=None, compact_keys=True):
+def build_mask_tables(mask, device=None, compact_keys=True, key_order=None):
     """mask: (Lq, Lk) additive mask whose entries are 0 or -inf (generate_attention_mask,
-    models/dreamvla_model.py:25-66; CLIP causal mask).  Host-side, once per mask."""
+    models/dreamvla_model.py:25-66; CLIP causal mask).  Host-side, once per mask.  `key_order` (optional int array) lists
+    the kept key columns in the order the tables should use (must name exactly the columns somebody can see)."""
     import numpy as np
     device = mask.device if device is None else device
     m = mask.detach().float().cpu()
@@ -427,10 +428,23 @@ def build_mask_tables(mask, device=None, compact_keys=True):
     Lq, Lk_full = vis.shape
     key_index = None
     if compact_keys:
-        cols = np.nonzero(vis.any(axis=0))[0]
+        # Keys nobody sees are dropped, and the kept ones are ORDERED by how many queries see them (stable, descending): the
+        # gather list is free to permute the keys (softmax and P.V are sums over keys), and columns with the same audience
+        # end up in the same 32-key tiles.  For the trunk mask that puts the text / state / image columns of all window steps
+        # first (a block-causal prefix: tiles entirely visible or entirely hidden) and the obs columns -- visible to the three
+        # action rows of their own step only -- last: 129 instead of 186 non-empty 32 x 32 tiles of 420 at L = 651, 45
+        # instead of 162 of them mixed (the order csrc/masks.hip builds from the rule).
+        count = vis.sum(axis=0)
+        cols = np.nonzero(count > 0)[0]
         if len(cols) == 0:
             raise ValueError("mask hides every key")
-        if len(cols) < Lk_full:
+        cols = cols[np.argsort(-count[cols], kind="stable")]
+        if key_order is not None:
+            given = np.asarray(key_order, dtype=np.int64).reshape(-1)
+            if len(given) != len(cols) or not np.array_equal(np.sort(given), np.sort(cols)):
+                raise ValueError("key_order must be a permutation of the visible key columns")
+            cols = given
+        if len(cols) < Lk_full or bool((cols != np.arange(Lk_full)).any()):
             key_index = torch.from_numpy(cols.astype(np.int32)).to(device)
             vis = vis[:, cols]
     Lk = vis.shape[1]

@@ -194,6 +194,7 @@ static void check_variant(const Case& c, int variant, int64_t Mchk) {
 int main(int argc, char** argv) {
   std::vector<int> variants = {0, 2, 4, 5, 6};
   int iters = 7, rounds = 3; bool check_only = false, no_check = false, stamps = false; int64_t stamps_k = 1024; std::string which = "model";
+  std::vector<int> stamp_variants = {89};
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--variants") && i + 1 < argc) variants = parse_list(argv[++i]);
     else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
@@ -201,28 +202,30 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--check-only")) check_only = true;
     else if (!strcmp(argv[i], "--no-check")) no_check = true;
     else if (!strcmp(argv[i], "--stamps")) { stamps = true; if (i + 1 < argc && argv[i + 1][0] != '-') stamps_k = atoll(argv[++i]); }
+    else if (!strcmp(argv[i], "--stamp-variants") && i + 1 < argc) stamp_variants = parse_list(argv[++i]);
     else if (!strcmp(argv[i], "--cases") && i + 1 < argc) which = argv[++i];
   }
-  if (stamps) {   // timeline of the phase kernel (variant 89): s_memtime at the 8 segment edges of the first 32 K-tiles, waves 0 and 4
+  if (stamps) {   // timeline of the phase kernel (variants 89 / 97 / 98): s_memtime at the 8 segment edges of the first 32 K-tiles, waves 0 and 4
     Case c{"stamps", 20832, 4096, stamps_k, 0, 0, "plain", 1};
     Problem q = make_problem(c, c.M);
     q.ws = dalloc(2 * 256 * 8); q.p.workspace = q.ws.p;
-    CK(hipMemset(q.ws.p, 0, q.ws.bytes));
-    dvla_set_gemm_variant(89);
-    for (int it = 0; it < 3; ++it) (void)dvla_gemm_bf16(&q.p, nullptr);
-    dvla_set_gemm_variant(0);
-    CK(hipDeviceSynchronize());
-    std::vector<unsigned long long> h(512);
-    CK(hipMemcpy(h.data(), q.ws.p, 512 * 8, hipMemcpyDeviceToHost));
-    const unsigned long long t0 = h[0];
-    printf("# s_memtime ticks (shader cycles, MI355X_MICROARCH.md) relative to wave 0's first stamp; edges: 0 LOAD1 start, 1 reads retired, "
-           "2 after barrier (MFMA1 start), 3 MFMA1 done, 4 after barrier (LOAD2 start), 5 reads retired, 6 after barrier (MFMA2 start), 7 MFMA2 done + vmcnt\n");
-    for (int g = 0; g < 2; ++g)
-      for (int kt = 0; kt < 32; ++kt) {
-        printf("{\"group\": %d, \"ktile\": %d, \"edges\": [", g, kt);
-        for (int e = 0; e < 8; ++e) printf("%lld%s", (long long)(h[g * 256 + kt * 8 + e] - t0), e < 7 ? ", " : "");
-        printf("]}\n");
-      }
+    printf("# s_memtime ticks (shader cycles, MI355X_MICROARCH.md); segments of K-tiles 3..6: LOAD1 | wait+barrier | MFMA1 | barrier | LOAD2 | wait+barrier | MFMA2(+vmcnt) ; period\n");
+    for (int v : stamp_variants) {
+      CK(hipMemset(q.ws.p, 0, q.ws.bytes));
+      dvla_set_gemm_variant(v);
+      for (int it = 0; it < 3; ++it) (void)dvla_gemm_bf16(&q.p, nullptr);
+      dvla_set_gemm_variant(0);
+      CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> h(512);
+      CK(hipMemcpy(h.data(), q.ws.p, 512 * 8, hipMemcpyDeviceToHost));
+      for (int g = 0; g < 2; ++g)
+        for (int kt = 3; kt < 7; ++kt) {
+          const unsigned long long* e = &h[g * 256 + kt * 8];
+          printf("variant %d group %d K-tile %d: LOAD1 %4lld | wait+barrier %4lld | MFMA1 %4lld | barrier %4lld | LOAD2 %4lld | wait+barrier %4lld | MFMA2 %4lld   period %lld\n",
+                 v, g, kt, (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[4] - e[3]),
+                 (long long)(e[5] - e[4]), (long long)(e[6] - e[5]), (long long)(e[7] - e[6]), (long long)(e[8] - e[0]));
+        }
+    }
     q.release();
     return 0;
   }

@@ -87,22 +87,45 @@ def test_mask_rule_mirror_bit_exact(kw):
     assert vis.shape == tuple(m.shape) and np.array_equal(vis, (m == 0).numpy())
 
 
+def test_key_order_groups_columns_by_audience():
+    """the gather list orders kept keys by audience size: for the trunk mask the leading columns of all steps come first
+    (block-causal prefix), the obs columns last -- far fewer non-empty and far fewer mixed 32 x 32 tiles"""
+    from dreamvla_amd.ops import build_mask_tables
+    m = generate_attention_mask(7, 36, 57, 0, False, False, False, 0.0, 54, 3)
+    mt = build_mask_tables(m, device="cpu")
+    ki = mt.key_index.numpy()
+    assert np.array_equal(ki[:7 * 36], (np.arange(7)[:, None] * 93 + np.arange(36)[None, :]).reshape(-1))
+    assert np.array_equal(ki[7 * 36:], (np.arange(7)[:, None] * 93 + 36 + np.arange(54)[None, :]).reshape(-1))
+    tm = mt.tile_map.numpy()
+    asc = build_mask_tables(m, device="cpu", key_order=np.sort(ki)).tile_map.numpy()
+    assert (tm != 0).sum() <= 130 and (asc != 0).sum() >= 180 and (tm == 2).sum() <= 45 and (asc == 2).sum() >= 160
+    with pytest.raises(ValueError):
+        build_mask_tables(m, device="cpu", key_order=ki[:-1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", COMBOS)
 def test_mask_tables_on_device_bit_identical(kw):
     """dvla_mask_tables (device, from the rule) == build_mask_tables(generate_attention_mask(...)) (host, from the (L, L)
-    tensor): key_index, both bit tables and the tile map, bit for bit."""
+    tensor): the device's key list names exactly the visible columns (leading columns first, obs columns last -- for the
+    default trunk flags that IS the host's own order), and both bit tables and the tile map agree bit for bit for that order."""
     from dreamvla_amd import ops
     np.random.seed(123)
-    want = ops.build_mask_tables(generate_attention_mask(**kw), device="cpu")
+    mask = generate_attention_mask(**kw)
+    own = ops.build_mask_tables(mask, device="cpu")
     np.random.seed(123)
     drop = ops.draw_mask_drop(kw["K"], kw["num_obs_token"], kw["action_pred_steps"], kw["atten_only_obs"], kw["mask_l_obs_ratio"])
     got = ops.build_mask_tables_device("cuda", drop=drop, **_rule_kw(kw))
     torch.cuda.synchronize()
-    assert (got.Lq, got.Lk_full, got.Lk) == (want.Lq, want.Lk_full, want.Lk)
-    wk = torch.arange(want.Lk_full, dtype=torch.int32) if want.key_index is None else want.key_index
     gk = torch.arange(got.Lk_full, dtype=torch.int32) if got.key_index is None else got.key_index.cpu()
-    assert torch.equal(gk, wk)
+    want = ops.build_mask_tables(mask, device="cpu", key_order=gk.numpy())     # raises unless gk names the visible columns
+    assert (got.Lq, got.Lk_full, got.Lk) == (want.Lq, want.Lk_full, want.Lk)
+    blk = kw["num_A"] + kw["num_B"]
+    lead = gk[:kw["K"] * kw["num_A"]].numpy()
+    assert np.array_equal(lead, (np.arange(kw["K"])[:, None] * blk + np.arange(kw["num_A"])[None, :]).reshape(-1))
+    if not kw["atten_only_obs"] and not kw["atten_goal"]:
+        ok = torch.arange(own.Lk_full, dtype=torch.int32) if own.key_index is None else own.key_index
+        assert torch.equal(gk, ok)
     assert torch.equal(got.bits_q.cpu(), want.bits_q) and torch.equal(got.bits_k.cpu(), want.bits_k)
     assert torch.equal(got.tile_map.cpu(), want.tile_map)
 
