@@ -265,10 +265,14 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
 // ====================================================================================================
 constexpr int FA_NS = 4, FA_TILE = 4096, FA_STAGE = 2 * FA_TILE, FA_RING = FA_NS * FA_STAGE;
 
-__device__ __forceinline__ void fa_glds16(const void* gsrc, uint32_t lds_dst) {
+// one LDS-DMA request: 16 B per lane from sbase (wave-uniform: SGPR pair) + voff (per-lane BYTE offset, 32 bit) to LDS
+// lds_dst + 16 lane.  The scalar-base form keeps the per-lane address state at one VGPR per operand (64-bit per-lane pointers
+// cost the dQ kernel 4 spilled VGPRs at 128 -- and a scratch reload inside the loop is a VMEM load: s_waitcnt vmcnt(0),
+// i.e. the ring drained every tile).  The host takes the staged kernels when an operand spans 4 GiB or more.
+__device__ __forceinline__ void fa_glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
   uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void fa_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -294,6 +298,14 @@ __device__ __forceinline__ bf16x8 fa_frag_vt(const char* vt, int db, int mm, int
 }
 
 __host__ __device__ inline int fa_pad16(int n) { return (n + 15) & ~15; }
+// Registers filled by ordinary global loads BEFORE a DMA-ring loop must be waited for before the loop: hipcc places the wait at
+// the first USE, i.e. inside the loop, as s_waitcnt vmcnt(0) -- which on the hardware also drains every LDS-DMA transfer the
+// ring has in flight (one in-order counter): each tile iteration then pays the full L2 / HBM latency of the tile issued a
+// few instructions earlier (cdna guide section 6, trap 4b; found in the ISA of all three ring kernels in round 2).  An empty
+// asm that "modifies" the register makes the compiler wait right here.
+template <class T>
+__device__ __forceinline__ void fa_settle(T& v) { asm volatile("" : "+v"(v)); }
+
 // dynamic LDS of the ring kernels: ring | tile flags [nkt] | key gather list [Lk] | visibility words [128][nkt]
 __host__ __device__ inline size_t fa_smem_bytes(int nkt, int Lk, bool has_index, bool has_bits) {
   return (size_t)FA_RING + fa_pad16(nkt) + (has_index ? (size_t)fa_pad16(Lk * 4) : 0) + (has_bits ? (size_t)128 * nkt * 4 : 0);
@@ -339,6 +351,8 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const uint4 u = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
     qf[s] = *reinterpret_cast<const bf16x8*>(&u);
   }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) fa_settle(qf[s]);
   __syncthreads();
 
   float m_run = -INFINITY, l_run = 0.f;
@@ -352,6 +366,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     return kt < p.nkt ? kt : -1;
   };
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t kst2 = (uint32_t)p.kst * 2u, vst2 = (uint32_t)p.vst * 2u;   // row strides in bytes (operand < 4 GiB: host check)
   // wave w copies rows 8w .. 8w+7 of the K tile and of the V tile: lane -> (row 8w + lane/8, LDS slot lane % 8)
   const int rl = 8 * wave + (lane >> 3);
   const int oct_k = (lane & 7) ^ ((rl >> 1) & 7);
@@ -359,10 +374,10 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   auto issue = [&](int kt, int slot) {
     int row = kt * 32 + rl;
     row = row < p.Lk ? row : p.Lk - 1;
-    const int64_t src = p.key_index ? (int64_t)kidx[row] : (int64_t)row;
+    const uint32_t src = p.key_index ? (uint32_t)kidx[row] : (uint32_t)row;
     const uint32_t dst = smem_base + (uint32_t)(slot * FA_STAGE + wave * 1024);
-    fa_glds16(kb + src * p.kst + oct_k * 8, __builtin_amdgcn_readfirstlane(dst));
-    fa_glds16(vb + src * p.vst + oct_v * 8, __builtin_amdgcn_readfirstlane(dst + FA_TILE));
+    fa_glds16(kb, src * kst2 + oct_k * 16, __builtin_amdgcn_readfirstlane(dst));
+    fa_glds16(vb, src * vst2 + oct_v * 16, __builtin_amdgcn_readfirstlane(dst + FA_TILE));
   };
 
   int kt = next_needed(0);
@@ -832,11 +847,14 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     dof[s] = *reinterpret_cast<const bf16x8*>(&c);
   }
   const int rowid = (b * p.H + h) * p.Lq + q;
-  const float lse2 = q_ok ? p.lse[rowid] * LOG2E : INFINITY;
-  const float dlt = q_ok ? p.delta[rowid] : 0.f;
+  float lse2 = q_ok ? p.lse[rowid] * LOG2E : INFINITY;
+  float dlt = q_ok ? p.delta[rowid] : 0.f;
   uint32_t rowkey = 0;
   if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
   f32x16 dqacc[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { fa_settle(qf[s]); fa_settle(dof[s]); }
+  fa_settle(lse2); fa_settle(dlt);
   __syncthreads();
 
   auto next_needed = [&](int kt) -> int {
@@ -846,13 +864,14 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int rl = 8 * wave + (lane >> 3);
   const int oct = (lane & 7) ^ fa_sw(rl);
+  const uint32_t kst2 = (uint32_t)p.kst * 2u, vst2 = (uint32_t)p.vst * 2u;
   auto issue = [&](int kt, int slot) {
     int row = kt * 32 + rl;
     row = row < p.Lk ? row : p.Lk - 1;
-    const int64_t src = p.key_index ? (int64_t)kidx[row] : (int64_t)row;
+    const uint32_t src = p.key_index ? (uint32_t)kidx[row] : (uint32_t)row;
     const uint32_t dst = smem_base + (uint32_t)(slot * FA_STAGE + wave * 1024);
-    fa_glds16(kb + src * p.kst + oct * 8, __builtin_amdgcn_readfirstlane(dst));
-    fa_glds16(vb + src * p.vst + oct * 8, __builtin_amdgcn_readfirstlane(dst + FA_TILE));
+    fa_glds16(kb, src * kst2 + oct * 16, __builtin_amdgcn_readfirstlane(dst));
+    fa_glds16(vb, src * vst2 + oct * 16, __builtin_amdgcn_readfirstlane(dst + FA_TILE));
   };
 
   int kt = next_needed(0);
@@ -975,6 +994,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
     vf[s] = *reinterpret_cast<const bf16x8*>(&c);
   }
   f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { fa_settle(kf[s]); fa_settle(vf[s]); }
   __syncthreads();
 
   auto next_needed = [&](int qt) -> int {
@@ -984,12 +1005,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int rl = 8 * wave + (lane >> 3);
   const int oct = (lane & 7) ^ fa_sw(rl);
+  const uint32_t qst2 = (uint32_t)p.qst * 2u, dst2 = (uint32_t)p.dst * 2u;
   auto issue = [&](int qt, int slot) {
     int row = qt * 32 + rl;
     row = row < p.Lq ? row : p.Lq - 1;
     const uint32_t dst = smem_base + (uint32_t)(slot * FA_STAGE + wave * 1024);
-    fa_glds16(qb + (int64_t)row * p.qst + oct * 8, __builtin_amdgcn_readfirstlane(dst));
-    fa_glds16(dob + (int64_t)row * p.dst + oct * 8, __builtin_amdgcn_readfirstlane(dst + FA_TILE));
+    fa_glds16(qb, (uint32_t)row * qst2 + oct * 16, __builtin_amdgcn_readfirstlane(dst));
+    fa_glds16(dob, (uint32_t)row * dst2 + oct * 16, __builtin_amdgcn_readfirstlane(dst + FA_TILE));
   };
 
   int qt = next_needed(0);
@@ -1078,6 +1100,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
 
 }  // namespace
 
+// The ring kernels address K / V / Q / dO rows as a 32-bit byte offset from the (batch, head) base: every row they can touch
+// must lie below 4 GiB.  Rows named through key_index are bounded by the contract of include/dvla.h (entries < 2^18).
+static bool attn_span32(int64_t rows, int64_t stride_elems, bool gathered) {
+  const int64_t r = gathered ? (rows > (1 << 18) ? rows : (1 << 18)) : rows;
+  return stride_elems >= 0 && r * stride_elems * 2 + 128 < (1LL << 32);
+}
+
 // DVLA_ATTN_STAGED=1 selects the register-staged kernels (A/B measurements, tests of the fallback path)
 static bool attn_force_staged() {
   static int v = -1;
@@ -1092,7 +1121,8 @@ extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
   if (rc != DVLA_OK) return rc;
   dim3 grid((unsigned)((a.nqt + 3) / 4), (unsigned)a.H, (unsigned)a.B), block(AT_THREADS);
   const size_t smem = fa_smem_bytes(a.nkt, a.Lk, a.key_index != nullptr, a.tile_map != nullptr && a.bits_q != nullptr);
-  if (smem <= 64 * 1024 && !attn_force_staged())
+  const bool span_kv = attn_span32(a.Lk, a.kst, a.key_index != nullptr) && attn_span32(a.Lk, a.vst, a.key_index != nullptr);
+  if (smem <= 64 * 1024 && span_kv && !attn_force_staged())
     hipLaunchKernelGGL(attn_fwd_ring_kernel, grid, block, smem, stream, a);
   else   // mask tables / key list too large for LDS
     hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, a);
@@ -1122,13 +1152,15 @@ extern "C" int dvla_attn_bwd(const dvla_attn_params* q, void* stream_) {
   const size_t smem_dkv = fa_dkv_smem_bytes(a.nqt, a.tile_map != nullptr && a.bits_k != nullptr);
   const dim3 grid_dq((unsigned)((a.nqt + 3) / 4), (unsigned)a.H, (unsigned)a.B);
   const dim3 grid_dkv((unsigned)((a.nkt + 3) / 4), (unsigned)a.H, (unsigned)a.B);
-  if (smem_dq <= 64 * 1024 && !attn_force_staged())
+  const bool span_kv = attn_span32(a.Lk, a.kst, a.key_index != nullptr) && attn_span32(a.Lk, a.vst, a.key_index != nullptr);
+  const bool span_q = attn_span32(a.Lq, a.qst, false) && attn_span32(a.Lq, a.dst, false);
+  if (smem_dq <= 64 * 1024 && span_kv && !attn_force_staged())
     hipLaunchKernelGGL(attn_bwd_dq_ring_kernel, grid_dq, block, smem_dq, stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid_dq, block, 0, stream, a);
   rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
-  if (smem_dkv <= 64 * 1024 && !attn_force_staged())
+  if (smem_dkv <= 64 * 1024 && span_q && !attn_force_staged())
     hipLaunchKernelGGL(attn_bwd_dkv_ring_kernel, grid_dkv, block, smem_dkv, stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid_dkv, block, 0, stream, a);

@@ -106,8 +106,9 @@ int64_t dvla_layernorm_bwd_partial_rows(void);
  *   tile_map    (ceil(Lq/32) x ceil(Lk/32) uint8): 0 = all -inf (tile skipped), 1 = all visible, 2 = mixed
  * so masked tiles cost nothing (64-81 % of the trunk's score matrix) and a mixed tile
  * costs one 32-bit load per lane.  key_index (Lk int32, optional) names the k/v (and dk/dv) token row that
- * holds key j: keys that no query can see are dropped from the key axis without copying K/V; dk/dv rows
- * that are not indexed are NOT written (the caller zero-fills them).
+ * holds key j (any order, every entry < 2^18): keys that no query can see are dropped from the key axis without
+ * copying K/V, and the caller is free to ORDER the kept keys so that keys with the same audience share 32-key tiles
+ * (dreamvla_amd.ops.build_mask_tables does); dk/dv rows that are not indexed are NOT written (the caller zero-fills them).
  * lse (B*H*Lq fp32, natural-log-sum-exp of the scaled+masked scores) is written when non-NULL.
  * Replaces: F.scaled_dot_product_attention in timm Attention (vit_mae.py:202-203, dreamvla_model.py:806-904,
  * action_model/models.py:137), GPT2Attention._attn / GPT2SdpaAttention (models/gpt2.py:61-84,267-274),

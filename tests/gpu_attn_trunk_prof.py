@@ -4,6 +4,7 @@ key list in ascending column order, then N with the audience-grouped order ops.b
 import csv
 import glob
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,7 +42,7 @@ def summarise(d):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     by = {}
     for r in rows:
-        by.setdefault(r["Kernel_Name"].split("(")[0].split("::")[-1], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        by.setdefault(re.search(r"attn_\w+", r["Kernel_Name"]).group(0), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("trunk attention B=32 H=16 L=651, microseconds per launch (median of %d): ascending key list -> audience-grouped key list" % N)
     for k, v in by.items():
         assert len(v) == 4 * N, (k, len(v))
