@@ -2,6 +2,7 @@
 // compiled one (configuration, operand layout) per translation unit in gemm_inst_*.hip so that the build runs in parallel).
 #include <stdlib.h>
 
+#include <mutex>
 #include "gemm_phase.h"
 
 namespace dvla_gemm {
@@ -123,9 +124,56 @@ void launch_phase_epi(const GemmKArgs& a, int split_k, hipStream_t stream) {
     default: launch_phase_one<AT, BT, EPI_GEN, 0>(a, split_k, stream); break;
   }
 }
-void launch_phase(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
+// ---- stream-K scratch: one 256-KiB fp32 slab and one flag per workgroup, per (device, stream); allocated on first use
+// (never while the stream is being captured: such launches take the plain schedule), kept for the life of the process.
+// Flags are zero between launches (the owner of a shared tile lowers the flag it waited for).
+struct SkScratch { int dev; hipStream_t stream; float* slabs; unsigned* flags; int groups; };
+static SkScratch g_sk[16];
+static int g_sk_n = 0;
+static std::mutex g_sk_mu;
+static bool streamk_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DVLA_GEMM_STREAMK"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+static bool sk_scratch(hipStream_t stream, int groups, float** slabs, unsigned** flags) {
+  if (!streamk_enabled()) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  for (int i = 0; i < g_sk_n; ++i)
+    if (g_sk[i].dev == dev && g_sk[i].stream == stream && g_sk[i].groups >= groups) { *slabs = g_sk[i].slabs; *flags = g_sk[i].flags; return true; }
+  if (g_sk_n == 16) return false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (st != hipStreamCaptureStatusNone) return false;
+  SkScratch e{dev, stream, nullptr, nullptr, groups};
+  if (hipMalloc(reinterpret_cast<void**>(&e.slabs), (size_t)groups * PCfg::BM * PCfg::BN * 4) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMalloc(reinterpret_cast<void**>(&e.flags), (size_t)(groups + 1) * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(e.slabs); return false; }
+  if (hipMemsetAsync(e.flags, 0, (size_t)(groups + 1) * 4, stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(e.slabs); (void)hipFree(e.flags); return false; }
+  g_sk[g_sk_n++] = e;
+  *slabs = e.slabs; *flags = e.flags;
+  return true;
+}
+// SUPER-tiles (16 consecutive tile ids each) the stream-K part of the hybrid schedule covers: what is left beyond whole
+// rounds, plus one round (so that a group's range is at least one super-tile long and a tile is shared by at most two
+// workgroups); 0 = the plain schedule is already even / the problem is smaller than one round / odd CU count
+inline int streamk_tiles(int64_t tiles, int cus) {
+  if (cus % 16 != 0) return 0;
+  const int64_t groups = cus / 16, st = (tiles + 15) / 16;
+  if (st < groups || st % groups == 0) return 0;
+  const int64_t dp_rounds = st / groups - 1;
+  return (int)(st - dp_rounds * groups);
+}
+void launch_phase(GemmKArgs& a, int combo, int split_k, hipStream_t stream, bool stream_k = false) {
   a.tiles_m = (int)((a.M + PCfg::BM - 1) / PCfg::BM);
   a.tiles_n = (int)((a.N + PCfg::BN - 1) / PCfg::BN);
+  a.sk_tiles = 0;
+  if (stream_k && split_k == 1) {
+    const int groups = num_cus();
+    const int r = streamk_tiles((int64_t)a.tiles_m * a.tiles_n, groups);
+    if (r > 0 && sk_scratch(stream, groups, &a.sk_slabs, &a.sk_flags)) a.sk_tiles = r;
+  }
   switch (combo) {
     case 0: launch_phase_epi<false, false>(a, split_k, stream); break;
     case 1: launch_phase_epi<false, true>(a, split_k, stream); break;
@@ -167,6 +215,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       return DVLA_ERR_ARG;
   }
   GemmKArgs a;
+  a.sk_tiles = 0; a.sk_slabs = nullptr; a.sk_flags = nullptr;
   a.A = reinterpret_cast<const bf16_t*>(q->A); a.lda = q->lda;
   a.B = reinterpret_cast<const bf16_t*>(q->B); a.ldb = q->ldb;
   a.C = q->C; a.ldc = q->ldc; a.c_f32 = (q->c_dtype == DVLA_DT_F32);
@@ -226,17 +275,28 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       if (ring_ok<RCfgS>(a, combo)) consider(3, 128, 128, 2, 2.9, 0.58);
       if (ring_ok<RCfgM64>(a, combo)) consider(4, 256, 128, 1, 3.6, 0.49);
       if (ring_ok<RCfgL>(a, combo)) consider(1, 256, 256, 1, 5.8, 0.85);
-      if (ring_ok<PCfg>(a, combo)) consider(5, 256, 256, 1, 6.6, 0.775);
+      if (ring_ok<PCfg>(a, combo)) {
+        consider(5, 256, 256, 1, 6.6, 0.775);
+        // stream-K hybrid of the same kernel: fractional rounds, plus one slab write + one slab read per workgroup and the
+        // less regular operand reuse of the shared round (~18 us measured over the plain schedule at equal round counts)
+        const int64_t tiles = ((q->M + 255) / 256) * ((q->N + 255) / 256);
+        if (split_k == 1 && streamk_enabled() && streamk_tiles(tiles, slots) > 0) {
+          const double t = (double)tiles / slots * (6.6 + 0.775 * ns) + 18.0;
+          if (t < best) { best = t; choice = 6; }
+        }
+      }
     } else if (variant == 4 && ring_ok<RCfgL>(a, combo)) choice = 1;
     else if (variant == 6 && ring_ok<RCfgS>(a, combo)) choice = 3;
     else if (variant == 7 && ring_ok<RCfgM64>(a, combo)) choice = 4;
     else if (variant == 8 && ring_ok<PCfg>(a, combo)) choice = 5;
+    else if (variant == 9 && ring_ok<PCfg>(a, combo)) choice = 6;
     else if (variant > 80 && variant < 90 && combo == 0 && ring_ok<PCfg>(a, combo)) choice = 80 + (variant - 80);
     switch (choice) {
       case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;
       case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
       case 4: launch_ring<RCfgM64>(a, combo, split_k, stream); break;
       case 5: launch_phase(a, combo, split_k, stream); break;
+      case 6: launch_phase(a, combo, split_k, stream, true); break;   // falls back to the plain schedule when stream-K does not apply
       case 81: case 83: case 84: case 85: case 86: case 89:   // ablations (plain bf16 epilogue only): 81 no MFMA, 83 no MFMA + no reads, 84 no DMA, 85 no epilogue, 86 raw stores only
         a.tiles_m = (int)((a.M + 255) / 256); a.tiles_n = (int)((a.N + 255) / 256);
         if (epi_class(a) != EPI_P0) return DVLA_ERR_UNSUPPORTED;

@@ -80,6 +80,9 @@ struct GemmKArgs {
   int split_k; int64_t k_per_split; float* workspace;
   int a_vec, b_vec, c_vec, aux_vec, epi_vec;
   int tiles_m, tiles_n;
+  // stream-K hybrid schedule of the phase kernel (gemm_phase.h): the first sk_tiles tiles are cut into gridDim.x equal
+  // K-iteration ranges, the others run one tile per workgroup and round; 0 = plain schedule
+  int sk_tiles; float* sk_slabs; unsigned* sk_flags;
 };
 
 // Row-major image of a k-contiguous operand: row r = 128 B = 8 slots of 16 B; k-octet o of row r lives in slot

@@ -46,6 +46,12 @@ struct PCfg {
   static constexpr int CPW = 4;                      // DMA pieces (1 KiB each) per wave and operand image
 };
 
+// 16-byte agent-coherent accesses to a stream-K slab (256 KiB, register layout) through a buffer descriptor with the sc1 bit:
+// write-through stores / loads served at the device coherence point -- the two workgroups that share a tile sit on different
+// XCDs, whose L2s do not snoop each other (cdna guide section 6, "in-launch combine").
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(float* slab) {
+  return __builtin_amdgcn_make_buffer_rsrc(slab, 0, PCfg::BM * PCfg::BN * 4, 0x00020000);
+}
 // DBG (ablation builds, results are garbage by design; variants 81..86 of the NT layout): 1 = no MFMAs, 2 = no fragment
 // reads, 4 = no DMA, 8 = no barriers inside the K loop
 template <bool A_T, bool B_T, int EPI, int DBG = 0>
@@ -61,9 +67,59 @@ void gemm_phase_kernel(GemmKArgs p) {
   const int nitems = p.tiles_m * p.tiles_n * p.split_k;
   const int grid = gridDim.x;
   const int perm = (grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  auto item_of = [&](int it) -> int {
-    const int id = it * grid + perm;
-    return id < nitems ? id : -1;
+  // ---- work segments.  Plain schedule: segment `it` = item it * grid + perm (a whole tile, or one K slice of it).
+  // Stream-K hybrid (p.sk_tiles = R > 0 SUPER-tiles, split_k == 1, one workgroup per CU):
+  //   a super-tile = SG = 16 consecutive tile ids (the raster makes that a 4 x 4 block of tiles), worked on by a GROUP of
+  //   16 workgroups of adjacent rank (one XCD) in K lockstep, workgroup i of the group on tile i of the super-tile -- so the
+  //   4 x 4 block's operand slices are fetched once per group and K-tile, as in the plain schedule (ranges per single
+  //   workgroup, each at its own K offset, share nothing: 1.3 GB of L2 misses per 20832 x 1024 x 4096 launch, HBM-bound);
+  //   the K-iterations of the first R super-tiles (R * nsT, super-tile-major) are cut into grid / 16 equal contiguous ranges,
+  //   one per group; then one whole tile per workgroup and round from the rest (16 R + j * grid + perm).
+  //   R >= number of groups, so a range is at least nsT long and a tile is shared by at most two workgroups: its HEAD
+  //   (from k = 0) is the LAST stream-K segment of workgroup `perm`, its TAIL (to the end) the FIRST segment of workgroup
+  //   perm + 16.  The tail's accumulators go to slab perm + 16 (fp32, register layout, write-through stores) and flag
+  //   perm + 16 is raised; the head's workgroup -- the tile's owner -- waits for that flag, adds the slab and runs the
+  //   epilogue.  A tail is the first thing its workgroup does and waits for nothing, so every wait ends as soon as that
+  //   workgroup has been scheduled and has run its first segment (all workgroups are co-resident: one per CU; a late one only
+  //   delays one epilogue of its predecessor).  The owner lowers the flag again: no per-launch memset.
+  constexpr int SG = 16;
+  const int nsT = (int)(p.K / BKS);
+  const int sk_R = p.sk_tiles;
+  const int sk_gi = perm & (SG - 1);
+  unsigned sk_lo = 0, sk_hi = 0;
+  int sk_t0 = 0, sk_n = 0;
+  if (sk_R > 0) {
+    const unsigned groups = (unsigned)grid / SG, g = (unsigned)perm / SG;
+    const unsigned long long I = (unsigned long long)sk_R * (unsigned)nsT;
+    sk_lo = (unsigned)(I * g / groups);
+    sk_hi = (unsigned)(I * (g + 1) / groups);
+    if (sk_hi > sk_lo) { sk_t0 = (int)(sk_lo / (unsigned)nsT); sk_n = (int)((sk_hi - 1) / (unsigned)nsT) - sk_t0 + 1; }
+    while (sk_n > 0 && (sk_t0 + sk_n - 1) * SG + sk_gi >= nitems) --sk_n;   // the last super-tile may be ragged
+  }
+  struct Seg { int m0, n0, k_begin, ns, split, kind; };   // kind: 0 whole item, 1 head (owner), 2 tail
+  auto seg_of = [&](int it, Seg& sg) -> bool {
+    int id;
+    sg.kind = 0;
+    if (sk_R == 0) {
+      id = it * grid + perm;
+      if (id >= nitems) return false;
+    } else if (it < sk_n) {
+      const int st = sk_t0 + it;
+      id = st * SG + sk_gi;
+      const unsigned t_begin = (unsigned)st * (unsigned)nsT, t_end = t_begin + (unsigned)nsT;
+      const unsigned b = sk_lo > t_begin ? sk_lo : t_begin, e = sk_hi < t_end ? sk_hi : t_end;
+      const RingItem w = ring_item<PCfg>(p, id);
+      sg.m0 = (int)w.m0; sg.n0 = (int)w.n0; sg.split = 0;
+      sg.k_begin = (int)(b - t_begin) * BKS; sg.ns = (int)(e - b);
+      sg.kind = b != t_begin ? 2 : (e != t_end ? 1 : 0);
+      return true;
+    } else {
+      id = sk_R * SG + (it - sk_n) * grid + perm;
+      if (id >= nitems) return false;
+    }
+    const RingItem w = ring_item<PCfg>(p, id);
+    sg.m0 = (int)w.m0; sg.n0 = (int)w.n0; sg.k_begin = (int)w.k_begin; sg.ns = w.ns; sg.split = w.split;
+    return true;
   };
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -76,19 +132,17 @@ void gemm_phase_kernel(GemmKArgs p) {
   const int64_t stepA = A_T ? (int64_t)BKS * p.lda : (int64_t)BKS;
   const int64_t stepB = B_T ? (int64_t)BKS * p.ldb : (int64_t)BKS;
   auto openA = [&](int it) {
-    const int id = item_of(it);
-    liveA = id >= 0;
+    Seg w;
+    liveA = seg_of(it, w);
     if (!liveA) return;
-    const RingItem w = ring_item<PCfg>(p, id);
     nkA = w.ns; ktA = 0;
 #pragma unroll
     for (int i = 0; i < CPW; ++i) srcA[i] = dma_src<A_T, BM, BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, wave * CPW + i, lane);
   };
   auto openB = [&](int it) {
-    const int id = item_of(it);
-    liveB = id >= 0;
+    Seg w;
+    liveB = seg_of(it, w);
     if (!liveB) return;
-    const RingItem w = ring_item<PCfg>(p, id);
     nkB = w.ns; ktB = 0;
 #pragma unroll
     for (int i = 0; i < CPW; ++i) srcB[i] = dma_src<B_T, BN, BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, wave * CPW + i, lane);
@@ -146,9 +200,12 @@ void gemm_phase_kernel(GemmKArgs p) {
   };
   int u = 0, ua = 0;   // global K-tile counter of the multiply, and u % 3
   for (int it = 0;; ++it) {
-    const int id = item_of(it);
-    if (id < 0) break;
-    const RingItem w = ring_item<PCfg>(p, id);
+    int seg_ns;
+    {
+      Seg w0;
+      if (!seg_of(it, w0)) break;
+      seg_ns = w0.ns;       // the segment's tile origin / kind are recomputed for the epilogue: nothing but the K-tile
+    }                       // count stays live across the K loop (the loop sits at the 256-VGPR limit)
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -161,7 +218,7 @@ void gemm_phase_kernel(GemmKArgs p) {
     if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one segment behind group 0
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int kt = 0; kt < w.ns; ++kt, ++u, ua = (ua == PCfg::NA - 1 ? 0 : ua + 1)) {
+    for (int kt = 0; kt < seg_ns; ++kt, ++u, ua = (ua == PCfg::NA - 1 ? 0 : ua + 1)) {
       const char* bufA = smem + ua * PCfg::A_BYTES;                         // ua = u % 3
       const char* bufB = smem + PCfg::B_BASE + (u & 1) * PCfg::B_BYTES;
       bf16x8 fa[2][4], fb[2][4];   // [sub-tile][k16-step]
@@ -263,13 +320,21 @@ void gemm_phase_kernel(GemmKArgs p) {
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align: both groups run the epilogue together
     __builtin_amdgcn_sched_barrier(0);
+    Seg w;
+    int lane_e = lane;
+    {
+      int it2 = it;
+      asm volatile("" : "+s"(it2));               // (keeps the compiler from carrying the first evaluation across the loop;
+      asm volatile("" : "+v"(lane_e));            //  likewise the per-lane epilogue addresses it would hoist out of the
+      (void)seg_of(it2, w);                       //  segment loop and spill: they are re-derived per tile from lane_e)
+    }
     if (DBG & 16) {        // no epilogue at all (keep the accumulators alive)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
     } else if (DBG & 32) { // stores only: 16 x 16 B per lane straight from accumulator registers (no conversion, no exchange)
-      const int l31 = lane & 31, g = lane >> 5;
+      const int l31 = lane_e & 31, g = lane_e >> 5;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t m = w.m0 + grp * 128 + j * 32 + l31;
@@ -281,8 +346,50 @@ void gemm_phase_kernel(GemmKArgs p) {
                            __float_as_uint(acc[q >> 1][j][4 * (q & 1) + 2]), __float_as_uint(acc[q >> 1][j][4 * (q & 1) + 3]));
         }
       }
+    } else if (w.kind == 2) {
+      // stream-K tail: the 128 accumulators of every lane -> slab `perm`, quad (i, j, rq) of wave `wave` at
+      // [(wave * 32 + quad) * 64 + lane] (16 B per lane, 1 KiB per instruction), write-through (sc1: the owner sits on
+      // another XCD); then every wave drains its stores, the workgroup meets, and one lane raises the flag.
+      const __amdgpu_buffer_rsrc_t rs = sk_rsrc(p.sk_slabs + (size_t)perm * (BM * BN));
+      const int voff = (wave * 32 * 64 + lane_e) * 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const u32x4 v = {__float_as_uint(acc[i][j][4 * rq]), __float_as_uint(acc[i][j][4 * rq + 1]),
+                             __float_as_uint(acc[i][j][4 * rq + 2]), __float_as_uint(acc[i][j][4 * rq + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + ((i * 4 + j) * 4 + rq) * 1024, 0, 16);
+          }
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (t == 0) __hip_atomic_store(p.sk_flags + perm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      reg_epilogue<4, EPI>(p, acc, lane, w.m0 + grp * 128, w.n0 + wc * 64, w.split);
+      if (w.kind == 1) {
+        // stream-K head = owner: wait for the tail of this tile (workgroup perm + 16), add its slab, lower the flag
+        if (t == 0) {
+          while (__hip_atomic_load(p.sk_flags + perm + SG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+          __hip_atomic_store(p.sk_flags + perm + SG, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_barrier();
+        const __amdgpu_buffer_rsrc_t rs = sk_rsrc(p.sk_slabs + (size_t)(perm + SG) * (BM * BN));
+        const int voff = (wave * 32 * 64 + lane_e) * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {     // 16 quads (64 VGPRs) per batch
+          u32x4 v[16];
+#pragma unroll
+          for (int qd = 0; qd < 16; ++qd) v[qd] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (i * 16 + qd) * 1024, 0, 16);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              acc[i][j][4 * rq] += __uint_as_float(v[j * 4 + rq].x); acc[i][j][4 * rq + 1] += __uint_as_float(v[j * 4 + rq].y);
+              acc[i][j][4 * rq + 2] += __uint_as_float(v[j * 4 + rq].z); acc[i][j][4 * rq + 3] += __uint_as_float(v[j * 4 + rq].w);
+            }
+        }
+      }
+      reg_epilogue<4, EPI>(p, acc, lane_e, w.m0 + grp * 128, w.n0 + wc * 64, w.split);
     }
   }
 }

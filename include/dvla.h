@@ -63,9 +63,15 @@ typedef struct dvla_gemm_params {
   int32_t split_k; void* workspace;
 } dvla_gemm_params;
 int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
-/* tuning hook: 0 = automatic kernel choice (default; env DVLA_GEMM_VARIANT overrides at load), 2 = register-staged
- * 128x128 kernel, 4 / 5 / 6 = LDS-DMA ring kernel 256x256 / 256x128 / 128x128 where it applies, 11..16 = ablation
- * builds (wrong results by design, timing only).  Variants 0..6 differ only in fp32 summation order. */
+/* tuning hook: 0 = automatic kernel choice by the built-in cost model (default; env DVLA_GEMM_VARIANT overrides at load);
+ * 2 = register-staged 128x128 kernel; 4 / 6 / 7 = LDS-DMA ring kernels 256x256 / 128x128 / 256x128 (K-tile 64); 8 = phase
+ * kernel (256x256, K-tile 64, two wave groups in ping-pong); 9 = the phase kernel under the stream-K hybrid schedule (whole
+ * rounds one tile per CU; the last, partial rounds as equal K-iteration ranges per group of 16 CUs, the two halves of a
+ * shared tile combined in-kernel through a 256-KiB fp32 slab).  A configuration that does not take a shape falls back
+ * inside the library.  All differ only in fp32 summation order.  81..89 = ablation / timeline builds of the phase kernel
+ * (wrong results by design, tests/probes/gemm_probe.cpp).
+ * Stream-K scratch: 64 MiB + flags per (device, stream), hipMalloc'ed on the first launch that uses it (never while the
+ * stream is being captured -- such launches take the plain schedule) and kept; DVLA_GEMM_STREAMK=0 turns the schedule off. */
 void dvla_set_gemm_variant(int variant);
 
 /* ---------------------------------------------------------------------------------------------------

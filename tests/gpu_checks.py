@@ -393,6 +393,7 @@ def all_checks(quick=False):
     # every hand-written configuration forced in turn over the epilogue matrix (the tuner locks 2 / 4 / 5 / 6 on the model's
     # shapes; a forced configuration that does not take a shape falls back inside the library, which is still a valid run):
     # 2 = register-staged 128x128, 4 / 6 / 7 = LDS-DMA ring 256x256 / 128x128 / 256x128 BK 64, 8 = phase kernel 256x256 BK 64
+    # (9 = the same kernel under the stream-K hybrid schedule: below, at sizes where it engages)
     for v in (2, 4, 6, 7, 8):
         L += [
             (check_gemm, dict(M=2100, N=1024, K=256, bias=True, act="gelu_tanh", want_preact=True, variant=v)),
@@ -406,6 +407,17 @@ def all_checks(quick=False):
             (check_gemm, dict(M=768, N=1024, K=2048, a_trans=True, b_trans=True, out_f32=True, variant=v)),
             (check_gemm, dict(M=1300, N=832, K=128, bias=True, out_f32=True, residual=True, variant=v)),
             (check_gemm, dict(M=1024, N=512, K=1024, a_trans=True, variant=v)),
+        ]
+    # 9 = the phase kernel's stream-K hybrid schedule: it only engages from one tile per CU upwards (328 tiles here: 20.5
+    # super-tiles of 16, i.e. ragged), with tiles shared by two workgroups -- every epilogue class, both slab paths, twice in a
+    # row on the same scratch (the flags must come back down)
+    for rep in range(2):
+        L += [
+            (check_gemm, dict(M=20832, N=1024, K=320, bias=True, act="gelu_tanh", want_preact=True, variant=9, seed=rep)),
+            (check_gemm, dict(M=20832, N=1024, K=192, bias=True, dropout_p=0.1, residual=True, b_trans=True, variant=9, seed=rep)),
+            (check_gemm, dict(M=20832, N=1024, K=448, dact="gelu_erf", variant=9, seed=rep)),
+            (check_gemm, dict(M=20992, N=1024, K=256, a_trans=True, b_trans=True, out_f32=True, variant=9, seed=rep)),
+            (check_gemm, dict(M=21000, N=1088, K=128, bias=True, act="gelu_erf", residual=True, variant=9, seed=rep)),
         ]
     L += [(check_flat_adamw, dict()), (check_direct_grads, dict()), (check_assemble_tokens, dict())]
     L += [(check_fused_losses, dict(case_name=c)) for c in ("C_calvin_dit", "E_libero_all_heads", "E_atten_goal")]

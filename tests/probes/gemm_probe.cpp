@@ -193,7 +193,7 @@ static void check_variant(const Case& c, int variant, int64_t Mchk) {
 
 int main(int argc, char** argv) {
   std::vector<int> variants = {0, 2, 4, 5, 6};
-  int iters = 7, rounds = 3; bool check_only = false, no_check = false, stamps = false; int64_t stamps_k = 1024; std::string which = "model";
+  int iters = 7, rounds = 3; bool check_only = false, no_check = false, full_check = false, stamps = false; int64_t stamps_k = 1024; std::string which = "model";
   std::vector<int> stamp_variants = {89};
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--variants") && i + 1 < argc) variants = parse_list(argv[++i]);
@@ -201,6 +201,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--rounds") && i + 1 < argc) rounds = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--check-only")) check_only = true;
     else if (!strcmp(argv[i], "--no-check")) no_check = true;
+    else if (!strcmp(argv[i], "--full-check")) full_check = true;   // additionally: every variant at the case's FULL size, twice
     else if (!strcmp(argv[i], "--stamps")) { stamps = true; if (i + 1 < argc && argv[i + 1][0] != '-') stamps_k = atoll(argv[++i]); }
     else if (!strcmp(argv[i], "--stamp-variants") && i + 1 < argc) stamp_variants = parse_list(argv[++i]);
     else if (!strcmp(argv[i], "--cases") && i + 1 < argc) which = argv[++i];
@@ -286,6 +287,13 @@ int main(int argc, char** argv) {
       if (cc.N > 1024 && !c.at) cc.N = 1024;
       for (int v : variants) check_variant(cc, v, Mchk);
     }
+  }
+  // the stream-K schedule only engages at full size (>= one tile per CU) and reuses its flags from launch to launch: twice
+  if (full_check) {
+    for (const Case& c : cases)
+      if ((double)c.M * (double)c.N <= 1.2e8)
+        for (int v : variants)
+          for (int rep = 0; rep < 2; ++rep) check_variant(c, v, c.M);
   }
   if (check_only) return 0;
   // ---- timing: variants interleaved, `rounds` rounds of `iters` launches each; median / min over rounds ----
