@@ -132,19 +132,20 @@ inline uint32_t thr_of(float p) {
 // gather-write pass replaces torch.cat + the position add.  One 16-byte vector per thread.
 struct AsmSrc { const bf16_t* p; int64_t sb, ss; int t0; };
 struct AsmArgs { AsmSrc src[DVLA_MAX_TOKEN_SRCS]; int n_src; bf16_t* out; const bf16_t* pos; int64_t pos_ss; int B, S, T, H; };
+template <class IDX>   // IDX = uint32_t when the vector count fits (64-bit div / mod per 16 bytes would pace the copy)
 __global__ __launch_bounds__(256) void assemble_kernel(AsmArgs a) {
-  const int hv = a.H >> 3;
-  const int64_t total = (int64_t)a.B * a.S * a.T * hv;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int v = (int)(i % hv);
-    const int64_t row = i / hv;
-    const int t = (int)(row % a.T);
-    const int64_t bs = row / a.T;
-    const int s = (int)(bs % a.S);
-    const int64_t b = bs / a.S;
+  const IDX hv = (IDX)(a.H >> 3);
+  const IDX total = (IDX)a.B * (IDX)a.S * (IDX)a.T * hv;
+  for (IDX i = (IDX)blockIdx.x * 256 + threadIdx.x; i < total; i += (IDX)gridDim.x * 256) {
+    const IDX row = i / hv;
+    const int v = (int)(i - row * hv);
+    const IDX bs = row / (IDX)a.T;
+    const int t = (int)(row - bs * (IDX)a.T);
+    const IDX b = bs / (IDX)a.S;
+    const int s = (int)(bs - b * (IDX)a.S);
     int k = 0;
     while (k + 1 < a.n_src && t >= a.src[k + 1].t0) ++k;      // sources are sorted by first token
-    const bf16_t* sp = a.src[k].p + b * a.src[k].sb + (int64_t)s * a.src[k].ss + (int64_t)(t - a.src[k].t0) * a.H + v * 8;
+    const bf16_t* sp = a.src[k].p + (int64_t)b * a.src[k].sb + (int64_t)s * a.src[k].ss + (int64_t)(t - a.src[k].t0) * a.H + v * 8;
     const uint4 x = *reinterpret_cast<const uint4*>(sp);
     uint4 o = x;
     if (a.pos) {
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmArgs a) {
                        bf2f((bf16_t)(xs[q] >> 16)) + bf2f((bf16_t)(zs[q] >> 16)));
       o = make_uint4(r[0], r[1], r[2], r[3]);
     }
-    *reinterpret_cast<uint4*>(a.out + row * a.H + v * 8) = o;
+    *reinterpret_cast<uint4*>(a.out + (int64_t)row * a.H + v * 8) = o;
   }
 }
 
@@ -260,7 +261,11 @@ extern "C" int dvla_assemble_tokens(const dvla_token_src* srcs, int32_t n_src, c
   a.pos = reinterpret_cast<const bf16_t*>(pos);
   a.pos_ss = pos_stride_s;
   a.B = B; a.S = S; a.T = T; a.H = H;
-  hipLaunchKernelGGL(assemble_kernel, dim3(grid_for((int64_t)B * S * T * H, 8)), dim3(256), 0, stream, a);
+  const int64_t vecs = (int64_t)B * S * T * (H / 8);
+  if (vecs + 256LL * 4096 < (1LL << 32))
+    hipLaunchKernelGGL(assemble_kernel<uint32_t>, dim3(grid_for(vecs)), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(assemble_kernel<uint64_t>, dim3(grid_for(vecs)), dim3(256), 0, stream, a);
   return dvla_check_launch();
 }
 

@@ -455,7 +455,12 @@ class DreamVLA(nn.Module):
         vdt = torch.bfloat16
         n = B * S
         with torch.no_grad():
-            imgs = torch.cat((image_primary.flatten(0, 1), image_wrist.flatten(0, 1)), dim=0).to(vdt)
+            if image_primary.dtype == vdt and image_wrist.dtype == vdt and image_primary[0, 0].numel() % 8 == 0:
+                # both views as one batch: one 16-byte-vector copy pass (torch.cat moved these 135 MB at ~0.9 TB/s)
+                frame = tuple(image_primary.shape[2:])
+                imgs = ops.assemble_tokens([image_primary.reshape(1, 1, 1, -1), image_wrist.reshape(1, 1, 1, -1)]).view(2 * n, *frame)
+            else:
+                imgs = torch.cat((image_primary.flatten(0, 1), image_wrist.flatten(0, 1)), dim=0).to(vdt)
             feats, _, _ = self.vision_encoder.forward_encoder(imgs, mask_ratio=0.0)       # (2n, 197, 768)
         feats = feats.to(torch.bfloat16)
         cls_tok = feats[:, :1, :]

@@ -108,9 +108,8 @@ class Block(nn.Module):
         its weight-gradient contraction) and broadcast into the per-sequence qkv buffer; from the attention on everything
         is per sequence.  Same function values as forward(cat(prefix, suffix.expand)); autograd sums the shared rows'
         gradient over the batch before the (tiny) backward GEMMs.   prefix (n_seq, n_q, D), suffix (n_suffix, D)."""
-        x = torch.cat((prefix, suffix.unsqueeze(0).expand(n_seq, -1, -1)), dim=1)
-        qkv = torch.cat((self.attn.qkv(self.norm1(prefix)),
-                         self.attn.qkv(self.norm1(suffix)).unsqueeze(0).expand(n_seq, -1, -1)), dim=1)
+        x = ops.concat_shared_suffix(prefix, suffix)
+        qkv = ops.concat_shared_suffix(self.attn.qkv(self.norm1(prefix)), self.attn.qkv(self.norm1(suffix)))
         o = ops.self_attention(qkv, self.attn.num_heads, scale=self.attn.scale)
         x = self.attn.proj(o, residual=x)
         r, n = self.norm2.fork(x)

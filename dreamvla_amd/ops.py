@@ -1036,6 +1036,48 @@ class _AssembleTokens(torch.autograd.Function):
         return (gpos, *grads)
 
 
+class _ConcatSharedSuffix(torch.autograd.Function):
+    """[prefix_b ; suffix] for every sequence b: (n, nq, D) and ONE (ns, D) block shared by all sequences -> (n, nq + ns, D).
+    Forward = one gather-write pass (dvla_assemble_tokens with a zero batch stride for the suffix: write-bound); backward =
+    a slice for the prefix and ONE column-sum pass over the batch for the suffix (dvla_colsum on the (n, ns * D) window of the
+    gradient).  torch.cat((prefix, suffix.expand(n, ...))) + autograd's expand-backward moved the same bytes at a third of the
+    bandwidth (the dream-head decoders build a 564-MB qkv buffer this way: 2.7 ms of cat kernels per training step)."""
+
+    @staticmethod
+    def forward(ctx, prefix, suffix):
+        lib = _lib.load()
+        _req(prefix, "concat_shared_suffix.prefix"); _req(suffix, "concat_shared_suffix.suffix")
+        n, nq, D = prefix.shape
+        ns = suffix.shape[0]
+        if suffix.shape[1] != D or D % 8 != 0:
+            raise ValueError("concat_shared_suffix: (n, nq, D) and (ns, D) with D % 8 == 0")
+        if not (prefix.stride(2) == 1 and prefix.stride(1) == D and prefix.stride(0) % 8 == 0 and prefix.data_ptr() % 16 == 0):
+            prefix = prefix.contiguous()
+        suffix = suffix.contiguous()
+        srcs = (_lib.TokenSrc * 2)()
+        srcs[0] = _lib.TokenSrc(prefix.data_ptr(), prefix.stride(0), 0, 0, nq)
+        srcs[1] = _lib.TokenSrc(suffix.data_ptr(), 0, 0, nq, ns)
+        out = torch.empty((n, nq + ns, D), dtype=BF16, device=prefix.device)
+        check(lib.dvla_assemble_tokens(srcs, 2, None, D, out.data_ptr(), n, 1, nq + ns, D, _stream()), "dvla_assemble_tokens")
+        ctx.nq, ctx.ns = nq, ns
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _req(g, "concat_shared_suffix.grad").contiguous()
+        n, L, D = g.shape
+        dp = g[:, :ctx.nq] if ctx.needs_input_grad[0] else None
+        ds = None
+        if ctx.needs_input_grad[1]:
+            ds = colsum(g.view(n, L * D)[:, ctx.nq * D:], out_dtype=BF16).view(ctx.ns, D)
+        return dp, ds
+
+
+def concat_shared_suffix(prefix, suffix):
+    """(n, nq, D), (ns, D) -> (n, nq + ns, D): every sequence followed by the same suffix block"""
+    return _ConcatSharedSuffix.apply(to_compute(prefix), to_compute(suffix))
+
+
 def assemble_tokens(parts, pos=None):
     """(B, S, sum t_k, H) = cat(parts, dim=2) + pos"""
     if len(parts) > 16:

@@ -105,7 +105,11 @@ class MaskedAutoencoderViT(nn.Module):
         # patch-embed GEMM + bias; the fixed pos-embed add rides in the residual slot of the epilogue
         x = self.patch_embed(x, pos=self.pos_embed[0, 1:, :])
         cls_token = (self.cls_token + self.pos_embed[:, :1, :]).to(x.dtype)
-        x = torch.cat((cls_token.expand(n, -1, -1), x), dim=1)
+        if x.dtype == torch.bfloat16 and not torch.is_grad_enabled():
+            D = x.shape[-1]       # the frozen encoder of DreamVLA: one gather-write pass instead of torch.cat
+            x = ops.assemble_tokens([cls_token.reshape(1, 1, 1, D).expand(n, 1, 1, D), x.reshape(n, 1, L, D)]).view(n, L + 1, D)
+        else:
+            x = torch.cat((cls_token.expand(n, -1, -1), x), dim=1)
         for blk in self.blocks:
             x = blk(x)
         x = self.norm(x)

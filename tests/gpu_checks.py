@@ -419,7 +419,8 @@ def all_checks(quick=False):
             (check_gemm, dict(M=20992, N=1024, K=256, a_trans=True, b_trans=True, out_f32=True, variant=9, seed=rep)),
             (check_gemm, dict(M=21000, N=1088, K=128, bias=True, act="gelu_erf", residual=True, variant=9, seed=rep)),
         ]
-    L += [(check_flat_adamw, dict()), (check_direct_grads, dict()), (check_assemble_tokens, dict())]
+    L += [(check_flat_adamw, dict()), (check_direct_grads, dict()), (check_assemble_tokens, dict()),
+          (check_concat_shared_suffix, dict()), (check_concat_shared_suffix, dict(n=5, nq=9, ns=256, D=3072, seed=1))]
     L += [(check_fused_losses, dict(case_name=c)) for c in ("C_calvin_dit", "E_libero_all_heads", "E_atten_goal")]
     L += [
         (check_layernorm, dict(rows=37, cols=768, eps=1e-6)),
@@ -524,6 +525,27 @@ def check_assemble_tokens(B=3, S=4, H=1024, seed=0):
     for nm, a, b in zip(("text", "state", "img", "tok_a", "tok_b", "pos", "sliced"), gh, gr):
         out.append(metrics(f"assemble_tokens d{nm}", a, b.cpu(), 1e-6, round_ref=False))
     return out
+
+
+def check_concat_shared_suffix(n=37, nq=9, ns=196, D=1024, seed=0):
+    """ops.concat_shared_suffix == torch.cat((prefix, suffix.expand(n, ...)), 1) bit for bit; prefix gradient = the slice,
+    suffix gradient = the batch sum (fp32 accumulation, one bf16 rounding -- what autograd's expand-backward does)."""
+    from dreamvla_amd import ops
+    res = {}
+    for mode in ("hip", "ref"):
+        gg = torch.Generator().manual_seed(77 + seed)
+        big = rnd((n, nq + 2, D), gg).to(DEV, BF).requires_grad_(True)
+        suffix = rnd((ns, D), gg).to(DEV, BF).requires_grad_(True)
+        prefix = big[:, 1:1 + nq]                                  # a strided view, as a caller may hand over
+        y = ops.concat_shared_suffix(prefix, suffix) if mode == "hip" else torch.cat((prefix, suffix.unsqueeze(0).expand(n, -1, -1)), 1)
+        w = rnd(tuple(y.shape), torch.Generator().manual_seed(9)).to(DEV, BF)
+        (y.float() * w.float()).sum().backward()
+        res[mode] = (y.detach(), big.grad.detach().float(), suffix.grad.detach().float())
+    yh, gph, gsh = res["hip"]
+    yr, gpr, gsr = res["ref"]
+    return [{"name": "concat_shared_suffix == cat (bit-exact)", "rel_l2": rel_l2(yh, yr), "tol": 0.0, "ok": bool(torch.equal(yh, yr))},
+            metrics("concat_shared_suffix dprefix", gph, gpr.cpu(), 1e-6, round_ref=False),
+            metrics("concat_shared_suffix dsuffix", gsh, gsr.cpu(), 4e-3, round_ref=False)]
 
 
 def check_direct_grads(seed=0):
