@@ -117,10 +117,10 @@ def main():
     ap.add_argument("--seq", type=int, default=7)
     ap.add_argument("--heads", default="C", choices=sorted(HEAD_SETS))
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--tune-steps", type=int, default=15,
+    ap.add_argument("--tune-steps", type=int, default=22,
                     help="untimed steps BEFORE the warm-up in which dreamvla_amd.ops.GemmTuner tries each GEMM kernel "
                          "configuration once per problem shape and locks the fastest (setup, like building the extension); "
-                         "seven candidates x GemmTuner.ROUNDS (2) trials: shapes that occur once per step need fifteen steps to lock")
+                         "seven candidates x GemmTuner.ROUNDS (3) trials (median): shapes that occur once per step need 22 steps to lock")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true",

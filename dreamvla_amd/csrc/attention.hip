@@ -46,6 +46,7 @@ struct AttnKArgs {
   float* delta;
   bf16_t *dq, *dk, *dv;
   int64_t dqsb, dqst, dqsh, dksb, dkst, dksh, dvsb, dvst, dvsh;
+  int st16;   // bit 0 / 1 / 2 / 3: o / dq / dk / dv rows are 16-byte aligned (16-byte output stores)
 };
 
 // accumulator register r of lane group g  <->  row index inside the 32-row MFMA tile
@@ -110,8 +111,29 @@ __device__ __forceinline__ f32x16 zero16() {
   for (int r = 0; r < 16; ++r) z[r] = 0.f;
   return z;
 }
-// store the transposed accumulators (lane = token row, regs = d) of one token as 16 x 8-byte pieces
-__device__ __forceinline__ void store_token(bf16_t* dst, const f32x16 (&acc)[2], float mul, int g) {
+// store the transposed accumulators (lane = token row, registers = d) of one token.
+//   vec16: the two half-waves hold alternating 4-value groups of the same row (d = 32 db + 8 rq + 4 g + e); one
+//   v_permlane32_swap per packed dword turns two groups into 8 consecutive bf16 per lane -- 4 stores of 16 B per lane
+//   instead of 16 of 8 B.  (The output tail of these kernels is store-ISSUE bound: with 8-byte pieces the "loop skeleton"
+//   build of the forward kernel -- no arithmetic, no K / V traffic -- took 62 % of the full kernel's time at L = 205,
+//   profiles/r02_attn_ablation.txt.)  Needs 16-byte aligned rows; otherwise the 8-byte form.
+__device__ __forceinline__ void fa_swap_halves(uint32_t& lo_grp, uint32_t& hi_grp) {
+  const auto r = __builtin_amdgcn_permlane32_swap(lo_grp, hi_grp, false, false);
+  lo_grp = r[0]; hi_grp = r[1];
+}
+__device__ __forceinline__ void store_token(bf16_t* dst, const f32x16 (&acc)[2], float mul, int g, bool vec16) {
+  if (vec16) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        uint32_t a0 = pack2bf(acc[db][8 * q] * mul, acc[db][8 * q + 1] * mul), a1 = pack2bf(acc[db][8 * q + 2] * mul, acc[db][8 * q + 3] * mul);
+        uint32_t b0 = pack2bf(acc[db][8 * q + 4] * mul, acc[db][8 * q + 5] * mul), b1 = pack2bf(acc[db][8 * q + 6] * mul, acc[db][8 * q + 7] * mul);
+        fa_swap_halves(a0, b0); fa_swap_halves(a1, b1);
+        *reinterpret_cast<uint4*>(dst + 32 * db + 16 * q + 8 * g) = make_uint4(a0, a1, b0, b1);
+      }
+    return;
+  }
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -243,7 +265,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
   }
   if (q_ok) {
     const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
-    store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g);
+    store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g, (p.st16 & 1) != 0);
     if (p.lse && g == 0) p.lse[rowid] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
   }
 }
@@ -311,15 +333,20 @@ __host__ __device__ inline size_t fa_smem_bytes(int nkt, int Lk, bool has_index,
   return (size_t)FA_RING + fa_pad16(nkt) + (has_index ? (size_t)fa_pad16(Lk * 4) : 0) + (has_bits ? (size_t)128 * nkt * 4 : 0);
 }
 
+// DBG (ablation builds selected by env DVLA_ATTN_DBG, results garbage by design, timing only -- tests/gpu_attn_ablate.py):
+//   1 no barrier / DMA wait in the tile loop, 2 no softmax arithmetic, 4 no P.V (fragment reads + MFMAs), 8 no K.Q^T,
+//   16 no DMA after the prologue, 32 no Q load / O store, 64 return at once (launch + dispatch)
+template <int DBG>
 __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_ring_kernel(AttnKArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (DBG & 64) return;                       // launch + workgroup dispatch only
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
   const int qt0 = blockIdx.x * 4;
   const int qt = qt0 + wave;
   const int q = qt * 32 + l31;
-  const bool q_ok = q < p.Lq;
+  const bool q_ok = (DBG & 32) ? false : q < p.Lq;   // 32: no Q load, no O store
   const float scale_log2 = p.scale * LOG2E;
   const bool has_bits = p.tile_map != nullptr && p.bits_q != nullptr;
 
@@ -331,6 +358,15 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
   const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
 
+  // the Q fragments are requested FIRST and waited for LAST (after the first K / V tiles are on their way): the workgroup's
+  // memory round trips -- tables, Q, first tiles -- overlap instead of queueing (short sequences are latency-bound per
+  // workgroup: the loop of L = 205 has 7 tiles)
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 u = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
+    qf[s] = *reinterpret_cast<const bf16x8*>(&u);
+  }
   for (int kt = t; kt < p.nkt; kt += AT_THREADS) {
     int f = 0;
 #pragma unroll
@@ -345,14 +381,6 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       const int qq = qt0 * 32 + ql;
       bits[i] = qq < p.Lq ? p.bits_q[(int64_t)qq * p.nkt + kt] : 0u;
     }
-  bf16x8 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const uint4 u = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
-    qf[s] = *reinterpret_cast<const bf16x8*>(&u);
-  }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) fa_settle(qf[s]);
   __syncthreads();
 
   float m_run = -INFINITY, l_run = 0.f;
@@ -389,15 +417,19 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       islot = (islot + 1) & (FA_NS - 1); ++inflight;
       kti = next_needed(kti + 1);
     }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) fa_settle(qf[s]);
   while (kt >= 0) {
-    if (inflight >= 3) fa_wait_vmcnt<4>();
-    else if (inflight == 2) fa_wait_vmcnt<2>();
-    else fa_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 1)) {
+      if (inflight >= 3) fa_wait_vmcnt<4>();
+      else if (inflight == 2) fa_wait_vmcnt<2>();
+      else fa_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
     __builtin_amdgcn_sched_barrier(0);
     --inflight;
     if (kti >= 0) {
-      issue(kti, islot);
+      if (!(DBG & 16)) issue(kti, islot);
       islot = (islot + 1) & (FA_NS - 1); ++inflight;
       kti = next_needed(kti + 1);
     }
@@ -408,7 +440,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       const char* vs = ks + FA_TILE;
       f32x16 sacc = zero16();
 #pragma unroll
-      for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_k(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) if (!(DBG & 8)) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_k(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
       const int k0 = kt * 32;
       uint32_t vis = 0xffffffffu;
       if (flag == 2) vis = bits[(wave * 32 + l31) * p.nkt + kt];
@@ -421,6 +453,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
         for (int r = 0; r < 16; ++r) sv[r] = vis_bit(vg, r) ? sv[r] : -INFINITY;
       }
+      if (!(DBG & 2)) {
       float mt = sv[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sv[r]);
@@ -438,6 +471,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
       }
+      }
       if (p.has_drop) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -448,6 +482,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
+        if (DBG & 4) { asm volatile("" :: "v"(pf0), "v"(pf1)); continue; }
         oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_vt(vs, db, 0, lane), pf0, oacc[db], 0, 0, 0);
         oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_vt(vs, db, 1, lane), pf1, oacc[db], 0, 0, 0);
       }
@@ -458,7 +493,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   }
   if (q_ok) {
     const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
-    store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g);
+    store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g, (p.st16 & 1) != 0);
     if (p.lse && g == 0) p.lse[rowid] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
   }
 }
@@ -594,7 +629,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
     cur ^= 1;
     kt = ktn;
   }
-  if (q_ok) store_token(p.dq + (int64_t)b * p.dqsb + (int64_t)q * p.dqst + (int64_t)h * p.dqsh, dqacc, 1.0f, g);
+  if (q_ok) store_token(p.dq + (int64_t)b * p.dqsb + (int64_t)q * p.dqst + (int64_t)h * p.dqsh, dqacc, 1.0f, g, (p.st16 & 2) != 0);
 }
 
 // ====================================================================================================
@@ -726,8 +761,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
     qt = qtn;
   }
   if (key_ok) {
-    store_token(p.dk + (int64_t)b * p.dksb + (int64_t)key_row * p.dkst + (int64_t)h * p.dksh, dkacc, 1.0f, g);
-    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, 1.0f, g);
+    store_token(p.dk + (int64_t)b * p.dksb + (int64_t)key_row * p.dkst + (int64_t)h * p.dksh, dkacc, 1.0f, g, (p.st16 & 4) != 0);
+    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, 1.0f, g, (p.st16 & 8) != 0);
   }
 }
 
@@ -770,6 +805,10 @@ int fill_args(const dvla_attn_params* q, AttnKArgs& a) {
   a.dqsb = q->dq_stride_b; a.dqst = q->dq_stride_t; a.dqsh = q->dq_stride_h;
   a.dksb = q->dk_stride_b; a.dkst = q->dk_stride_t; a.dksh = q->dk_stride_h;
   a.dvsb = q->dv_stride_b; a.dvst = q->dv_stride_t; a.dvsh = q->dv_stride_h;
+  a.st16 = (ok16(q->o, q->o_stride_b, q->o_stride_t, q->o_stride_h) ? 1 : 0) |
+           ((q->dq && ok16(q->dq, q->dq_stride_b, q->dq_stride_t, q->dq_stride_h)) ? 2 : 0) |
+           ((q->dk && ok16(q->dk, q->dk_stride_b, q->dk_stride_t, q->dk_stride_h)) ? 4 : 0) |
+           ((q->dv && ok16(q->dv, q->dv_stride_b, q->dv_stride_t, q->dv_stride_h)) ? 8 : 0);
   return DVLA_OK;
 }
 
@@ -824,6 +863,18 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
   const bf16_t* dob = p.dout + (int64_t)b * p.dsb + (int64_t)h * p.dsh;
 
+  // requested first, waited for after the first K / V tiles are on their way (see the forward kernel)
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 a = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
+    const uint4 c = load16(dob + (int64_t)q * p.dst + 16 * s + 8 * g, q_ok);
+    qf[s] = *reinterpret_cast<const bf16x8*>(&a);
+    dof[s] = *reinterpret_cast<const bf16x8*>(&c);
+  }
+  const int rowid = (b * p.H + h) * p.Lq + q;
+  float lse2 = q_ok ? p.lse[rowid] * LOG2E : INFINITY;
+  float dlt = q_ok ? p.delta[rowid] : 0.f;
   for (int kt = t; kt < p.nkt; kt += AT_THREADS) {
     int f = 0;
 #pragma unroll
@@ -838,23 +889,9 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       const int qq = qt0 * 32 + ql;
       bits[i] = qq < p.Lq ? p.bits_q[(int64_t)qq * p.nkt + kt] : 0u;
     }
-  bf16x8 qf[4], dof[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const uint4 a = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
-    const uint4 c = load16(dob + (int64_t)q * p.dst + 16 * s + 8 * g, q_ok);
-    qf[s] = *reinterpret_cast<const bf16x8*>(&a);
-    dof[s] = *reinterpret_cast<const bf16x8*>(&c);
-  }
-  const int rowid = (b * p.H + h) * p.Lq + q;
-  float lse2 = q_ok ? p.lse[rowid] * LOG2E : INFINITY;
-  float dlt = q_ok ? p.delta[rowid] : 0.f;
   uint32_t rowkey = 0;
   if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
   f32x16 dqacc[2] = {zero16(), zero16()};
-#pragma unroll
-  for (int s = 0; s < 4; ++s) { fa_settle(qf[s]); fa_settle(dof[s]); }
-  fa_settle(lse2); fa_settle(dlt);
   __syncthreads();
 
   auto next_needed = [&](int kt) -> int {
@@ -883,6 +920,9 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       islot = (islot + 1) & (FA_NS - 1); ++inflight;
       kti = next_needed(kti + 1);
     }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { fa_settle(qf[s]); fa_settle(dof[s]); }
+  fa_settle(lse2); fa_settle(dlt);
   while (kt >= 0) {
     if (inflight >= 3) fa_wait_vmcnt<4>();
     else if (inflight == 2) fa_wait_vmcnt<2>();
@@ -938,12 +978,13 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     cslot = (cslot + 1) & (FA_NS - 1);
     kt = next_needed(kt + 1);
   }
-  if (q_ok) store_token(p.dq + (int64_t)b * p.dqsb + (int64_t)q * p.dqst + (int64_t)h * p.dqsh, dqacc, 1.0f, g);
+  if (q_ok) store_token(p.dq + (int64_t)b * p.dqsb + (int64_t)q * p.dqst + (int64_t)h * p.dqsh, dqacc, 1.0f, g, (p.st16 & 2) != 0);
 }
 
 // dynamic LDS of the dK/dV ring kernel: ring | tile flags [nqt] | visibility words [128 keys][nqt] | lse2 [32 nqt] | delta [32 nqt]
+// | dropout row keys [32 nqt] (one hash per query row and workgroup instead of one per score element)
 __host__ __device__ inline size_t fa_dkv_smem_bytes(int nqt, bool has_bits) {
-  return (size_t)FA_RING + fa_pad16(nqt) + (has_bits ? (size_t)128 * nqt * 4 : 0) + (size_t)2 * 32 * nqt * 4;
+  return (size_t)FA_RING + fa_pad16(nqt) + (has_bits ? (size_t)128 * nqt * 4 : 0) + (size_t)3 * 32 * nqt * 4;
 }
 
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs p) {
@@ -968,7 +1009,17 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
   uint32_t* bits = reinterpret_cast<uint32_t*>(smem + FA_RING + fa_pad16(p.nqt));
   float* lse2s = reinterpret_cast<float*>(smem + FA_RING + fa_pad16(p.nqt) + (has_bits ? (size_t)128 * p.nqt * 4 : 0));
   float* dlts = lse2s + 32 * p.nqt;
+  uint32_t* rks = reinterpret_cast<uint32_t*>(dlts + 32 * p.nqt);
 
+  // requested first, waited for after the first Q / dO tiles are on their way (see the forward kernel)
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 a = load16(kb + (int64_t)key_row * p.kst + 16 * s + 8 * g, key_ok);
+    const uint4 c = load16(vb + (int64_t)key_row * p.vst + 16 * s + 8 * g, key_ok);
+    kf[s] = *reinterpret_cast<const bf16x8*>(&a);
+    vf[s] = *reinterpret_cast<const bf16x8*>(&c);
+  }
   for (int qt = t; qt < p.nqt; qt += AT_THREADS) {
     int f = 0;
 #pragma unroll
@@ -984,18 +1035,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
   for (int i = t; i < 32 * p.nqt; i += AT_THREADS) {
     lse2s[i] = i < p.Lq ? p.lse[bh_row0 + i] * LOG2E : INFINITY;   // q >= Lq: exp2(s - inf) = 0
     dlts[i] = i < p.Lq ? p.delta[bh_row0 + i] : 0.f;
-  }
-  bf16x8 kf[4], vf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const uint4 a = load16(kb + (int64_t)key_row * p.kst + 16 * s + 8 * g, key_ok);
-    const uint4 c = load16(vb + (int64_t)key_row * p.vst + 16 * s + 8 * g, key_ok);
-    kf[s] = *reinterpret_cast<const bf16x8*>(&a);
-    vf[s] = *reinterpret_cast<const bf16x8*>(&c);
+    if (p.has_drop) rks[i] = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + i));
   }
   f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
-#pragma unroll
-  for (int s = 0; s < 4; ++s) { fa_settle(kf[s]); fa_settle(vf[s]); }
   __syncthreads();
 
   auto next_needed = [&](int qt) -> int {
@@ -1023,6 +1065,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
       islot = (islot + 1) & (FA_NS - 1); ++inflight;
       qti = next_needed(qti + 1);
     }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { fa_settle(kf[s]); fa_settle(vf[s]); }
   while (qt >= 0) {
     if (inflight >= 3) fa_wait_vmcnt<4>();
     else if (inflight == 2) fa_wait_vmcnt<2>();
@@ -1066,17 +1110,25 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
         for (int r = 0; r < 16; ++r) pr[r] = vis_bit(vg, r) ? pr[r] : 0.f;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float dp = dpacc[r];
-        float pdrop = pr[r];
-        if (p.has_drop) {
-          const uint32_t rk = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + q0 + acc_row(r, g)));
-          const bool keep = drop_hash_rk(rk, (uint32_t)key) >= p.drop_thr;
-          dp = keep ? dp * p.inv_keep : 0.f;
-          pdrop = keep ? pdrop * p.inv_keep : 0.f;
+      for (int rq = 0; rq < 4; ++rq) {
+        uint32_t rk[4] = {0u, 0u, 0u, 0u};
+        if (p.has_drop) {      // row keys of queries q0 + 8 rq + 4 g .. + 3 (= acc_row(4 rq + e, g)), hashed once per workgroup
+          const uint4 a = *reinterpret_cast<const uint4*>(rks + q0 + 8 * rq + 4 * g);
+          rk[0] = a.x; rk[1] = a.y; rk[2] = a.z; rk[3] = a.w;
         }
-        ds[r] = pr[r] * (dp - dlt[r]) * p.scale;
-        pr[r] = pdrop;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rq + e;
+          float dp = dpacc[r];
+          float pdrop = pr[r];
+          if (p.has_drop) {
+            const bool keep = drop_hash_rk(rk[e], (uint32_t)key) >= p.drop_thr;
+            dp = keep ? dp * p.inv_keep : 0.f;
+            pdrop = keep ? pdrop * p.inv_keep : 0.f;
+          }
+          ds[r] = pr[r] * (dp - dlt[r]) * p.scale;
+          pr[r] = pdrop;
+        }
       }
       const bf16x8 pf0 = pack_frag(pr), pf1 = pack_frag(pr + 8);
       const bf16x8 sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
@@ -1093,8 +1145,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
     qt = next_needed(qt + 1);
   }
   if (key_ok) {
-    store_token(p.dk + (int64_t)b * p.dksb + (int64_t)key_row * p.dkst + (int64_t)h * p.dksh, dkacc, 1.0f, g);
-    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, 1.0f, g);
+    store_token(p.dk + (int64_t)b * p.dksb + (int64_t)key_row * p.dkst + (int64_t)h * p.dksh, dkacc, 1.0f, g, (p.st16 & 4) != 0);
+    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, 1.0f, g, (p.st16 & 8) != 0);
   }
 }
 
@@ -1114,6 +1166,9 @@ static bool attn_force_staged() {
   return v == 1;
 }
 
+// DVLA_ATTN_DBG=<bits>: ablation builds of the forward ring kernel (timing only); re-read at every launch
+static int attn_dbg() { const char* e = getenv("DVLA_ATTN_DBG"); return e ? atoi(e) : 0; }
+
 extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   AttnKArgs a;
@@ -1123,7 +1178,19 @@ extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
   const size_t smem = fa_smem_bytes(a.nkt, a.Lk, a.key_index != nullptr, a.tile_map != nullptr && a.bits_q != nullptr);
   const bool span_kv = attn_span32(a.Lk, a.kst, a.key_index != nullptr) && attn_span32(a.Lk, a.vst, a.key_index != nullptr);
   if (smem <= 64 * 1024 && span_kv && !attn_force_staged())
-    hipLaunchKernelGGL(attn_fwd_ring_kernel, grid, block, smem, stream, a);
+    switch (attn_dbg()) {
+      case 1: hipLaunchKernelGGL(attn_fwd_ring_kernel<1>, grid, block, smem, stream, a); break;
+      case 2: hipLaunchKernelGGL(attn_fwd_ring_kernel<2>, grid, block, smem, stream, a); break;
+      case 4: hipLaunchKernelGGL(attn_fwd_ring_kernel<4>, grid, block, smem, stream, a); break;
+      case 8: hipLaunchKernelGGL(attn_fwd_ring_kernel<8>, grid, block, smem, stream, a); break;
+      case 16: hipLaunchKernelGGL(attn_fwd_ring_kernel<16>, grid, block, smem, stream, a); break;
+      case 14: hipLaunchKernelGGL(attn_fwd_ring_kernel<14>, grid, block, smem, stream, a); break;
+      case 15: hipLaunchKernelGGL(attn_fwd_ring_kernel<15>, grid, block, smem, stream, a); break;
+      case 31: hipLaunchKernelGGL(attn_fwd_ring_kernel<31>, grid, block, smem, stream, a); break;
+      case 63: hipLaunchKernelGGL(attn_fwd_ring_kernel<63>, grid, block, smem, stream, a); break;
+      case 64: hipLaunchKernelGGL(attn_fwd_ring_kernel<64>, grid, block, smem, stream, a); break;
+      default: hipLaunchKernelGGL(attn_fwd_ring_kernel<0>, grid, block, smem, stream, a); break;
+    }
   else   // mask tables / key list too large for LDS
     hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, a);
   return dvla_check_launch();

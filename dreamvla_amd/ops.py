@@ -157,7 +157,7 @@ class GemmTuner:
     Every candidate is a hand-written HIP kernel of libdvla_hip.so: no vendor GEMM library is linked or offered (the
     hipBLASLt yardstick lives in libdvla_cmp.so and is driven only by tests/library_yardstick.py)."""
     CANDIDATES = tuple(int(v) for v in os.environ.get("DVLA_GEMM_CANDIDATES", "0,4,6,7,8,9,2").split(","))
-    ROUNDS = int(os.environ.get("DVLA_GEMM_TUNE_ROUNDS", "2"))
+    ROUNDS = int(os.environ.get("DVLA_GEMM_TUNE_ROUNDS", "3"))
     enabled = os.environ.get("DVLA_GEMM_AUTOTUNE", "1") != "0" and os.environ.get("DVLA_GEMM_VARIANT") is None
     table = {}      # key -> locked variant
     trials = {}     # key -> {"pending": [(variant, e0, e1)], "times": {variant: [ms]}, "next": int}
