@@ -39,9 +39,9 @@ TRAIN_GFLOP_PER_SAMPLE = {"A": 1802.0, "B": 1974.0, "C": 3485.0, "D": 2798.0, "E
 BF16_PEAK_TFLOPS = 2500.0
 
 
-def model_cfg(heads, S, layers=24):
+def model_cfg(heads, S, layers=24, phase="finetune"):
     cfg = dict(finetune_type="calvin", sequence_length=S, num_resampler_query=16, num_obs_token_per_image=9,
-               action_pred_steps=3, transformer_layers=layers, hidden_dim=1024, transformer_heads=16, phase="finetune",
+               action_pred_steps=3, transformer_layers=layers, hidden_dim=1024, transformer_heads=16, phase=phase,
                attn_implementation="sdpa")
     cfg.update(HEAD_SETS[heads])
     return cfg
@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--seq", type=int, default=7)
     ap.add_argument("--heads", default="C", choices=sorted(HEAD_SETS))
     ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--phase", default="finetune", choices=["finetune", "pretrain"],
+                    help="pretrain: the attention mask is regenerated every training step (dreamvla_model.py:610-628) -- here "
+                         "as device-side tables from the rule (SURVEY 8 f4); same shapes, for the f4 timing comparison")
     ap.add_argument("--tune-steps", type=int, default=22,
                     help="untimed steps BEFORE the warm-up in which dreamvla_amd.ops.GemmTuner tries each GEMM kernel "
                          "configuration once per problem shape and locks the fastest (setup, like building the extension); "
@@ -153,7 +156,7 @@ def main():
     ops.set_seed_salt(rank)
     BF = torch.bfloat16
     S, B = args.seq, args.batch
-    cfg = model_cfg(args.heads, S, args.layers)
+    cfg = model_cfg(args.heads, S, args.layers, args.phase)
     model = DreamVLA(clip_device="cpu", vit_checkpoint_path=None, **cfg).bfloat16()
     model.clip_model.requires_grad_(False)
     model.vision_encoder.requires_grad_(False)
@@ -303,7 +306,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "fwd_ms_per_step": fwd_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"DreamVLA CALVIN finetune step, head set {args.heads} "
+            "config": {"workload": f"DreamVLA CALVIN {args.phase} step, head set {args.heads} "
                                    f"({'+'.join(k for k in HEAD_SETS[args.heads] if HEAD_SETS[args.heads][k])}), "
                                    f"B={B}/GPU, S={S}, window {S + 3}, 2x224^2 views, 77 text tokens, hidden 1024 / "
                                    f"{args.layers} layers / 16 heads, dropout 0.1 on, AdamW + clip 0.1",
