@@ -124,6 +124,9 @@ def main():
                     help="untimed steps BEFORE the warm-up in which dreamvla_amd.ops.GemmTuner tries each GEMM kernel "
                          "configuration once per problem shape and locks the fastest (setup, like building the extension); "
                          "seven candidates x GemmTuner.ROUNDS (3) trials (median): shapes that occur once per step need 22 steps to lock")
+    ap.add_argument("--torch-profile", default=None, metavar="FILE",
+                    help="diagnostics: after the timed region, one more step under torch.profiler; ATen / autograd operators by "
+                         "device time (with input shapes) are written to FILE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true",
@@ -236,6 +239,15 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     loss_val = float(last.detach())
+
+    if args.torch_profile and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        with open(args.torch_profile, "w") as fh:
+            fh.write(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60,
+                                                                         max_name_column_width=60, max_shapes_column_width=90))
 
     # forward-only latency (train mode, autograd graph recorded, no backward)
     fwd_ms = None

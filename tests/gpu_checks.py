@@ -437,6 +437,11 @@ def all_checks(quick=False):
         (check_self_attention, dict(B=2, H=3, L=197)),
         (check_self_attention, dict(B=3, H=2, L=6)),
         (check_self_attention, dict(B=1, H=2, L=265)),
+        # the packed path of ops.self_attention (short sequences under a block-diagonal mask): the DiT head's shape class
+        # (L = 6: 16 sequences per 96-token pack), a length that does not divide 32 and a batch that forces a smaller pack
+        (check_self_attention, dict(B=224, H=12, L=6)),
+        (check_self_attention, dict(B=130, H=2, L=11, seed=3)),
+        (check_self_attention, dict(B=64, H=3, L=16, seed=4)),
         (check_self_attention, dict(B=2, H=2, L=133, mask_kind="block")),
         (check_self_attention, dict(B=1, H=4, L=399, mask_kind="block")),
         (check_self_attention, dict(B=2, H=2, L=77, mask_kind="causal")),
