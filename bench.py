@@ -246,7 +246,7 @@ def main():
             step()
             torch.cuda.synchronize()
         with open(args.torch_profile, "w") as fh:
-            fh.write(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60,
+            fh.write(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=300,
                                                                          max_name_column_width=60, max_shapes_column_width=90))
 
     # forward-only latency (train mode, autograd graph recorded, no backward)
