@@ -284,7 +284,7 @@ def main():
             traffic_src = {"source": t.get("source"), "measured_on_commit": t.get("commit"),
                            "algorithmic_bytes_per_launch": t.get("algorithmic_bytes_per_launch")}
         roofline = {"bound": "mfma",
-                    "kernel": "gemm_ring_kernel + gemm_kernel (hand-written bf16 MFMA 32x32x16; every GEMM launch of one training step)",
+                    "kernel": "gemm_phase_kernel + gemm_ring_kernel + gemm_kernel (hand-written bf16 MFMA 32x32x16; every GEMM launch of one training step)",
                     "achieved": r["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": r["tflops"] / BF16_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "launches": r["launches"], "avg_launch_us": r["avg_us"],
                     "gflop_per_launch": r["gflop_per_launch"], "gemm_ms_per_step": r["total_ms"],
