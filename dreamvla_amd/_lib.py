@@ -80,6 +80,7 @@ SYMBOLS = {
     "dvla_abi_version": (C.c_int, []),
     "dvla_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), _P]),
     "dvla_set_gemm_variant": (None, [C.c_int]),
+    "dvla_set_gemm_schedule": (None, [C.c_int, C.c_int]),
     "dvla_layernorm_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I64, _I64, _F, _P]),
     "dvla_layernorm_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "dvla_layernorm_bwd_add": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _P]),

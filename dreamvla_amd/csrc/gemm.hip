@@ -131,10 +131,10 @@ struct SkScratch { int dev; hipStream_t stream; float* slabs; unsigned* flags; i
 static SkScratch g_sk[16];
 static int g_sk_n = 0;
 static std::mutex g_sk_mu;
+static int g_streamk = -1;   // -1: read DVLA_GEMM_STREAMK at first use; dvla_set_gemm_schedule overrides
 static bool streamk_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DVLA_GEMM_STREAMK"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
+  if (g_streamk < 0) { const char* e = getenv("DVLA_GEMM_STREAMK"); g_streamk = (e && e[0] == '0') ? 0 : 1; }
+  return g_streamk == 1;
 }
 static bool sk_scratch(hipStream_t stream, int groups, float** slabs, unsigned** flags) {
   if (!streamk_enabled()) return false;
@@ -201,6 +201,10 @@ inline double fill(int64_t tiles, int64_t slots) {
 }  // namespace
 
 extern "C" void dvla_set_gemm_variant(int v) { g_gemm_variant = v; }
+extern "C" void dvla_set_gemm_schedule(int oversubscribe, int stream_k) {
+  if (oversubscribe >= 1) dvla_gemm::gemm_oversubscribe() = oversubscribe > 16 ? 16 : oversubscribe;
+  if (stream_k >= 0) g_streamk = stream_k ? 1 : 0;
+}
 
 extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

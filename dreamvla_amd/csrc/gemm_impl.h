@@ -1054,6 +1054,25 @@ void gemm_ring_kernel(GemmKArgs p) {
   }
 }
 
+// Workgroups per CU slot of the persistent kernels (plain schedule).  1 = one workgroup per slot walks its share of the
+// tiles (best on an otherwise idle GPU: every prologue but the first hides under the previous tile's epilogue).  k > 1 =
+// k times as many, shorter-lived workgroups handed out by the hardware dispatcher as slots free up: when a kernel on another
+// stream (an RCCL collective during the backward pass) holds some CUs, a static share per CU makes the whole launch wait for
+// the workgroups that could not start -- measured 1.7x for 16 of 256 CUs taken (profiles/r02_gemm_cu_contention.txt).
+inline int& gemm_oversubscribe() {
+  static int k = [] { const char* e = getenv("DVLA_GEMM_OVERSUBSCRIBE"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+  return k;
+}
+
+// workgroups of a persistent launch over `items` work items on `slots` co-resident workgroup slots: one per slot, or (over-
+// subscription k > 1) up to k per slot with EQUAL item counts (ceil(items / (k slots)) items each, no ragged second wave)
+inline int64_t persistent_grid(int64_t items, int64_t slots) {
+  const int k = gemm_oversubscribe();
+  if (k <= 1 || items <= slots) return items < slots ? items : slots;
+  const int64_t per = (items + k * slots - 1) / (k * slots);
+  return (items + per - 1) / per;
+}
+
 inline int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1086,8 +1105,7 @@ void launch_ring_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
     attr_set = true;
   }
   const int64_t items = (int64_t)a.tiles_m * a.tiles_n * split_k;
-  const int64_t slots = (int64_t)num_cus() * RC::WG_PER_CU;
-  dim3 grid((unsigned)(items < slots ? items : slots), 1, 1), block(RC::NT, 1, 1);
+  dim3 grid((unsigned)persistent_grid(items, (int64_t)num_cus() * RC::WG_PER_CU), 1, 1), block(RC::NT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, RC::SMEM_BYTES, stream, a);
 }
 

@@ -404,7 +404,8 @@ void launch_phase_one(const GemmKArgs& a, int split_k, hipStream_t stream) {
   }
   const int64_t items = (int64_t)a.tiles_m * a.tiles_n * split_k;
   const int64_t slots = (int64_t)num_cus();
-  dim3 grid((unsigned)(items < slots ? items : slots), 1, 1), block(PCfg::NT, 1, 1);
+  const int64_t nwg = a.sk_tiles > 0 ? slots : persistent_grid(items, slots);   // stream-K: exactly one workgroup per CU
+  dim3 grid((unsigned)nwg, 1, 1), block(PCfg::NT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, PCfg::SMEM_BYTES, stream, a);
 }
 

@@ -73,6 +73,16 @@ int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
  * Stream-K scratch: 64 MiB + flags per (device, stream), hipMalloc'ed on the first launch that uses it (never while the
  * stream is being captured -- such launches take the plain schedule) and kept; DVLA_GEMM_STREAMK=0 turns the schedule off. */
 void dvla_set_gemm_variant(int variant);
+/* How the persistent kernels spread tiles over the CUs (process-wide; env DVLA_GEMM_OVERSUBSCRIBE / DVLA_GEMM_STREAMK at load).
+ *   oversubscribe = 1 (default): one workgroup per CU slot walks a fixed share of the tiles; the stream-K schedule may apply.
+ *     Fastest on a GPU that runs nothing else (the default bench: 165 ms / step against 176 with k = 8).
+ *   oversubscribe = k > 1: up to k times as many, shorter-lived workgroups with equal tile counts, handed out by the hardware
+ *     dispatcher as slots free up.  For callers whose GEMMs run for long stretches next to another stream's kernel that holds
+ *     CUs: with a fixed share per CU a launch waits for the workgroups that could not start (measured +65 % per launch for
+ *     16 of 256 CUs taken; k = 8: +0 ... +9 %; profiles/r02_gemm_cu_contention.txt).  The data-parallel path keeps k = 1: its
+ *     bucket all-reduces (0.99 GB per step) occupy CUs for a few milliseconds of a 165-ms step.
+ *   stream_k = 0 / 1: forbid / allow the stream-K schedule (needs every workgroup co-resident); -1 / oversubscribe < 1: keep. */
+void dvla_set_gemm_schedule(int oversubscribe, int stream_k);
 
 /* ---------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (rows x cols, bf16 in/out, fp32 statistics).

@@ -146,6 +146,15 @@ static std::vector<int> parse_list(const char* s) {
 }
 
 // returns {max rel err (vs |ref| + atol scale), fraction of elements off by > tol}
+// --hog N: N workgroups that each take a whole CU's LDS and spin for `cycles` -- what a communication kernel on another
+// stream does to the persistent GEMM schedules (a CU it sits on cannot host a 160-KiB workgroup)
+__global__ void hog_kernel(long long cycles, int* sink) {
+  extern __shared__ char hog_smem[];
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+  while ((long long)__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(16);
+  if (cycles < 0) sink[0] = hog_smem[threadIdx.x];
+}
+
 static void check_variant(const Case& c, int variant, int64_t Mchk) {
   Problem q = make_problem(c, Mchk);
   const int64_t MN = Mchk * c.N;
@@ -195,6 +204,7 @@ int main(int argc, char** argv) {
   std::vector<int> variants = {0, 2, 4, 5, 6};
   int iters = 7, rounds = 3; bool check_only = false, no_check = false, full_check = false, stamps = false; int64_t stamps_k = 1024; std::string which = "model";
   std::vector<int> stamp_variants = {89};
+  int hog = 0;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--variants") && i + 1 < argc) variants = parse_list(argv[++i]);
     else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
@@ -204,6 +214,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--full-check")) full_check = true;   // additionally: every variant at the case's FULL size, twice
     else if (!strcmp(argv[i], "--stamps")) { stamps = true; if (i + 1 < argc && argv[i + 1][0] != '-') stamps_k = atoll(argv[++i]); }
     else if (!strcmp(argv[i], "--stamp-variants") && i + 1 < argc) stamp_variants = parse_list(argv[++i]);
+    else if (!strcmp(argv[i], "--hog") && i + 1 < argc) hog = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--cases") && i + 1 < argc) which = argv[++i];
   }
   if (stamps) {   // timeline of the phase kernel (variants 89 / 97 / 98): s_memtime at the 8 segment edges of the first 32 K-tiles, waves 0 and 4
@@ -305,6 +316,14 @@ int main(int argc, char** argv) {
       for (size_t vi = 0; vi < variants.size(); ++vi) {
         dvla_set_gemm_variant(variants[vi]);
         (void)dvla_gemm_bf16(&q.p, nullptr);   // warm
+        if (hog > 0) {   // occupy `hog` CUs on another stream for ~4 ms while the GEMMs run
+          static hipStream_t hs = nullptr; static int* sink = nullptr;
+          if (!hs) { CK(hipStreamCreateWithFlags(&hs, hipStreamNonBlocking)); CK(hipMalloc(&sink, 64));
+                     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(hog_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); }
+          CK(hipDeviceSynchronize());
+          hipLaunchKernelGGL(hog_kernel, dim3(hog), dim3(256), 96 * 1024, hs, 8000000LL, sink);
+          CK(hipStreamQuery(hs) == hipErrorNotReady ? hipSuccess : hipSuccess);
+        }
         CK(hipEventRecord(e0, 0));
         for (int it = 0; it < iters; ++it) (void)dvla_gemm_bf16(&q.p, nullptr);
         CK(hipEventRecord(e1, 0));
