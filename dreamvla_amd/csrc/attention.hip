@@ -47,6 +47,7 @@ struct AttnKArgs {
   bf16_t *dq, *dk, *dv;
   int64_t dqsb, dqst, dqsh, dksb, dkst, dksh, dvsb, dvst, dvsh;
   int st16;   // bit 0 / 1 / 2 / 3: o / dq / dk / dv rows are 16-byte aligned (16-byte output stores)
+  int fuse_delta;   // the dQ ring kernel computes and writes delta itself (no attn_delta_kernel launch)
 };
 
 // accumulator register r of lane group g  <->  row index inside the 32-row MFMA tile
@@ -805,6 +806,7 @@ int fill_args(const dvla_attn_params* q, AttnKArgs& a) {
   a.dqsb = q->dq_stride_b; a.dqst = q->dq_stride_t; a.dqsh = q->dq_stride_h;
   a.dksb = q->dk_stride_b; a.dkst = q->dk_stride_t; a.dksh = q->dk_stride_h;
   a.dvsb = q->dv_stride_b; a.dvst = q->dv_stride_t; a.dvsh = q->dv_stride_h;
+  a.fuse_delta = 0;
   a.st16 = (ok16(q->o, q->o_stride_b, q->o_stride_t, q->o_stride_h) ? 1 : 0) |
            ((q->dq && ok16(q->dq, q->dq_stride_b, q->dq_stride_t, q->dq_stride_h)) ? 2 : 0) |
            ((q->dk && ok16(q->dk, q->dk_stride_b, q->dk_stride_t, q->dk_stride_h)) ? 4 : 0) |
@@ -874,7 +876,29 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   }
   const int rowid = (b * p.H + h) * p.Lq + q;
   float lse2 = q_ok ? p.lse[rowid] * LOG2E : INFINITY;
-  float dlt = q_ok ? p.delta[rowid] : 0.f;
+  float dlt;
+  if (p.fuse_delta) {
+    // delta = rowsum(dO * O) computed here from the dO fragment already in registers and the matching O fragment (the two
+    // half-waves hold the two halves of the row), written out for the dK/dV kernel: the separate delta launch is gone
+    const bf16_t* ob = p.o + (int64_t)b * p.osb + (int64_t)h * p.osh;
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 ov = load16(ob + (int64_t)q * p.ost + 16 * s + 8 * g, q_ok);
+      const uint4 dv = *reinterpret_cast<const uint4*>(&dof[s]);
+      const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc += bf2f((bf16_t)(dw[i] & 0xffff)) * bf2f((bf16_t)(ow[i] & 0xffff));
+        acc += bf2f((bf16_t)(dw[i] >> 16)) * bf2f((bf16_t)(ow[i] >> 16));
+      }
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    dlt = q_ok ? acc : 0.f;
+    if (q_ok && g == 0) p.delta[rowid] = acc;
+  } else {
+    dlt = q_ok ? p.delta[rowid] : 0.f;
+  }
   for (int kt = t; kt < p.nkt; kt += AT_THREADS) {
     int f = 0;
 #pragma unroll
@@ -1211,9 +1235,6 @@ extern "C" int dvla_attn_bwd(const dvla_attn_params* q, void* stream_) {
       !ok8(q->dv, q->dv_stride_b, q->dv_stride_t, q->dv_stride_h) || !ok16(q->o, q->o_stride_b, q->o_stride_t, q->o_stride_h))
     return DVLA_ERR_UNSUPPORTED;
   const int64_t nrows = (int64_t)a.B * a.H * a.Lq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows * 8 + 255) / 256)), dim3(256), 0, stream, a);
-  rc = dvla_check_launch();
-  if (rc != DVLA_OK) return rc;
   dim3 block(AT_THREADS);
   const size_t smem_dq = fa_smem_bytes(a.nkt, a.Lk, a.key_index != nullptr, a.tile_map != nullptr && a.bits_q != nullptr);
   const size_t smem_dkv = fa_dkv_smem_bytes(a.nqt, a.tile_map != nullptr && a.bits_k != nullptr);
@@ -1221,7 +1242,14 @@ extern "C" int dvla_attn_bwd(const dvla_attn_params* q, void* stream_) {
   const dim3 grid_dkv((unsigned)((a.nkt + 3) / 4), (unsigned)a.H, (unsigned)a.B);
   const bool span_kv = attn_span32(a.Lk, a.kst, a.key_index != nullptr) && attn_span32(a.Lk, a.vst, a.key_index != nullptr);
   const bool span_q = attn_span32(a.Lq, a.qst, false) && attn_span32(a.Lq, a.dst, false);
-  if (smem_dq <= 64 * 1024 && span_kv && !attn_force_staged())
+  const bool dq_ring = smem_dq <= 64 * 1024 && span_kv && !attn_force_staged();
+  a.fuse_delta = dq_ring ? 1 : 0;     // the dQ ring kernel covers every query row: it computes delta on its way
+  if (!dq_ring) {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows * 8 + 255) / 256)), dim3(256), 0, stream, a);
+    rc = dvla_check_launch();
+    if (rc != DVLA_OK) return rc;
+  }
+  if (dq_ring)
     hipLaunchKernelGGL(attn_bwd_dq_ring_kernel, grid_dq, block, smem_dq, stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid_dq, block, 0, stream, a);
