@@ -447,6 +447,7 @@ def build_mask_tables(mask, device=None, compact_keys=True, key_order=None):
         if len(cols) < Lk_full or bool((cols != np.arange(Lk_full)).any()):
             key_index = torch.from_numpy(cols.astype(np.int32)).to(device)
             vis = vis[:, cols]
+        dead = np.setdiff1d(np.arange(Lk_full), cols)
     Lk = vis.shape[1]
     nqt, nkt = (Lq + 31) // 32, (Lk + 31) // 32
     vp = np.zeros((nqt * 32, nkt * 32), dtype=bool)
@@ -462,8 +463,11 @@ def build_mask_tables(mask, device=None, compact_keys=True, key_order=None):
     tile_map[t_vis == t_val] = 1
     tile_map[t_vis == 0] = 0
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32) if a.dtype == np.uint32 else np.ascontiguousarray(a)).to(device)
-    return MaskTables(Lq, Lk_full, Lk, key_index, to_dev(bits_q), to_dev(bits_k), to_dev(tile_map),
-                      float(vis.mean()))
+    mt = MaskTables(Lq, Lk_full, Lk, key_index, to_dev(bits_q), to_dev(bits_k), to_dev(tile_map), float(vis.mean()))
+    if compact_keys and key_index is not None:
+        # key rows nobody sees: the backward kernels do not write their dk / dv -- the caller zero-fills exactly these rows
+        mt.dead_keys = torch.from_numpy(dead.astype(np.int64)).to(device)
+    return mt
 
 
 def draw_mask_drop(K, num_obs_token, action_pred_steps, atten_only_obs, mask_l_obs_ratio):
@@ -937,7 +941,13 @@ class _SelfAttention(torch.autograd.Function):
         H, mt = ctx.H, ctx.mt
         v5 = qkv.view(B, L, 3, H, 64)
         # with a compacted key axis the kernel leaves dk/dv rows of never-visible keys untouched -> zeros
-        dqkv = torch.zeros_like(qkv) if (mt is not None and mt.key_index is not None) else torch.empty_like(qkv)
+        dead = getattr(mt, "dead_keys", None) if mt is not None else None
+        if mt is not None and mt.key_index is not None and dead is None:
+            dqkv = torch.zeros_like(qkv)             # tables built on the device: the unnamed rows are not listed
+        else:
+            dqkv = torch.empty_like(qkv)
+            if dead is not None and dead.numel():
+                dqkv.view(B, L, 3, H * 64)[:, dead, 1:] = 0   # dk / dv of the never-visible keys (a few rows, not the buffer)
         d5 = dqkv.view(B, L, 3, H, 64)
         do = _req(dout, "attention.grad_output").contiguous().view(B, L, H, 64)
         attn_bwd_raw(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], o, lse, do, d5[:, :, 0], d5[:, :, 1], d5[:, :, 2],
