@@ -773,6 +773,37 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
   // Store-layout operand vectors (EPI_AUX): requested per BATCH of JB = 2 row slabs (8 vectors = 32 VGPRs per lane) before
   // that batch's first store.  A 128-row wave block (TM = 4) therefore has ONE point per tile where loads follow stores
   // (all 16 vectors at once = 64 VGPRs next to the 128 accumulators made hipcc spill ~100 registers).
+  // The bias of the wave's 64 columns is loaded ONCE per tile, before the first store: a load issued after stores can only be
+  // waited for together with them (one in-order counter), and re-loading it per (row batch, column group) made three of
+  // the four s_waitcnt per tile drain every store issued so far.
+  float bias_f[2][4][4];
+  auto load_bias = [&](auto ic) {     // column group i of the wave's 64 columns -> fp32, settled at once (the compiler would
+    constexpr int i = decltype(ic)::value;   // otherwise wait at every use site, in the middle of the store sequence)
+    if (p.bias_f32) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
+        bias_f[i][rq][0] = b.x; bias_f[i][rq][1] = b.y; bias_f[i][rq][2] = b.z; bias_f[i][rq][3] = b.w;
+      }
+    } else {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
+        unpack2(b.x, bias_f[i][rq][0], bias_f[i][rq][1]); unpack2(b.y, bias_f[i][rq][2], bias_f[i][rq][3]);
+      }
+    }
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(bias_f[i][rq][e]));
+  };
+  // classes without store-layout operands have the registers to hold both column groups: ONE load point per tile, before the
+  // first store (a load issued after stores can only be waited for together with them: re-loading per (row batch, column
+  // group) made three of four waits per tile drain every store issued so far).  The others load per column group.
+  constexpr bool BIAS_ONCE = EPI == EPI_P0 || EPI == EPI_P_ERF || EPI == EPI_P_TANH || EPI == EPI_F32;
+  if constexpr (BIAS_ONCE) {
+    if (has_bias) { static_for<2>([&](auto ic) { load_bias(ic); }); }
+  }
   constexpr int JB = TM < 2 ? TM : 2, NB = TM / JB;
   static_for<NB>([&](auto bc) {
   constexpr int jb0 = decltype(bc)::value * JB;
@@ -797,21 +828,8 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
   // conversion work of the block to the top and spilling next to the 128 accumulators).
   static_for<2>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    uint32_t bias_pk[4][2];
-    if (has_bias && !p.bias_f32) {
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
-        bias_pk[rq][0] = b.x; bias_pk[rq][1] = b.y;
-      }
-    }
-    float bias_f[4][4];
-    if (has_bias && p.bias_f32) {
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
-        bias_f[rq][0] = b.x; bias_f[rq][1] = b.y; bias_f[rq][2] = b.z; bias_f[rq][3] = b.w;
-      }
+    if constexpr (!BIAS_ONCE) {
+      if (has_bias) load_bias(ic);
     }
     static_for<JB>([&](auto jc) {
       constexpr int j = jb0 + decltype(jc)::value;
@@ -825,14 +843,8 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = acc[i][j][4 * rq + e];
         if (has_bias) {
-          if (p.bias_f32) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z[e] += bias_f[rq][e];
-          } else {
-            float b0, b1, b2, b3;
-            unpack2(bias_pk[rq][0], b0, b1); unpack2(bias_pk[rq][1], b2, b3);
-            z[0] += b0; z[1] += b1; z[2] += b2; z[3] += b3;
-          }
+          for (int e = 0; e < 4; ++e) z[e] += bias_f[i][rq][e];
         }
       };
       auto act_drop = [&](int rq, float (&z)[4]) {
