@@ -123,8 +123,8 @@ static Problem make_problem(const Case& c, int64_t M) {
   if (c.epi == "gelu_erf") { need_bias(); p.act = 1; }
   if (c.epi == "relu") { need_bias(); p.act = 3; }
   if (c.epi == "silu_res") { need_bias(); p.act = 4; q.res = dalloc((size_t)M * N * 2); fill(q.res, 4u, 1.0f); p.residual = q.res.p; p.ld_res = N; }
-  if (c.epi == "gelu_tanh_preact" || c.epi == "gelu_erf_preact") {
-    need_bias(); p.act = c.epi == "gelu_tanh_preact" ? 2 : 1;
+  if (c.epi == "gelu_tanh_preact" || c.epi == "gelu_erf_preact" || c.epi == "none_preact" || c.epi == "relu_preact") {
+    need_bias(); p.act = c.epi == "gelu_tanh_preact" ? 2 : (c.epi == "gelu_erf_preact" ? 1 : (c.epi == "relu_preact" ? 3 : 0));
     q.preact = dalloc((size_t)M * N * 2); p.preact = q.preact.p; p.ld_preact = N;
   }
   if (c.epi == "drop_res" || c.epi == "res") {
@@ -276,6 +276,18 @@ int main(int argc, char** argv) {
       {"NT fused K64", 20832, 4096, 64, 0, 0, "gelu_tanh_preact", 1},
       {"NT fused", 20832, 4096, 1024, 0, 0, "gelu_tanh_preact", 1},
       {"square", 8192, 8192, 8192, 0, 0, "plain", 1},
+    };
+  } else if (which == "epi") {   // what a fused epilogue costs, part by part: one store / two stores / two stores + cheap / GELU math
+    cases = {
+      {"one store", 20832, 4096, 1024, 0, 0, "bias", 1},
+      {"two stores", 20832, 4096, 1024, 0, 0, "none_preact", 1},
+      {"two stores + relu", 20832, 4096, 1024, 0, 0, "relu_preact", 1},
+      {"two stores + tanh-GELU", 20832, 4096, 1024, 0, 0, "gelu_tanh_preact", 1},
+      {"two stores + erf-GELU", 20832, 4096, 1024, 0, 0, "gelu_erf_preact", 1},
+      {"one store + erf-GELU", 20832, 4096, 1024, 0, 0, "gelu_erf", 1},
+      {"one store K64", 20832, 4096, 64, 0, 0, "bias", 1},
+      {"two stores K64", 20832, 4096, 64, 0, 0, "none_preact", 1},
+      {"two stores + tanh-GELU K64", 20832, 4096, 64, 0, 0, "gelu_tanh_preact", 1},
     };
   } else if (which == "small") {
     cases = {
