@@ -7,11 +7,14 @@
 //   16-byte-vectorisable operands: the dispatcher checks (ring_ok<PCfg>), other layouts stay with the phase / ring kernels.
 // One tile per workgroup (the hardware dispatcher balances; XCD-contiguous tile runs as in gemm_kernel).
 //
-// STATUS (round 2): NOT part of the build -- a starting point for the next round.  Correct (18 probe checks as variant 94), but
-// hipcc (ROCm 7.2) spills the eight staging registers of every global load to scratch right after the load (s_waitcnt +
-// scratch_store per load inside the K loop) although the loop needs ~130 of the 256 VGPRs next to the 256 AGPR accumulators:
-// 272 TFLOP/s at 20832 x 4096 x 1024 against 934 for the phase kernel.  The structure needs its loop written at the
-// instruction level (inline asm for the load / ds_write / MFMA interleave), as the vendor's kernels are.
+// STATUS (round 2): NOT part of the build -- a starting point for the next round.  Correct (18 probe checks as variant 94).
+//   first form (HIP uint4 staging arrays indexed from `#pragma unroll` loops): the arrays stay stack objects -- a scratch store
+//     behind every global load inside the K loop: 272 TFLOP/s at 20832 x 4096 x 1024;
+//   this form (ext-vector staging registers, static_for, half a K-tile of fragments read before its 32 MFMAs; no scratch in the
+//     loop, 140 VGPRs + 256 AGPRs): 711 TFLOP/s there, 870 at K = 2048, 1042 at 8192^3 (phase kernel: 890 / 1088 / 1249);
+//   with fragment double-buffering across the barrier and a whole K-tile of staging in flight: 663 / 807 / 977 -- slower.
+// The compiler-scheduled loop leaves LDS-read latency, the ds_write burst and the barrier between the MFMA groups; the
+// structure needs its loop written at the instruction level, as the vendor's kernels are.
 // To try it: #include it from csrc/gemm.hip (path "../../tests/probes/experimental/gemm_quad.h"), instantiate
 // launch_quad_one<EPI> and route a variant number to it.
 #pragma once
@@ -53,33 +56,30 @@ void gemm_quad_kernel(GemmKArgs p) {
   // row: their products land in output rows / columns the epilogue never stores).
   const int r = t >> 3, oct = t & 7;
   uint32_t offa[NCH], offb[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
+  static_for<NCH>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
     int64_t ra = m0 + r + 32 * i; ra = ra < p.M ? ra : p.M - 1;
     int64_t rb = n0 + r + 32 * i; rb = rb < p.N ? rb : p.N - 1;
     offa[i] = (uint32_t)(((ra - m0) * p.lda + oct * 8) * 2);
     offb[i] = (uint32_t)(((rb - n0) * p.ldb + oct * 8) * 2);
-  }
+  });
   const char* baseA = reinterpret_cast<const char*>(p.A + m0 * p.lda + w.k_begin);
   const char* baseB = reinterpret_cast<const char*>(p.B + n0 * p.ldb + w.k_begin);
   int lds_st[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) lds_st[i] = rm_off(r + 32 * i, oct);
+  static_for<NCH>([&](auto ic) { constexpr int i = decltype(ic)::value; lds_st[i] = rm_off(r + 32 * i, oct); });
 
-  uint4 st[NCH];     // one operand's 8 chunks at a time: A rides through the first half of the multiply, B through the second
+  u32x4 st[NCH];     // one operand's 8 chunks at a time (ext-vector type + static_for: HIP's uint4 struct array indexed from a
+                     // `#pragma unroll` loop stays a stack object -- scratch traffic inside the K loop, 272 TFLOP/s): A rides through the first half of the multiply, B through the second
   auto gloadA = [&]() {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) st[i] = *reinterpret_cast<const uint4*>(baseA + offa[i]);
+    static_for<NCH>([&](auto ic) { constexpr int i = decltype(ic)::value; st[i] = *reinterpret_cast<const u32x4*>(baseA + offa[i]); });
     baseA += BK * 2;
   };
   auto gloadB = [&]() {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) st[i] = *reinterpret_cast<const uint4*>(baseB + offb[i]);
+    static_for<NCH>([&](auto ic) { constexpr int i = decltype(ic)::value; st[i] = *reinterpret_cast<const u32x4*>(baseB + offb[i]); });
     baseB += BK * 2;
   };
   auto lstore = [&](char* img) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) *reinterpret_cast<uint4*>(img + lds_st[i]) = st[i];
+    static_for<NCH>([&](auto ic) { constexpr int i = decltype(ic)::value; *reinterpret_cast<u32x4*>(img + lds_st[i]) = st[i]; });
   };
 
   f32x16 acc[4][4];   // [n-subtile i][m-subtile j]
