@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvla_hip.so")
 
 DT_BF16, DT_F32 = 0, 1
+ABI_VERSION = 3          # DVLA_ABI_VERSION of include/dvla.h
 ACT = {"none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "gelu_new": 2, "relu": 3, "silu": 4,
        "quick_gelu": 5, "tanh": 6, "sigmoid": 7}
 
@@ -80,6 +81,7 @@ SYMBOLS = {
     "dvla_abi_version": (C.c_int, []),
     "dvla_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), _P]),
     "dvla_set_gemm_variant": (None, [C.c_int]),
+    "dvla_last_gemm_variant": (C.c_int, []),
     "dvla_set_gemm_schedule": (None, [C.c_int, C.c_int]),
     "dvla_layernorm_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I64, _I64, _F, _P]),
     "dvla_layernorm_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
@@ -125,6 +127,14 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (hipcc --offload-arch=gfx950) from the repo root. There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    try:
+        lib.dvla_abi_version.restype = C.c_int
+        got = lib.dvla_abi_version()
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise DvlaError(f"{LIB_PATH} reports ABI version {got}, this package binds version {ABI_VERSION}: the library is stale. "
+                        f"Rebuild it (`python -c 'import __graft_entry__ as g; g.build(force=True)'`).")
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res

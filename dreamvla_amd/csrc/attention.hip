@@ -232,7 +232,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
 #pragma unroll
       for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sv[r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run, mt * scale_log2);
+      // the running maximum is kept as an INTEGER in the log2 domain (rounded up): every rescale factor alpha is then an exact
+      // power of two, so the bf16 rounding of P commutes with it -- O = sum_j bf16(2^(s_j - M)) v_j / sum_j 2^(s_j - M) whatever
+      // the tile order or the intermediate maxima, which is what lets oracle/torch_ref.py::attention_bf16 restate the kernel's
+      // arithmetic exactly (same two rounding points: P and dS) instead of waving a 3e-3 tolerance through
+      const float m_new = fmaxf(m_run, ceilf(mt * scale_log2));
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = fast_exp2(m_run - m_safe);
       float rs = 0.f;
@@ -459,7 +463,11 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
       for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sv[r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run, mt * scale_log2);
+      // the running maximum is kept as an INTEGER in the log2 domain (rounded up): every rescale factor alpha is then an exact
+      // power of two, so the bf16 rounding of P commutes with it -- O = sum_j bf16(2^(s_j - M)) v_j / sum_j 2^(s_j - M) whatever
+      // the tile order or the intermediate maxima, which is what lets oracle/torch_ref.py::attention_bf16 restate the kernel's
+      // arithmetic exactly (same two rounding points: P and dS) instead of waving a 3e-3 tolerance through
+      const float m_new = fmaxf(m_run, ceilf(mt * scale_log2));
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = fast_exp2(m_run - m_safe);
       float rs = 0.f;

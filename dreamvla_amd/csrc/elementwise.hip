@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmArgs a) {
 
 }  // namespace
 
-extern "C" int dvla_abi_version(void) { return 1; }
+extern "C" int dvla_abi_version(void) { return DVLA_ABI_VERSION; }
 extern "C" int64_t dvla_colsum_partial_rows(void) { return CS_BLOCKS; }
 
 extern "C" int dvla_colsum_dt(const void* x, int64_t ld, int64_t rows, int64_t cols, void* out, int32_t out_dtype,

@@ -158,20 +158,26 @@ static bool sk_scratch(hipStream_t stream, int groups, float** slabs, unsigned**
 // SUPER-tiles (16 consecutive tile ids each) the stream-K part of the hybrid schedule covers: what is left beyond whole
 // rounds, plus one round (so that a group's range is at least one super-tile long and a tile is shared by at most two
 // workgroups); 0 = the plain schedule is already even / the problem is smaller than one round / odd CU count
-inline int streamk_tiles(int64_t tiles, int cus) {
+// full = true ("full stream-K", variant 10): EVERY super-tile is part of the K-iteration ranges.  Same number of shared tiles
+// (one per group boundary), but the ranges of different groups now cross tile boundaries at different times for the whole
+// launch: the epilogues (an HBM write burst of 128-256 KiB per CU that the plain rounds issue from all 256 CUs at once)
+// spread out under the other groups' main loops.
+inline int streamk_tiles(int64_t tiles, int cus, bool full = false) {
   if (cus % 16 != 0) return 0;
   const int64_t groups = cus / 16, st = (tiles + 15) / 16;
   if (st < groups || st % groups == 0) return 0;
+  if (full) return (int)st;
   const int64_t dp_rounds = st / groups - 1;
   return (int)(st - dp_rounds * groups);
 }
-void launch_phase(GemmKArgs& a, int combo, int split_k, hipStream_t stream, bool stream_k = false) {
+// stream_k: 0 = plain schedule, 1 = hybrid (partial rounds only), 2 = full
+void launch_phase(GemmKArgs& a, int combo, int split_k, hipStream_t stream, int stream_k = 0) {
   a.tiles_m = (int)((a.M + PCfg::BM - 1) / PCfg::BM);
   a.tiles_n = (int)((a.N + PCfg::BN - 1) / PCfg::BN);
   a.sk_tiles = 0;
   if (stream_k && split_k == 1) {
     const int groups = num_cus();
-    const int r = streamk_tiles((int64_t)a.tiles_m * a.tiles_n, groups);
+    const int r = streamk_tiles((int64_t)a.tiles_m * a.tiles_n, groups, stream_k == 2);
     if (r > 0 && sk_scratch(stream, groups, &a.sk_slabs, &a.sk_flags)) a.sk_tiles = r;
   }
   switch (combo) {
@@ -200,6 +206,11 @@ inline double fill(int64_t tiles, int64_t slots) {
 
 }  // namespace
 
+// what the last dvla_gemm_bf16 call of this process actually launched (tests assert that a forced configuration ran and did
+// not fall back): 2 register-staged, 4 / 6 / 7 ring 256^2 / 128^2 / 256x128, 8 phase (plain schedule), 9 / 10 phase with the
+// stream-K hybrid / full schedule ENGAGED (a stream-K request that does not apply reports 8); 0 = nothing launched yet
+static int g_last_variant = 0;
+extern "C" int dvla_last_gemm_variant(void) { return g_last_variant; }
 extern "C" void dvla_set_gemm_variant(int v) { g_gemm_variant = v; }
 extern "C" void dvla_set_gemm_schedule(int oversubscribe, int stream_k) {
   if (oversubscribe >= 1) dvla_gemm::gemm_oversubscribe() = oversubscribe > 16 ? 16 : oversubscribe;
@@ -294,13 +305,15 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     else if (variant == 7 && ring_ok<RCfgM64>(a, combo)) choice = 4;
     else if (variant == 8 && ring_ok<PCfg>(a, combo)) choice = 5;
     else if (variant == 9 && ring_ok<PCfg>(a, combo)) choice = 6;
+    else if (variant == 10 && ring_ok<PCfg>(a, combo)) choice = 7;
     else if (variant > 80 && variant < 90 && combo == 0 && ring_ok<PCfg>(a, combo)) choice = 80 + (variant - 80);
     switch (choice) {
       case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;
       case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
       case 4: launch_ring<RCfgM64>(a, combo, split_k, stream); break;
       case 5: launch_phase(a, combo, split_k, stream); break;
-      case 6: launch_phase(a, combo, split_k, stream, true); break;   // falls back to the plain schedule when stream-K does not apply
+      case 6: launch_phase(a, combo, split_k, stream, 1); break;   // falls back to the plain schedule when stream-K does not apply
+      case 7: launch_phase(a, combo, split_k, stream, 2); break;
       case 81: case 83: case 84: case 85: case 86: case 89:   // ablations (plain bf16 epilogue only): 81 no MFMA, 83 no MFMA + no reads, 84 no DMA, 85 no epilogue, 86 raw stores only
         a.tiles_m = (int)((a.M + 255) / 256); a.tiles_n = (int)((a.N + 255) / 256);
         if (epi_class(a) != EPI_P0) return DVLA_ERR_UNSUPPORTED;
@@ -313,6 +326,8 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
         break;
       default: launch_cfg<CfgS>(a, combo, split_k, stream); break;
     }
+    g_last_variant = choice == 1 ? 4 : choice == 3 ? 6 : choice == 4 ? 7 : choice == 5 ? 8
+                   : (choice == 6 || choice == 7) ? (a.sk_tiles > 0 ? (choice == 6 ? 9 : 10) : 8) : choice >= 80 ? choice : 2;
   }
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;

@@ -81,7 +81,8 @@ class GradBucketReducer:
             p._dvla_grad_free = False
             p.grad = None if self.direct_grads else view
         self.buckets.append({"flat": flat, "params": plist, "offsets": offsets, "pending": len(plist), "launched": False,
-                             "fired": [False] * len(plist),      # this step
+                             "fired": [False] * len(plist),      # this step (any backward pass of it): what the reducer learns from
+                             "arrived": [False] * len(plist),    # this backward PASS (re-armed when no_sync() exits)
                              "expected": [True] * len(plist),    # parameters the launch waits for (learned)
                              "hold": False})
 
@@ -97,15 +98,16 @@ class GradBucketReducer:
                 view = param._dvla_grad_view
                 g = param.grad
                 if g is not None and g.data_ptr() != view.data_ptr():
-                    if b["fired"][pi]:
-                        view.add_(g)      # accumulation pass: the slot already holds the earlier passes' sum
-                    else:
-                        view.copy_(g)
+                    # a post-accumulate hook sees the RUNNING TOTAL of this step in param.grad (first pass: the incoming
+                    # gradient; later passes: autograd has already added to it, in place -- then it still is the slot and we
+                    # are not here -- or out of place (create_graph=True), and then `g` is the sum): copy, never add
+                    view.copy_(g)
                     param.grad = view
                     self.copied += 1
-            if b["fired"][pi]:
-                return                    # accumulation pass: already counted
             b["fired"][pi] = True
+            if b["arrived"][pi]:
+                return                    # already counted in this pass
+            b["arrived"][pi] = True
             if not b["expected"][pi]:
                 b["hold"] = True          # the used set grew: flush at finish() this step, re-learn there
                 return
@@ -128,7 +130,14 @@ class GradBucketReducer:
         self._next_launch += 1
         if self.world > 1:
             op = dist.ReduceOp.AVG if self._avg_in_collective() else dist.ReduceOp.SUM
-            self._handles.append(dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True))
+            flat = b["flat"]
+            if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+                # test configuration (several ranks sharing one GPU; RCCL refuses duplicate devices): gloo reduces on the
+                # host -- stage the bucket through host memory explicitly (ordered behind the backward kernels that wrote it)
+                host = flat.cpu()
+                self._handles.append((dist.all_reduce(host, op=op, group=self.group, async_op=True), host, flat))
+            else:
+                self._handles.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), None, None))
 
     def _avg_in_collective(self):
         return dist.get_backend(self.group) == "nccl"
@@ -143,8 +152,18 @@ class GradBucketReducer:
 
             def __exit__(self_inner, *exc):
                 red._no_sync = False
+                red._rearm_pass()
                 return False
         return _NoSync()
+
+    def _rearm_pass(self):
+        """the accumulation passes are over: the NEXT backward is the one whose arrivals launch the buckets, so count its
+        arrivals from zero (round-2 ADVICE: the counters used to stay at zero after the no_sync passes, every hook of the last
+        pass returned early and all collectives were issued back to back in finish() -- correct, but never overlapped)"""
+        for b in self.buckets:
+            if not b["launched"]:
+                b["arrived"] = [False] * len(b["params"])
+                b["pending"] = sum(b["expected"])
 
     def zero_grad(self):
         """zero the flat buffers (grads stay views) and re-arm the hooks for the next backward."""
@@ -154,6 +173,7 @@ class GradBucketReducer:
             b["launched"] = False
             b["hold"] = False
             b["fired"] = [False] * len(b["params"])
+            b["arrived"] = [False] * len(b["params"])
             if self.direct_grads:
                 for p in b["params"]:
                     p.grad = None
@@ -174,8 +194,10 @@ class GradBucketReducer:
                     b["expected"] = [e or f for e, f in zip(b["expected"], b["fired"])]
                 elif all(b["expected"]):            # first learning step: wait only for what fired
                     b["expected"] = list(b["fired"])
-        for h in self._handles:
+        for h, host, flat in self._handles:
             h.wait()
+            if host is not None:
+                flat.copy_(host)
         self._handles = []
         if self.world > 1 and not self._avg_in_collective():
             for b in self.buckets:

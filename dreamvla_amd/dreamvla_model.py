@@ -382,39 +382,31 @@ class DreamVLA(nn.Module):
         parts = self.encode_frames(image_primary, image_wrist, state, text_token)
         return self.decode_tokens(parts, action_label=action_label, mode=mode)
 
-    def _text_rows_equal(self, text_token):
-        """Are the S token rows of every sample equal?  The FIRST forward answers with one device reduction + read-back and
-        fixes the mode.  In "shared" mode every later forward only LAUNCHES the reduction (result copied asynchronously into
-        pinned host memory) and reads the verdict of the PREVIOUS forward, which has long completed: no host synchronisation
-        per step (round 1 synchronised every forward).  A violated assumption is therefore noticed one forward late and
-        raises -- the earlier step broadcast frame 0's instruction -- instead of training on silently wrong text."""
-        B, S = text_token.shape[0], text_token.shape[1]
+    def _text_share_begin(self, text_token):
+        """Are the S token rows of every sample equal (utils/train_utils.py:124 repeats the instruction over the window)?
+        The answer is needed on the HOST (it changes the text tower's batch size), so it costs a device -> host read.  This
+        only LAUNCHES the comparison and the copy of its one-byte verdict into pinned memory; `_text_share_end` waits for it
+        after the state / vision path of the SAME forward has been enqueued -- the host blocks until the device reaches the
+        comparison, the device then still has the whole ViT + resampler queued behind it and never idles.  The verdict is
+        exact for every forward: no assumption carried over from an earlier batch, nothing to raise a step late (round-2
+        ADVICE), identical on every rank of a data-parallel job.  Returns the pending (flag, event) or None (decided: not
+        shared -- S == 1, switched off, CPU tokens, or inside a stream capture where a host read is illegal)."""
+        S = text_token.shape[1]
         if S <= 1 or not self.share_text_over_time or not text_token.is_cuda or torch.cuda.is_current_stream_capturing():
-            return False
-        mode = getattr(self, "_text_share_mode", None)
-        if mode is None:
-            mode = "shared" if bool((text_token == text_token[:, :1]).all()) else "per_frame"
-            self._text_share_mode = mode
-            self._text_share_pending = None
-            return mode == "shared"
-        if mode == "per_frame":
-            return False
-        pend = self._text_share_pending
-        if pend is not None:
-            flag, ev = pend
-            ev.synchronize()            # recorded one forward ago: returns at once
-            if not bool(flag.item()):
-                self._text_share_mode = "per_frame"
-                raise RuntimeError("DreamVLA.encode_frames: the instruction tokens of a window differ between frames, but the "
-                                   "previous forward assumed (share_text_over_time, verified asynchronously) that they are "
-                                   "repeated over the window as utils/train_utils.py:124 does; that forward used frame 0's "
-                                   "instruction for every frame.  Set model.share_text_over_time = False for such data.")
+            return None
         flag = torch.empty(1, dtype=torch.bool, pin_memory=True)
         flag.copy_((text_token == text_token[:, :1]).all().reshape(1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._text_share_pending = (flag, ev)
-        return True
+        return flag, ev
+
+    @staticmethod
+    def _text_share_end(pending):
+        if pending is None:
+            return False
+        flag, ev = pending
+        ev.synchronize()
+        return bool(flag.item())
 
     def encode_frames(self, image_primary, image_wrist, state, text_token):
         """Conditioning tokens of every frame, as the list [text (B,S,1,H), state (B,S,1,H), primary image (B,S,nq,H),
@@ -426,19 +418,7 @@ class DreamVLA(nn.Module):
         H = self.hidden_dim
         wdt = torch.bfloat16     # compute dtype: fp32 parameters are masters, the kernels run on bf16 shadows (ops.shadow)
 
-        # text: frozen CLIP text tower -> Linear(512, H)                                  (643-653)
-        # The training loop feeds the SAME instruction to every frame of a window (`text_tokens.unsqueeze(1).repeat(1,
-        # window_size, 1)`, utils/train_utils.py:124): when all S rows of a sample are equal the 12-layer tower runs on B
-        # sequences instead of B*S and the result is broadcast (self._text_rows_equal: decided once, verified without a
-        # host synchronisation afterwards).
-        if self._text_rows_equal(text_token):
-            with torch.no_grad():
-                text_feature = self.clip_model.encode_text(text_token[:, 0].contiguous())
-            text_embedding = self.text_projector(text_feature.to(wdt)).view(B, 1, -1, H).expand(B, S, -1, H)
-        else:
-            with torch.no_grad():
-                text_feature = self.clip_model.encode_text(text_token.flatten(0, 1))
-            text_embedding = self.text_projector(text_feature.to(wdt)).view(B, S, -1, H)
+        share_pending = self._text_share_begin(text_token)     # verdict read below, after the vision path is enqueued
 
         # state: arm Linear(6,H) | gripper one-hot(2) -> Linear(2,H) -> cat -> Linear(2H,H)   (656-664)
         st = state.flatten(0, 1).to(wdt)
@@ -474,6 +454,19 @@ class DreamVLA(nn.Module):
         cls2 = cls_tok.reshape(2, n, 768)
         cls_primary = self.cls_token_primary_projector(cls2[0]).view(B, S, -1, H)
         cls_wrist = self.cls_token_wrist_projector(cls2[1]).view(B, S, -1, H)
+
+        # text: frozen CLIP text tower -> Linear(512, H)                                  (643-653)
+        # The training loop feeds the SAME instruction to every frame of a window (`text_tokens.unsqueeze(1).repeat(1,
+        # window_size, 1)`, utils/train_utils.py:124): when all S rows of every sample are equal the 12-layer tower runs on B
+        # sequences instead of B*S and the result is broadcast.  Decided per forward, exactly (self._text_share_begin/_end).
+        if self._text_share_end(share_pending):
+            with torch.no_grad():
+                text_feature = self.clip_model.encode_text(text_token[:, 0].contiguous())
+            text_embedding = self.text_projector(text_feature.to(wdt)).view(B, 1, -1, H).expand(B, S, -1, H)
+        else:
+            with torch.no_grad():
+                text_feature = self.clip_model.encode_text(text_token.flatten(0, 1))
+            text_embedding = self.text_projector(text_feature.to(wdt)).view(B, S, -1, H)
 
         return [text_embedding, state_embedding, image_primary_embedding, image_wrist_embedding, cls_primary, cls_wrist]
 

@@ -546,21 +546,25 @@ _MASK_CACHE = {}
 
 
 def mask_tables_for(mask):
-    """Cached build_mask_tables for a mask TENSOR OBJECT (the reference keeps the mask as an nn.Parameter,
-    dreamvla_model.py:286-298).  The cache entry holds a weak reference to the tensor and is valid only for that very object
-    at that version: a freed mask's storage address can be handed to the next mask of the same size by the caching
-    allocator, so (data_ptr, shape) alone would return the tables of a mask that no longer exists (round-1 ADVICE)."""
+    """Cached build_mask_tables for a mask tensor (the reference keeps the mask as an nn.Parameter,
+    dreamvla_model.py:286-298, and hands the trunk `mask[None, None]`-style views of it).  The cache is keyed on the BASE
+    tensor object (a view such as `m4[0, 0]` is a new Python object on every call; its `_base` is not) plus the view's
+    geometry, and an entry is valid only while that base object is alive at the same version, storage address and device:
+    a freed mask's storage address can be handed to the next mask of the same size by the caching allocator, so
+    (data_ptr, shape) alone would return the tables of a mask that no longer exists (round-1 ADVICE); a `.data` rebind or a
+    cross-device move changes address / device without changing the version (round-2 ADVICE)."""
     import weakref
-    key = id(mask)
+    base = mask._base if mask._base is not None else mask
+    key = (id(base), mask.storage_offset(), tuple(mask.shape), tuple(mask.stride()))
     ent = _MASK_CACHE.get(key)
     if ent is not None:
-        ref, version, mt = ent
-        if ref() is mask and version == mask._version:
+        ref, version, ptr, dev, mt = ent
+        if ref() is base and version == base._version and ptr == mask.data_ptr() and dev == mask.device:
             return mt
-    for k in [k for k, (r, _, _) in _MASK_CACHE.items() if r() is None]:
+    for k in [k for k, e in _MASK_CACHE.items() if e[0]() is None]:
         del _MASK_CACHE[k]
     mt = build_mask_tables(mask)
-    _MASK_CACHE[key] = (weakref.ref(mask), mask._version, mt)
+    _MASK_CACHE[key] = (weakref.ref(base), base._version, mask.data_ptr(), mask.device, mt)
     return mt
 
 
@@ -634,23 +638,52 @@ def attn_bwd_raw(q, k, v, o, lse, dout, dq, dk, dv, *, scale, mask_tables=None, 
 #   biases / LayerNorm affine parameters: read as fp32 by the kernels, gradients written as fp32 (param_dtype codes)
 # ---------------------------------------------------------------------------------------------------
 class _Shadow(torch.autograd.Function):
-    cache = {}       # id(master) -> (weakref(master), version, bf16 shadow)
+    """bf16 compute copy of an fp32 master weight, cached per weight.  An entry is valid for exactly one (tensor object,
+    version counter, storage address, device): in-place updates made on the parameter itself (`p.add_()`, torch optimizers)
+    bump the version; `p.data = ...` / `module.to(device)` / flat re-homing change the address or the device.  What NONE of
+    these can see is an in-place update through `.data` or a raw pointer (`p.data.add_()`, a custom kernel): every
+    `Optimizer.step()` therefore drops the shadows of the trainable weights (global post-step hook installed below), and
+    code that edits masters any other way calls `ops.invalidate_shadows()` (EMA swaps, manual SGD, checkpoint loads do not
+    need to: `load_state_dict` copies through `param.copy_`, which bumps the version)."""
+    cache = {}       # id(master) -> (weakref(master), version, data_ptr, device, bf16 shadow, requires_grad)
 
     @staticmethod
     def forward(ctx, w):
         import weakref
         ent = _Shadow.cache.get(id(w))
-        if ent is not None and ent[0]() is w and ent[1] == w._version:
-            return ent[2]
+        if (ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr() and ent[3] == w.device):
+            return ent[4]
         sh = cast_to(w.detach(), BF16)
         if len(_Shadow.cache) > 4096:
             _Shadow.cache.clear()
-        _Shadow.cache[id(w)] = (weakref.ref(w), w._version, sh)
+        _Shadow.cache[id(w)] = (weakref.ref(w), w._version, w.data_ptr(), w.device, sh, bool(w.requires_grad))
         return sh
 
     @staticmethod
     def backward(ctx, g):
         return cast_to(g.contiguous(), torch.float32) if g.dtype == BF16 else g.float()
+
+
+def invalidate_shadows(trainable_only=False):
+    """Forget the cached bf16 shadows of fp32 master weights (all of them, or only those of weights with requires_grad):
+    the next forward re-casts from the masters.  Called automatically after every torch `Optimizer.step()`; call it yourself
+    after updating masters through `.data` / raw pointers outside an optimizer."""
+    if not trainable_only:
+        _Shadow.cache.clear()
+        return
+    for k in [k for k, e in _Shadow.cache.items() if e[5] or e[0]() is None]:
+        del _Shadow.cache[k]
+
+
+def _install_optimizer_hook():
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+    except ImportError:       # very old torch: masters must then be updated in place on the parameter (version counter)
+        return
+    register_optimizer_step_post_hook(lambda opt, args, kwargs: invalidate_shadows(trainable_only=True))
+
+
+_install_optimizer_hook()
 
 
 class _ToCompute(torch.autograd.Function):

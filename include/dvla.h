@@ -9,8 +9,11 @@
  *
  * Conventions: plain pointers + sizes, no torch types.  All tensors are device pointers.  bf16 is the
  * raw 16-bit pattern.  Every function enqueues work on `stream` (a hipStream_t passed as void*),
- * never allocates, never synchronises, is re-entrant per stream, and returns 0 on success or a negative
- * DVLA_ERR_* code (no exceptions cross the ABI).  dtype codes: 0 = bf16, 1 = fp32.
+ * never synchronises, is re-entrant per stream, and returns 0 on success or a negative DVLA_ERR_* code (no
+ * exceptions cross the ABI).  Workspaces are the caller's (torch's caching allocator) with ONE exception: the
+ * stream-K schedules of dvla_gemm_bf16 keep a 64-MiB slab area + flags per (device, stream), hipMalloc'ed at the
+ * first launch that uses it (never during stream capture) and kept for the life of the process -- see
+ * dvla_set_gemm_variant / dvla_set_gemm_schedule.  dtype codes: 0 = bf16, 1 = fp32.
  */
 #ifndef DVLA_H_
 #define DVLA_H_
@@ -32,6 +35,9 @@ extern "C" {
 #define DVLA_ACT_TANH 6
 #define DVLA_ACT_SIGMOID 7
 
+/* ABI revision of this header; dreamvla_amd/_lib.py refuses a library that reports another one (a stale prebuilt .so then fails
+ * with a clear message instead of a missing-symbol error).  3 = round 3 (dvla_last_gemm_variant, variant 10, ...). */
+#define DVLA_ABI_VERSION 3
 int dvla_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -73,6 +79,12 @@ int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
  * Stream-K scratch: 64 MiB + flags per (device, stream), hipMalloc'ed on the first launch that uses it (never while the
  * stream is being captured -- such launches take the plain schedule) and kept; DVLA_GEMM_STREAMK=0 turns the schedule off. */
 void dvla_set_gemm_variant(int variant);
+/* 10 = the phase kernel under the FULL stream-K schedule: every tile belongs to the K-iteration ranges, so the groups' tile
+ * boundaries (epilogue write bursts) fall at different times for the whole launch instead of in lockstep rounds.
+ * What the last dvla_gemm_bf16 call of this process launched: 2 / 4 / 6 / 7 / 8 as above, 9 / 10 only when the stream-K
+ * schedule actually ENGAGED (otherwise 8: the plain schedule of the same kernel); 0 before the first call.  Tests use it to
+ * assert that a forced configuration ran instead of falling back. */
+int dvla_last_gemm_variant(void);
 /* How the persistent kernels spread tiles over the CUs (process-wide; env DVLA_GEMM_OVERSUBSCRIBE / DVLA_GEMM_STREAMK at load).
  *   oversubscribe = 1 (default): one workgroup per CU slot walks a fixed share of the tiles; the stream-K schedule may apply.
  *     Fastest on a GPU that runs nothing else (the default bench: 165 ms / step against 176 with k = 8).

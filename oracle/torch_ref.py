@@ -87,13 +87,20 @@ def linear(x, w, b=None, conv1d=False):
     return y if b is None else y + b
 
 
-def attention(q, k, v, scale=None, mask=None, drop=None, drop_cols=None):
+def _drop_rows(B, H, Lq, batch_index):
+    """dropout row ids (b*H + h)*Lq + i of a batch (or of the rows `batch_index` of a larger batch)"""
+    b = torch.arange(B, dtype=torch.int64) if batch_index is None else torch.as_tensor(batch_index, dtype=torch.int64)
+    return ((b.view(B, 1, 1) * H + torch.arange(H, dtype=torch.int64).view(1, H, 1)) * Lq
+            + torch.arange(Lq, dtype=torch.int64).view(1, 1, Lq)).unsqueeze(-1)
+
+
+def attention(q, k, v, scale=None, mask=None, drop=None, drop_cols=None, batch_index=None):
     """softmax(q k^T * scale + mask) v over (B, H, L, d) tensors.
     timm Attention -> F.scaled_dot_product_attention (vit_mae.py:202-203 via Block);
     GPT2Attention._attn (gpt2.py:61-84): scores / sqrt(d) + additive mask, softmax, dropout, @ v;
     PerceiverAttention (perceiver_resampler.py:53-60).  drop = (p, seed) applies our hash mask to the probabilities
     with idx_hi = (b*H + h)*Lq + i, idx_lo = drop_cols[j] (default j; with a compacted key axis the kernel hashes the
-    compact key index)."""
+    compact key index).  `batch_index`: the true batch indices of the given rows when they are a subset of a larger batch."""
     B, H, Lq, d = q.shape
     Lk = k.shape[2]
     scale = d ** -0.5 if scale is None else scale
@@ -103,11 +110,78 @@ def attention(q, k, v, scale=None, mask=None, drop=None, drop_cols=None):
     p = torch.softmax(s, dim=-1)
     if drop is not None and drop[0] > 0:
         pd, seed = drop
-        rows = torch.arange(B * H * Lq, dtype=torch.int64).view(B, H, Lq, 1)
+        rows = _drop_rows(B, H, Lq, batch_index)
         cols = (torch.arange(Lk, dtype=torch.int64) if drop_cols is None else drop_cols.to(torch.int64)).view(1, 1, 1, Lk)
         keep = drop_keep_mask(seed, rows, cols, pd)
         p = torch.where(keep, p / (1.0 - pd), torch.zeros_like(p))
     return torch.matmul(p, v)
+
+
+LOG2E = 1.4426950408889634
+LN2 = 0.6931471805599453
+
+
+def attention_bf16(q, k, v, scale=None, mask=None, drop=None, drop_cols=None, dout=None, batch_index=None):
+    """The SAME attention as `attention` above (same reference lines), restated with the two bf16 rounding points every
+    bf16 flash attention has -- the probabilities that enter the P.V matrix product and the score gradients that enter
+    the dQ / dK products -- placed exactly where dreamvla_amd/csrc/attention.hip places them, so that the HIP kernels can
+    be held to 1e-3 instead of a tolerance that absorbs those roundings (round-2 VERDICT).  fp32 everywhere else.
+
+      forward   s2 = (q k^T) * (scale * log2 e) + mask;  M = ceil(rowmax s2)  (an INTEGER: every online-softmax rescale
+                in the kernel is an exact power of two, so rounding P commutes with it and the result does not depend on the
+                tile order);  p = 2^(s2 - M);  l = sum_j p  (fp32, unrounded p);  P~ = bf16(dropout(p));
+                o = bf16((P~ v) / l);  lse = (M + log2 l) ln 2
+      backward  P = 2^(s2 - lse log2 e)  (from the saved lse, unrounded);  dP = dropout'(dout v^T);
+                delta = rowsum(dout * o)  (o as stored: bf16);  dS~ = bf16(P (dP - delta) scale);
+                dq = bf16(dS~ k),  dk = bf16(dS~^T q),  dv = bf16(bf16(dropout(P))^T dout)
+
+    Pinned by tests/test_attention_oracle.py: equals `attention` (and its autograd) up to those two roundings -- 3e-3 /
+    4e-3 rel-L2 on random data -- and is exactly invariant to the order in which key tiles are visited.
+    (B, H, L, d) tensors; returns (o, lse) or (o, lse, dq, dk, dv) when `dout` is given."""
+    B, H, Lq, d = q.shape
+    Lk = k.shape[2]
+    scale = d ** -0.5 if scale is None else scale
+    q, k, v = q.float(), k.float(), v.float()
+    s = torch.matmul(q, k.transpose(-1, -2))
+    s2 = s * (scale * LOG2E)
+    vis = None
+    if mask is not None:
+        vis = (mask == 0).expand(B, H, Lq, Lk) if mask.dim() < 4 else (mask == 0)
+        s2 = torch.where(vis, s2, torch.full_like(s2, float("-inf")))
+    m = torch.ceil(s2.amax(dim=-1, keepdim=True))
+    m = torch.where(torch.isinf(m), torch.zeros_like(m), m)
+    p = torch.exp2(s2 - m)
+    l = p.sum(dim=-1, keepdim=True)
+    keep = None
+    inv_keep = 1.0
+    if drop is not None and drop[0] > 0:
+        pd, seed = drop
+        rows = _drop_rows(B, H, Lq, batch_index)
+        cols = (torch.arange(Lk, dtype=torch.int64) if drop_cols is None else drop_cols.to(torch.int64)).view(1, 1, 1, Lk)
+        keep = drop_keep_mask(seed, rows, cols, pd)
+        inv_keep = 1.0 / (1.0 - pd)
+    pdrop = p if keep is None else torch.where(keep, p * inv_keep, torch.zeros_like(p))
+    some = l > 0                    # a row that sees no key: o = 0, lse = +inf (the kernel's convention; the reference never builds one)
+    o = bf16_round(torch.where(some, torch.matmul(bf16_round(pdrop), v) / torch.where(some, l, torch.ones_like(l)),
+                               torch.zeros(1)))
+    lse = torch.where(some, (m + torch.log2(torch.where(some, l, torch.ones_like(l)))) * LN2,
+                      torch.full_like(l, float("inf"))).squeeze(-1)
+    if dout is None:
+        return o, lse
+    dout = dout.float()
+    P = torch.exp2(s2 - (lse * LOG2E).unsqueeze(-1))
+    if vis is not None:
+        P = torch.where(vis, P, torch.zeros_like(P))
+    dP = torch.matmul(dout, v.transpose(-1, -2))
+    if keep is not None:
+        dP = torch.where(keep, dP * inv_keep, torch.zeros_like(dP))
+    delta = (dout * o).sum(dim=-1, keepdim=True)
+    dS = bf16_round(P * (dP - delta) * scale)
+    Pd = P if keep is None else torch.where(keep, P * inv_keep, torch.zeros_like(P))
+    dq = bf16_round(torch.matmul(dS, k))
+    dk = bf16_round(torch.matmul(dS.transpose(-1, -2), q))
+    dv = bf16_round(torch.matmul(bf16_round(Pd).transpose(-1, -2), dout))
+    return o, lse, dq, dk, dv
 
 
 def split_qkv(qkv, H):

@@ -6,11 +6,13 @@ tests/gpu_diag.py dumps all of them into gpurun_out/ in one go (no stop at first
 Tolerances (written here, used everywhere):
   * bf16 outputs are compared with the fp32 oracle result rounded to bf16:   rel-L2 <= 1e-3
   * fp32 outputs (GEMM with fp32 C, LayerNorm statistics, LSE):              rel-L2 <= 1e-5 / abs 1e-4
-  * attention outputs:                                                       rel-L2 <= 3e-3
-    (the probabilities are rounded to bf16 for the P.V MFMA, as in every bf16 flash attention incl. the SDPA
-    flash backend the reference dispatches to; measured 1.7e-3 .. 2.8e-3 on random data, not reducible
-    without an fp32/fp16 P operand)
-  * gradients (bf16, pass through bf16-rounded P / dS fragments):            rel-L2 <= 4e-3
+  * attention outputs vs oracle/torch_ref.py::attention_bf16 -- the restatement that rounds the probabilities (P.V operand)
+    and the score gradients (dQ / dK operand) to bf16 exactly where the kernels do:           rel-L2 <= 1e-3
+    attention gradients vs the same:                                                          rel-L2 <= 2e-3
+    (round 2 compared with the unrounded fp32 restatement and had to allow 3e-3 / 4e-3 for those two roundings -- the SDPA
+    flash backend the reference dispatches to has them too; that comparison is still made, as the link to the
+    reference-pinned fp32 oracle, and recorded under the names "... (fp32 oracle)")
+  * other gradients (bf16, through bf16-rounded intermediates):              rel-L2 <= 4e-3
 rel-L2 = ||a - b||_2 / max(||b||_2, tiny).
 """
 import math
@@ -22,7 +24,9 @@ from oracle import torch_ref as R
 TOL_FWD = 1e-3
 TOL_F32 = 1e-5
 TOL_GRAD = 4e-3
-TOL_ATTN = 3e-3
+TOL_ATTN = 1e-3          # vs the bf16-faithful oracle
+TOL_ATTN_GRAD = 2e-3
+TOL_ATTN_F32 = 3e-3      # vs the unrounded fp32 oracle (bf16 P not modelled)
 DEV = "cuda"
 BF = torch.bfloat16
 
@@ -118,6 +122,84 @@ def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", re
     return out
 
 
+# the GEMM problems of the benchmarked training step (BASELINE configs[1]: B = 32, S = 7, head set C; profiles/r02_gemm_breakdown.json)
+# at FULL size, with their real K and epilogue, under every kernel configuration the tuner locks for them (bench.py's
+# tuner_wins_by_problem_key) -- round-2 VERDICT: the forced-variant tests stopped at K <= 448 / M <= 4300, where the stream-K
+# schedules never engage and a tile sees 2-7 K-tiles instead of 12-64.  `variants`: 0 = the library's cost model (no assertion
+# on what ran), anything else is FORCED and the test asserts through dvla_last_gemm_variant() that it ran (9 / 10 only count
+# when the stream-K schedule actually engaged).  Every forced variant runs twice in a row (stream-K scratch / flags reused).
+MODEL_GEMMS = {
+    "trunk fc1 fwd": dict(M=20832, N=4096, K=1024, b_trans=True, bias=True, act="gelu_tanh", want_preact=True, variants=(8, 9, 10)),
+    "trunk fc1 dact": dict(M=20832, N=4096, K=1024, dact="gelu_tanh", variants=(9, 10)),
+    "trunk fc2 fwd": dict(M=20832, N=1024, K=4096, b_trans=True, bias=True, residual=True, dropout_p=0.1, variants=(0, 9, 10)),
+    "trunk fc2 dX": dict(M=20832, N=1024, K=4096, variants=(9, 10)),
+    "trunk c_attn fwd": dict(M=20832, N=3072, K=1024, b_trans=True, bias=True, variants=(8, 10)),
+    "trunk c_proj fwd": dict(M=20832, N=1024, K=1024, b_trans=True, bias=True, residual=True, dropout_p=0.1, variants=(0, 7, 10)),
+    "vit fc1": dict(M=88256, N=3072, K=768, bias=True, act="gelu_erf", variants=(8, 10)),
+    "trunk dW fc1": dict(M=1024, N=4096, K=20832, a_trans=True, b_trans=True, split_k=4, variants=(0, 4)),
+    "decoder dW fc2": dict(M=4096, N=1024, K=91840, a_trans=True, b_trans=True, split_k=4, variants=(8,)),
+    "decoder fc2 dX": dict(M=91840, N=1024, K=4096, b_trans=True, variants=(9, 10)),
+}
+
+
+def check_gemm_model_scale(name):
+    from dreamvla_amd import _lib, ops
+    from dreamvla_amd._lib import ACT
+    c = dict(MODEL_GEMMS[name])
+    variants = c.pop("variants")
+    M, N, K = c["M"], c["N"], c["K"]
+    a_trans, b_trans = c.get("a_trans", False), c.get("b_trans", False)
+    act, dact, p_drop = c.get("act", "none"), c.get("dact"), c.get("dropout_p", 0.0)
+    want_preact, split_k = c.get("want_preact", False), c.get("split_k", 1)
+    g = torch.Generator().manual_seed(4321)
+    A = rnd((M, K), g)
+    B = rnd((N, K), g, 1.0 / math.sqrt(K))
+    bias_t = rnd((N,), g) if c.get("bias") else None
+    res_t = rnd((M, N), g) if c.get("residual") else None
+    aux_t = rnd((M, N), g) if dact else None
+    sd = (77, 4242)
+    ref = A @ B.t()
+    if bias_t is not None:
+        ref += bias_t
+    pre_ref = ref.clone() if want_preact else None
+    if want_preact:
+        ref = R.bf16_round(ref)
+    ref = R.act(ref, act)
+    if p_drop > 0:
+        ref = R.dropout_elementwise(ref, p_drop, sd)
+    if dact or res_t is not None:
+        ref = R.bf16_round(ref)
+    if dact:
+        x = aux_t.clone().requires_grad_(True)
+        R.act(x, dact).sum().backward()
+        ref = ref * x.grad
+    if res_t is not None:
+        ref = ref + res_t
+    dev = lambda t: None if t is None else t.to(DEV, BF)
+    a_dev = (A.t().contiguous() if a_trans else A).to(DEV, BF)
+    b_dev = (B.t().contiguous() if b_trans else B).to(DEV, BF)
+    bias_d, res_d, aux_d = dev(bias_t), dev(res_t), dev(aux_t)
+    del A, B
+    lib = _lib.load()
+    out = []
+    for v in variants:
+        for rep in range(1 if v == 0 else 2):
+            r = ops.gemm(a_dev, b_dev, a_trans=a_trans, b_trans=b_trans, bias=bias_d, act=ACT[act], want_preact=want_preact,
+                         dact_aux=aux_d, dact=ACT[dact] if dact else 0, dropout_p=p_drop, seed=sd, residual=res_d,
+                         split_k=split_k, variant=v)
+            ran = int(lib.dvla_last_gemm_variant())
+            got, pre = r if want_preact else (r, None)
+            tag = f"gemm[{name}] {M}x{N}x{K} sk{split_k} v{v} run{rep}"
+            out.append(metrics(tag, got, ref, TOL_FWD))
+            if want_preact:
+                out.append(metrics(tag + " preact", pre, pre_ref, TOL_FWD))
+            if v != 0:
+                out.append({"name": tag + f": forced configuration ran (dvla_last_gemm_variant = {ran})", "rel_l2": 0.0, "tol": 0.0,
+                            "ok": ran == v})
+            del r, got, pre
+    return out
+
+
 def check_layernorm(rows, cols, affine=True, eps=1e-5, param_f32=False, seed=0):
     from dreamvla_amd import ops
     g = torch.Generator().manual_seed(99 + seed)
@@ -187,11 +269,29 @@ def make_block_mask(L, blk, nA):
     return m
 
 
-def check_self_attention(B, H, L, mask_kind="none", dropout_p=0.0, grad=True, seed=0, scale=None):
+def _sample_rows(B, rows):
+    if rows is None or rows >= B:
+        return list(range(B))
+    idx = sorted(set([0, 1, B // 2, B - 2, B - 1] + [int(x) for x in torch.randint(0, B, (max(rows - 5, 0),), generator=torch.Generator().manual_seed(B))]))
+    return [i for i in idx if 0 <= i < B]
+
+
+def check_self_attention(B, H, L, mask_kind="none", dropout_p=0.0, grad=True, seed=0, scale=None, rows=None, period=None):
+    """HIP self-attention (forward + backward) against oracle/torch_ref.py::attention_bf16 (1e-3 / 2e-3) and, as the link
+    to the reference-pinned fp32 restatement, against ::attention (3e-3 / 4e-3).
+    rows   : the oracle is evaluated on that many batch rows only (first / last / middle + seeded random ones; the CPU
+             restatement materialises B*H*L*L scores) -- for the benchmark-scale cases (B = 32 / 448);
+    period : batch row b carries the inputs of row b % period; without dropout the kernels are deterministic, so EVERY row of the
+             device result must equal its representative bit for bit -- full coverage of the batch at no oracle cost."""
     from dreamvla_amd import ops
     g = torch.Generator().manual_seed(7 + seed)
-    qkv = rnd((B, L, 3 * H * 64), g)
-    do = rnd((B, L, H * 64), g)
+    P = B if period is None else min(B, period)
+    qkv = rnd((P, L, 3 * H * 64), g)
+    do = rnd((P, L, H * 64), g)
+    if P < B:
+        rep = -(-B // P)
+        qkv = qkv.repeat(rep, 1, 1)[:B].contiguous()
+        do = do.repeat(rep, 1, 1)[:B].contiguous()
     mask = None
     if mask_kind == "block":
         mask = make_block_mask(L, 19, 12)
@@ -212,24 +312,47 @@ def check_self_attention(B, H, L, mask_kind="none", dropout_p=0.0, grad=True, se
     o = ops.self_attention(qd, H, mask_tables=mt, dropout_p=dropout_p, scale=scale)
     sd = (_Seeds.counter, _Seeds.next()[1])
     _Seeds.counter -= 1
-    qr = qkv.clone().requires_grad_(grad)
-    q, k, v = R.split_qkv(qr, H)
+    if grad:
+        o.backward(do.to(DEV, BF))
+    sel = _sample_rows(B, rows)
+    idx = torch.tensor(sel)
     drop_cols = None
     if mt is not None and mt.key_index is not None:
         drop_cols = torch.zeros(L, dtype=torch.int64)
         drop_cols[mt.key_index.cpu().long()] = torch.arange(mt.Lk)
-    orf = R.merge_heads(R.attention(q, k, v, scale=scale, mask=mask, drop=(dropout_p, sd) if dropout_p > 0 else None,
-                                    drop_cols=drop_cols))
-    tag = f"self_attn B{B} H{H} L{L} mask={mask_kind} p{dropout_p}"
-    out = [metrics(tag + " o", o, orf, TOL_ATTN)]
+    drop = (dropout_p, sd) if dropout_p > 0 else None
+    W = H * 64
+    tag = f"self_attn B{B} H{H} L{L} mask={mask_kind} p{dropout_p}" + ("" if len(sel) == B else f" ({len(sel)} rows)")
+    o_h = o.detach().float().cpu()[idx]
+    g_h = qd.grad.detach().float().cpu()[idx] if grad else None
+    qs, dos = qkv[idx], do[idx]
+    # (1) the bf16-faithful restatement: same rounding points as the kernels
+    q, k, v = R.split_qkv(qs, H)
+    do4 = dos.view(len(sel), L, H, 64).permute(0, 2, 1, 3)
+    res = R.attention_bf16(q, k, v, scale=scale, mask=mask, drop=drop, drop_cols=drop_cols, dout=do4 if grad else None,
+                           batch_index=sel)
+    out = [metrics(tag + " o", o_h, R.merge_heads(res[0]), TOL_ATTN)]
     if grad:
-        o.backward(do.to(DEV, BF))
-        orf.backward(do)
-        out.append(metrics(tag + " dqkv", qd.grad, qr.grad, TOL_GRAD))
-        W = H * 64
-        out.append(metrics(tag + " dq", qd.grad[..., :W], qr.grad[..., :W], TOL_GRAD))
-        out.append(metrics(tag + " dk", qd.grad[..., W:2 * W], qr.grad[..., W:2 * W], TOL_GRAD))
-        out.append(metrics(tag + " dv", qd.grad[..., 2 * W:], qr.grad[..., 2 * W:], TOL_GRAD))
+        dq, dk, dv = (R.merge_heads(t) for t in res[2:])
+        out.append(metrics(tag + " dq", g_h[..., :W], dq, TOL_ATTN_GRAD))
+        out.append(metrics(tag + " dk", g_h[..., W:2 * W], dk, TOL_ATTN_GRAD))
+        out.append(metrics(tag + " dv", g_h[..., 2 * W:], dv, TOL_ATTN_GRAD))
+    # (2) the unrounded fp32 restatement of the reference's softmax attention (what the golden fixtures pin)
+    qr = qs.clone().requires_grad_(grad)
+    q, k, v = R.split_qkv(qr, H)
+    orf = R.merge_heads(R.attention(q, k, v, scale=scale, mask=mask, drop=drop, drop_cols=drop_cols, batch_index=sel))
+    out.append(metrics(tag + " o (fp32 oracle)", o_h, orf, TOL_ATTN_F32))
+    if grad:
+        orf.backward(dos)
+        out.append(metrics(tag + " dqkv (fp32 oracle)", g_h, qr.grad, TOL_GRAD))
+    # (3) every batch row equals its representative (deterministic kernels, no dropout)
+    if P < B and dropout_p == 0.0:
+        of = o.detach().view(-1, L * W)
+        same = bool(torch.equal(of[P:], of[:B - P]))
+        if grad:
+            gf = qd.grad.detach().view(-1, 3 * L * W)
+            same = same and bool(torch.equal(gf[P:], gf[:B - P]))
+        out.append({"name": tag + f" all {B} rows == their representative (period {P})", "rel_l2": 0.0, "tol": 0.0, "ok": same})
     return out
 
 
@@ -243,15 +366,22 @@ def check_cross_attention(B, H, Lq, Lk, seed=0):
     kvd = kv.to(DEV, BF).requires_grad_(True)
     o = ops.cross_attention(qd, kvd, H)
     o.backward(do.to(DEV, BF))
+    tag = f"cross_attn B{B} H{H} Lq{Lq} Lk{Lk}"
+    q4 = q.view(B, Lq, H, 64).permute(0, 2, 1, 3)
+    kv5 = kv.view(B, Lk, 2, H, 64).permute(2, 0, 3, 1, 4)
+    of, _, dq, dk, dv = R.attention_bf16(q4, kv5[0], kv5[1], dout=do.view(B, Lq, H, 64).permute(0, 2, 1, 3))
+    dkv = torch.stack((dk, dv), 0).permute(1, 3, 0, 2, 4).reshape(B, Lk, 2 * H * 64)     # (2,B,H,Lk,64) -> (B,Lk,2,H,64)
+    out = [metrics(tag + " o", o, R.merge_heads(of), TOL_ATTN), metrics(tag + " dq", qd.grad, R.merge_heads(dq), TOL_ATTN_GRAD),
+           metrics(tag + " dkv", kvd.grad, dkv, TOL_ATTN_GRAD)]
     qr = q.clone().requires_grad_(True)
     kvr = kv.clone().requires_grad_(True)
     q4 = qr.view(B, Lq, H, 64).permute(0, 2, 1, 3)
     kv5 = kvr.view(B, Lk, 2, H, 64).permute(2, 0, 3, 1, 4)
     orf = R.merge_heads(R.attention(q4, kv5[0], kv5[1]))
     orf.backward(do)
-    tag = f"cross_attn B{B} H{H} Lq{Lq} Lk{Lk}"
-    return [metrics(tag + " o", o, orf, TOL_ATTN), metrics(tag + " dq", qd.grad, qr.grad, TOL_GRAD),
-            metrics(tag + " dkv", kvd.grad, kvr.grad, TOL_GRAD)]
+    out += [metrics(tag + " o (fp32 oracle)", o, orf, TOL_ATTN_F32), metrics(tag + " dq (fp32 oracle)", qd.grad, qr.grad, TOL_GRAD),
+            metrics(tag + " dkv (fp32 oracle)", kvd.grad, kvr.grad, TOL_GRAD)]
+    return out
 
 
 def check_linear_fn(M, K, N, act="none", conv1d=False, residual=False, bias=True, dropout_p=0.0, seed=0):
@@ -419,6 +549,16 @@ def all_checks(quick=False):
             (check_gemm, dict(M=20992, N=1024, K=256, a_trans=True, b_trans=True, out_f32=True, variant=9, seed=rep)),
             (check_gemm, dict(M=21000, N=1088, K=128, bias=True, act="gelu_erf", residual=True, variant=9, seed=rep)),
         ]
+    # 10 = the FULL stream-K schedule (every tile in the K-iteration ranges): same shapes as 9
+    for rep in range(2):
+        L += [
+            (check_gemm, dict(M=20832, N=1024, K=320, bias=True, act="gelu_tanh", want_preact=True, variant=10, seed=rep)),
+            (check_gemm, dict(M=20832, N=1024, K=192, bias=True, dropout_p=0.1, residual=True, b_trans=True, variant=10, seed=rep)),
+            (check_gemm, dict(M=20992, N=1024, K=256, a_trans=True, b_trans=True, out_f32=True, variant=10, seed=rep)),
+            (check_gemm, dict(M=21000, N=1088, K=128, bias=True, act="gelu_erf", residual=True, variant=10, seed=rep)),
+        ]
+    # the benchmarked step's own GEMM problems at full size, real K, real epilogue, every locked configuration
+    L += [(check_gemm_model_scale, dict(name=n)) for n in MODEL_GEMMS]
     L += [(check_flat_adamw, dict()), (check_direct_grads, dict()), (check_assemble_tokens, dict()),
           (check_concat_shared_suffix, dict()), (check_concat_shared_suffix, dict(n=5, nq=9, ns=256, D=3072, seed=1))]
     L += [(check_fused_losses, dict(case_name=c)) for c in ("C_calvin_dit", "E_libero_all_heads", "E_atten_goal")]
@@ -452,6 +592,14 @@ def all_checks(quick=False):
         (check_self_attention, dict(B=2, H=16, L=651, mask_kind="dreamvla", dropout_p=0.1)),
         (check_self_attention, dict(B=2, H=16, L=930, mask_kind="dreamvla")),
         (check_self_attention, dict(B=2, H=16, L=930, mask_kind="dreamvla", dropout_p=0.1)),
+        # ... at the benchmark's batch: B = 32 trunk (oracle on 8 sampled rows; all rows == their representative without
+        # dropout), the decoders' B = 2 * 32 * 7 = 448 sequences of 9 + 196 / 9 + 256 tokens, the DiT head's 1792 x 6
+        (check_self_attention, dict(B=32, H=16, L=651, mask_kind="dreamvla", dropout_p=0.1, rows=8)),
+        (check_self_attention, dict(B=32, H=16, L=651, mask_kind="dreamvla", rows=6, period=5)),
+        (check_self_attention, dict(B=448, H=16, L=205, rows=10, period=9)),
+        (check_self_attention, dict(B=448, H=16, L=265, rows=10, period=9, seed=1)),
+        (check_self_attention, dict(B=448, H=12, L=197, rows=8, period=7, grad=False)),
+        (check_self_attention, dict(B=1792, H=12, L=6, rows=32, period=48)),
         (check_cross_attention, dict(B=3, H=8, Lq=16, Lk=212)),
         (check_cross_attention, dict(B=2, H=2, Lq=40, Lk=33)),
     ]

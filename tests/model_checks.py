@@ -46,13 +46,17 @@ OUTPUT_NAMES = ["arm_action", "gripper_action", "image_pred", "arm_state", "grip
 TOL_FLOOR = 1e-3        # north_star: "within 1e-3 rel bf16"
 
 
+REF_DEV_FACTOR = 1.25   # round-2 VERDICT: the bound sits AT the reference's own bf16 floor (round 2 allowed 2 x)
+
+
 def output_tolerances(fx, fallback):
-    """per-output (rel-L2 tolerance, max-abs tolerance): max(1e-3, 2 x the REAL reference's own bf16 deviation from its fp32
-    result on the same inputs), recorded per output in the fixture by oracle/make_golden.py `amp` for the reference's two
+    """per-output (rel-L2 tolerance, max-abs tolerance): max(1e-3, 1.25 x the REAL reference's own bf16 deviation from its
+    fp32 result on the same inputs), recorded per output in the fixture by oracle/make_golden.py `amp` for the reference's two
     bf16 modes: `--precision amp_bf16` (autocast; fx["ref_amp_bf16_deviation"]) and `--precision bf16` (train.py:122-123,
     the whole module cast -- parameters, residual stream and normalisations in bf16: the mode the HIP path implements;
-    fx["ref_bf16_cast_deviation"]).  The larger of the two is the floor: every op boundary rounds.  `fallback` is used only
-    for outputs without a record."""
+    fx["ref_bf16_cast_deviation"]).  The larger of the two is the floor: every op boundary rounds.  The HIP path measures
+    0.97 ... 1.01 x that floor (image / depth / sam predictions of fixtures A and C), so the factor leaves ~20 % for the
+    scatter between kernel configurations (fp32 summation order).  `fallback` is used only for outputs without a record."""
     recs = [fx.get("ref_amp_bf16_deviation"), fx.get("ref_bf16_cast_deviation")]
     out = []
     for i in range(len(OUTPUT_NAMES)):
@@ -62,7 +66,7 @@ def output_tolerances(fx, fallback):
         else:
             rel = max(d["rel_l2"] for d in ds)
             mab = max(d["max_abs"] for d in ds)
-            out.append((max(TOL_FLOOR, 2.0 * rel), max(2.0 * mab, 4.0 * 2.0 ** -8 * ds[0]["absmax"])))
+            out.append((max(TOL_FLOOR, REF_DEV_FACTOR * rel), max(1.5 * mab, 3.0 * 2.0 ** -8 * ds[0]["absmax"])))
     return out
 
 
@@ -206,12 +210,12 @@ def hip_full_model_checks(name):
             # north_star: action-MSE parity within 1e-3 (relative once the loss exceeds 1) -- or, where the REAL reference's
             # own bf16 path (train.py --precision amp_bf16 = autocast; run five times on the same inputs and noise by
             # oracle/make_golden.py, CPU bf16 GEMMs scatter run to run) is itself further from its fp32 value than that,
-            # within 2x the reference's own largest bf16 deviation (HIP: 2.3e-3 on E, reference scatter up to 1.6e-3)
+            # within 1.25 x the reference's own largest bf16 deviation (HIP: 1.3e-3 on C, reference `--precision bf16`: 1.9e-3)
             ref_dev = max([abs(r - want) for r in fx.get("train_loss_ref_amp_bf16_runs", [])] or [0.0])
             cast = (fx.get("ref_bf16_cast_deviation") or [None])[0]
             if cast is not None:          # the reference's `--precision bf16` loss on the same inputs / noise
                 ref_dev = max(ref_dev, cast["max_abs"])
-            tol = max(1e-3 * max(1.0, abs(want)), 2.0 * ref_dev)
+            tol = max(1e-3 * max(1.0, abs(want)), REF_DEV_FACTOR * ref_dev)
             res.append({"name": f"hip.{name}.train.action_mse_err", "rel_l2": abs(got - want), "tol": tol,
                         "ok": abs(got - want) <= tol, "want": want, "got": got})
             m.action_model._injected = None
@@ -223,6 +227,88 @@ def hip_full_model_checks(name):
             finally:
                 torch.randn = real
             res += compare_outputs(out, fx["test"], TOL_MODEL, f"hip.{name}.test")
+    return res
+
+
+def hip_model_batch32_checks():
+    """Fixture C (the benchmarked configuration: S = 7, 24 layers, head set C, full width) inside the BENCHMARK'S batch:
+    B = 32, row 0 = the fixture's input, rows 1..31 = other synthetic samples.  M = 20832 rows reach the trunk GEMMs, the
+    stream-K / phase configurations engage and the attention grids are the timed ones (round-2 VERDICT: fixture C alone runs
+    at M = 651).  Checked: row 0's dream-head outputs against the REAL reference's golden values (fixture tolerance), row 0's
+    DiT loss (its noise / timesteps injected at row 0's positions of the 8-fold repeat) against the golden loss, and rows 13
+    and 31 against the reference-pinned oracle run on those samples alone (samples are independent in eval mode)."""
+    from dreamvla_amd import ops
+    fx = load("dreamvla_C.pt")
+    cfg = fx["cfg"]
+    S, Bn = fx["S"], 32
+    m = build_hip_model(cfg)
+    sd32 = f32(m.state_dict())
+    m = m.to(BF).to("cuda")
+    m._init_model_type()
+    m.eval()
+    gi = golden_inputs(fx)
+    other = weights.synthetic_batch(Bn, S, window=fx["window"], seed=fx["seed"] + 1000)
+    inp = {k: other[k][:, :S].clone() for k in ("image_primary", "image_wrist", "state", "text_token")}
+    for k in inp:
+        inp[k][0] = gi[k][0]
+    Sp = fx["action_label"].shape[1]
+    g = torch.Generator().manual_seed(99)
+    lab = torch.rand(Bn, Sp, 3, 7, generator=g) * 2 - 1
+    lab[0] = fx["action_label"][0]
+    r = 8
+    noise = torch.randn(r * Bn * Sp, 3, 7, generator=g).to(BF).float()
+    tstep = torch.randint(0, 100, (r * Bn * Sp,), generator=g)
+    rows0 = torch.cat([torch.arange(Sp) + rep * Bn * Sp for rep in range(r)])          # row 0's entries of labels.repeat(8,1,1)
+    noise[rows0] = fx["dit_noise"].float()
+    tstep[rows0] = fx["dit_timestep"]
+    captured = {}
+    hook = m.action_model.net.register_forward_hook(lambda mod, a, out: captured.__setitem__("eps", out.detach().float().cpu()))
+    res = []
+    with torch.no_grad():
+        m.action_model._injected = (noise.to("cuda", BF), tstep.to("cuda"))
+        out = m(inp["image_primary"].to("cuda", BF), inp["image_wrist"].to("cuda", BF), inp["state"].to("cuda", BF),
+                inp["text_token"].to("cuda"), action_label=lab.to("cuda", BF), mode="train")
+        m.action_model._injected = None
+    hook.remove()
+    tuned = ops.GemmTuner.summary()
+    # row 0 vs the real reference's golden outputs
+    row0 = [None if o is None or o.dim() == 0 else o[:S] for o in out]
+    want = [None if (w is None or (torch.is_tensor(w) and w.dim() == 0)) else w for w in fx["train"]]
+    res += compare_outputs(row0, want, TOL_MODEL, "hip.C@B32.row0", fx=fx)
+    eps = captured["eps"]
+
+    def dit_loss(rows):
+        return float(((eps[rows] - noise[rows]) ** 2).mean())
+    want0, got0 = float(fx["train"][0]), dit_loss(rows0)
+    ref_dev = max([abs(x - want0) for x in fx.get("train_loss_ref_amp_bf16_runs", [])] or [0.0])
+    cast = (fx.get("ref_bf16_cast_deviation") or [None])[0]
+    if cast is not None:
+        ref_dev = max(ref_dev, cast["max_abs"])
+    tol = max(1e-3 * max(1.0, abs(want0)), REF_DEV_FACTOR * ref_dev)
+    res.append({"name": "hip.C@B32.row0.action_mse_err", "rel_l2": abs(got0 - want0), "tol": tol, "ok": abs(got0 - want0) <= tol,
+                "want": want0, "got": got0})
+    # other rows vs the oracle on those samples alone
+    tols = output_tolerances(fx, TOL_MODEL)
+    for b in (13, 31):
+        rows_b = torch.cat([torch.arange(Sp) + b * Sp + rep * Bn * Sp for rep in range(r)])
+        o_r = M.dreamvla_forward(sd32, cfg, inp["image_primary"][b:b + 1], inp["image_wrist"][b:b + 1], inp["state"][b:b + 1],
+                                 inp["text_token"][b:b + 1], action_label=lab[b:b + 1], mode="train",
+                                 dit_noise=noise[rows_b], dit_timestep=tstep[rows_b])
+        for nm, o_h, o_o, (t_rel, t_abs) in zip(OUTPUT_NAMES, out, o_r, tols):
+            if o_o is None or o_h is None:
+                continue
+            if o_o.dim() == 0:
+                if nm == "arm_action":       # (slot 1 is the same scalar)
+                    gb, wb = dit_loss(rows_b), float(o_o)
+                    res.append({"name": f"hip.C@B32.row{b}.action_mse_err (oracle)", "rel_l2": abs(gb - wb), "tol": tol,
+                                "ok": abs(gb - wb) <= tol, "want": wb, "got": gb})
+                continue
+            gh = o_h[b * S:(b + 1) * S]
+            rr = rel_l2(gh, o_o)
+            mab = float((gh.detach().float().cpu() - o_o.float()).abs().max())
+            res.append({"name": f"hip.C@B32.row{b}.{nm} (oracle)", "rel_l2": rr, "tol": t_rel, "max_abs": mab, "max_abs_tol": t_abs,
+                        "ok": bool(rr <= t_rel and (t_abs is None or mab <= t_abs))})
+    res.append({"name": f"hip.C@B32 ran with M = {Bn * S * 93} trunk rows (tuner: {tuned})", "rel_l2": 0.0, "tol": 0.0, "ok": True})
     return res
 
 
@@ -244,29 +330,28 @@ def hip_text_sharing_checks():
         res.append({"name": "text tower shared over time == per frame", "rel_l2": r, "tol": 2e-3, "ok": r <= 2e-3})
         tt = inp["text_token"].clone()
         tt[:, 1, 3] = (tt[:, 1, 3] + 1) % 49000          # rows differ -> the shared path must NOT be taken
-        # (1) a model whose FIRST batch has unequal rows decides "per frame" for good
-        m._text_share_mode = None
+        # the verdict is exact for EVERY forward (round-2 ADVICE: no mode carried over from the first batch, nothing noticed a
+        # step late): equal, unequal, equal again -- each call takes the right path
         m.share_text_over_time = True
         a = m.encode_frames(args[0], args[1], args[2], tt)[0]
         m.share_text_over_time = False
         b = m.encode_frames(args[0], args[1], args[2], tt)[0]
         r = rel_l2(a, b)
         differs = not torch.equal(a[:, 0], a[:, 1])       # frame 1 got its own text embedding, not frame 0's broadcast
-        res.append({"name": "unequal token rows fall back to per-frame encoding", "rel_l2": r, "tol": 2e-3,
-                    "ok": r <= 2e-3 and differs and m._text_share_mode == "per_frame"})
-        # (2) a model in "shared" mode (decided on an equal batch) that is later fed unequal rows: no host sync per forward,
-        #     the violation is detected by the asynchronous verdict at the next forward and raises
-        m._text_share_mode = None
+        res.append({"name": "unequal token rows are encoded per frame in the same forward", "rel_l2": r, "tol": 0.0,
+                    "ok": bool(torch.equal(a, b)) and differs})
         m.share_text_over_time = True
-        m.encode_frames(*args)                            # decides "shared"
-        m.encode_frames(*args)                            # steady state: launches the asynchronous check only
-        m.encode_frames(args[0], args[1], args[2], tt)    # wrong assumption: goes unnoticed in this call ...
-        raised = False
-        try:
-            m.encode_frames(*args)                        # ... and raises here
-        except RuntimeError as e:
-            raised = "share_text_over_time" in str(e)
-        res.append({"name": "violated text-sharing assumption raises at the next forward", "rel_l2": 0.0, "tol": 0.0, "ok": raised})
+        again = m.encode_frames(*args)[0]                 # equal rows right after an unequal batch: shared path again
+        res.append({"name": "equal rows after an unequal batch take the shared path again", "rel_l2": rel_l2(again, shared),
+                    "tol": 0.0, "ok": bool(torch.equal(again, shared))})
+        only_one = tt.clone()
+        only_one[:] = inp["text_token"]
+        only_one[-1, -1, -1] = (only_one[-1, -1, -1] + 1) % 49000     # ONE differing token in the last frame of the last sample
+        a = m.encode_frames(args[0], args[1], args[2], only_one)[0]
+        m.share_text_over_time = False
+        b = m.encode_frames(args[0], args[1], args[2], only_one)[0]
+        res.append({"name": "a single differing token switches that forward to per-frame encoding", "rel_l2": rel_l2(a, b),
+                    "tol": 0.0, "ok": bool(torch.equal(a, b))})
     return res
 
 
@@ -308,6 +393,8 @@ def oracle_grads(fx, sd32):
 
 
 GRAD_TOL_FLOOR = 4e-3    # single-kernel gradient tolerance (gpu_checks.TOL_GRAD): bf16 P / dS fragments
+GRAD_MEDIAN_FACTOR = 1.25   # median over the trainable tensors of (HIP gradient error / reference's own bf16 gradient error)
+GRAD_P90_FACTOR = 1.6       # 90th percentile of the same (calibrated in round 3 from the measured distribution)
 
 
 def hip_grad_checks(name="A"):
@@ -336,6 +423,7 @@ def hip_grad_checks(name="A"):
     params = dict(m.named_parameters())
     worst = (0.0, "", 0.0)
     n_checked = 0
+    ratios = []          # rel-L2 of each tensor in units of the REAL reference's own bf16 gradient deviation for that tensor
     for k, gr in ref_grads.items():
         if float(gr.norm()) == 0.0:
             continue
@@ -348,10 +436,21 @@ def hip_grad_checks(name="A"):
         tol = max(GRAD_TOL_FLOOR, 2.0 * max(devs)) if devs else 2e-2
         r = rel_l2(p.grad, gr)
         n_checked += 1
+        if devs:
+            ratios.append(r / max(max(devs), GRAD_TOL_FLOOR / 2.0))
         if r / tol > worst[0]:
             worst = (r / tol, k, r)
         if r > tol:
             res.append({"name": f"grad.{name}.{k}", "rel_l2": r, "tol": tol, "ok": False})
     res.append({"name": f"grad.{name} rel-L2 over {n_checked} parameter tensors (worst vs its tolerance: {worst[1]} {worst[2]:.2e})",
                 "rel_l2": worst[0], "tol": 1.0, "ok": worst[0] <= 1.0 and n_checked > 50})
+    if ratios:
+        rt = torch.tensor(ratios)
+        q = lambda f: float(rt.quantile(f))
+        within = lambda x: float((rt <= x).float().mean())
+        # the distribution, in units of the reference's own bf16 gradient deviation (1.0 = as far from fp32 as the reference's
+        # own bf16 run): the median must sit at the reference's floor, the bulk within 1.25 x of it
+        res.append({"name": f"grad.{name} / reference bf16 deviation: median {q(0.5):.2f}, p90 {q(0.9):.2f}, max {float(rt.max()):.2f}; "
+                            f"within 1.0x {within(1.0):.0%}, 1.25x {within(1.25):.0%}, 1.5x {within(1.5):.0%}",
+                    "rel_l2": q(0.5), "tol": GRAD_MEDIAN_FACTOR, "ok": q(0.5) <= GRAD_MEDIAN_FACTOR and q(0.9) <= GRAD_P90_FACTOR})
     return res

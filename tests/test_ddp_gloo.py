@@ -70,12 +70,15 @@ def _worker(rank, world, port, q, direct):
     for i in ub:                                    # step 3: the used set grew -> held until finish(); step 4: re-learned
         assert not early[3][i] and early[4][i], (early, i)
     # gradient accumulation (utils/train_utils.py:588-607): two half-batches under no_sync() + outside == one full pass
-    m.use_extra = False
+    m.use_extra = True          # (the set learned in steps 3-4: every expected gradient arrives, so buckets can go out early)
     red.zero_grad()
     with red.no_sync():
         ((m(xs[:2]) - ys[:2]) ** 2).mean().mul(0.5).backward()
         assert not any(b["launched"] for b in red.buckets)
     ((m(xs[2:]) - ys[2:]) ** 2).mean().mul(0.5).backward()
+    # round-2 ADVICE: the LAST pass of an accumulation cycle launches buckets during backward (arrival counters are re-armed
+    # when no_sync() exits), it does not leave every collective to finish()
+    assert red._next_launch > 0 and any(b["launched"] for b in red.buckets)
     red.finish()
     acc = {n: red.grad_of(p).clone() for n, p in m.named_parameters()}
     red.zero_grad()

@@ -140,9 +140,32 @@ def test_mask_table_cache_is_per_tensor_object():
     b[:, :5] = -float("inf")
     tb = ops.mask_tables_for(b)
     assert tb is not ta and tb.Lk == ta.Lk - 5
-    ident = id(a)
+    key_a = next(k for k, e in ops._MASK_CACHE.items() if e[4] is ta)
     del a
-    ops._MASK_CACHE[ident] = ops._MASK_CACHE.get(ident, (lambda: None, 0, ta))   # a dead entry under a recyclable id
+    ops._MASK_CACHE[key_a] = (lambda: None, 0, 0, torch.device("cpu"), ta)   # a dead entry under a recyclable id
     c = generate_attention_mask(3, 36, 21, 0, False, True, True, 0.0, 18, 3)
     tc = ops.mask_tables_for(c)
     assert tc is not ta
+
+
+def test_mask_table_cache_hits_for_views_and_misses_after_rebind():
+    """round-2 ADVICE: (a) the (B,1,L,L) call form hands the trunk `mask[0][0]`, a NEW view object on every forward -- the
+    cache is keyed on the base tensor + view geometry, so it hits; (b) a `.data` rebind (module.to(device), flat re-homing)
+    changes the storage address without touching the version counter -- the entry must not be served."""
+    from dreamvla_amd import ops
+    m = generate_attention_mask(3, 36, 21, 0, False, False, False, 0.0, 18, 3)
+    m4 = torch.nn.Parameter(m[None, None].expand(2, 1, -1, -1).contiguous(), requires_grad=False)
+    t1 = ops.mask_tables_for(m4[0][0])
+    t2 = ops.mask_tables_for(m4[0][0])
+    assert t2 is t1
+    t3 = ops.mask_tables_for(m4[1][0])              # same base, other offset: its own entry (same content here)
+    assert t3 is not t1 and torch.equal(t3.bits_q, t1.bits_q)
+    other = m4.data.clone()
+    other[..., :5] = -float("inf")
+    m4.data = other                                 # rebind: version unchanged, address changed
+    t4 = ops.mask_tables_for(m4[0][0])
+    assert t4 is not t1 and t4.Lk == t1.Lk - 5
+    with torch.no_grad():
+        m4[..., 5:7] = -float("inf")                # in-place edit on the parameter: version bump
+    t5 = ops.mask_tables_for(m4[0][0])
+    assert t5 is not t4 and t5.Lk == t4.Lk - 2
