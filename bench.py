@@ -55,7 +55,7 @@ def label_heads(heads):
 
 def cpu_baseline(heads, S):
     """Oracle forward + loss + backward on the host cores: BASELINE configs[0] (B = 2, S = 7, fp32), one un-timed
-    warm-up step, then two timed steps (bounded: ~20-30 s on 16 threads)."""
+    warm-up step, then three timed steps (bounded: ~25-35 s on 16 threads)."""
     from oracle import model_ref as M
     from oracle import weights
     from dreamvla_amd.dreamvla_model import DreamVLA
@@ -76,7 +76,7 @@ def cpu_baseline(heads, S):
     g = torch.Generator().manual_seed(3)
     noise = torch.randn(8 * B * S, 3, 7, generator=g)
     tstep = torch.randint(0, 100, (8 * B * S,), generator=g)
-    nsteps = 2
+    nsteps = 3
     t_fwd = 0.0
     t0 = None
     for it in range(nsteps + 1):
@@ -120,10 +120,14 @@ def main():
     ap.add_argument("--phase", default="finetune", choices=["finetune", "pretrain"],
                     help="pretrain: the attention mask is regenerated every training step (dreamvla_model.py:610-628) -- here "
                          "as device-side tables from the rule (SURVEY 8 f4); same shapes, for the f4 timing comparison")
-    ap.add_argument("--tune-steps", type=int, default=22,
+    ap.add_argument("--plan", default=None, metavar="FILE",
+                    help="replay the GEMM configuration choices saved by --save-plan (no tuner trials: for profiler / counter passes "
+                         "of the tuned step); default: $DVLA_GEMM_PLAN")
+    ap.add_argument("--save-plan", default=None, metavar="FILE", help="write the tuner's locked choices after the tune steps")
+    ap.add_argument("--tune-steps", type=int, default=25,
                     help="untimed steps BEFORE the warm-up in which dreamvla_amd.ops.GemmTuner tries each GEMM kernel "
                          "configuration once per problem shape and locks the fastest (setup, like building the extension); "
-                         "seven candidates x GemmTuner.ROUNDS (3) trials (median): shapes that occur once per step need 22 steps to lock")
+                         "eight candidates x GemmTuner.ROUNDS (3) trials (median): shapes that occur once per step need 24 steps to lock")
     ap.add_argument("--torch-profile", default=None, metavar="FILE",
                     help="diagnostics: after the timed region, one more step under torch.profiler; ATen / autograd operators by "
                          "device time (with input shapes) are written to FILE")
@@ -220,10 +224,15 @@ def main():
         torch.cuda.synchronize()
 
     from dreamvla_amd.ops import GemmTuner
-    if GemmTuner.enabled:
+    plan = args.plan or os.environ.get("DVLA_GEMM_PLAN")
+    if plan and os.path.exists(plan):
+        GemmTuner.load_plan(plan)
+    elif GemmTuner.enabled:
         for _ in range(args.tune_steps):
             step()
         sync()
+    if args.save_plan and rank == 0:
+        GemmTuner.save_plan(args.save_plan)
     for _ in range(args.warmup):
         step()
     sync()
@@ -276,7 +285,9 @@ def main():
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command (tests/pmc_traffic.sh), stored with the
         # commit they were measured on; a file from another tree is reported as stale, never presented as current
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)

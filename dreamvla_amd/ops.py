@@ -156,7 +156,7 @@ class GemmTuner:
     library, so every trial is valid.  Disable with DVLA_GEMM_AUTOTUNE=0 (the cost model is then used for every call).
     Every candidate is a hand-written HIP kernel of libdvla_hip.so: no vendor GEMM library is linked or offered (the
     hipBLASLt yardstick lives in libdvla_cmp.so and is driven only by tests/library_yardstick.py)."""
-    CANDIDATES = tuple(int(v) for v in os.environ.get("DVLA_GEMM_CANDIDATES", "0,4,6,7,8,9,2").split(","))
+    CANDIDATES = tuple(int(v) for v in os.environ.get("DVLA_GEMM_CANDIDATES", "0,4,6,7,8,9,10,2").split(","))
     ROUNDS = int(os.environ.get("DVLA_GEMM_TUNE_ROUNDS", "3"))
     enabled = os.environ.get("DVLA_GEMM_AUTOTUNE", "1") != "0" and os.environ.get("DVLA_GEMM_VARIANT") is None
     table = {}      # key -> locked variant
@@ -194,6 +194,22 @@ class GemmTuner:
     @classmethod
     def reset(cls):
         cls.table.clear(); cls.trials.clear()
+
+    @classmethod
+    def save_plan(cls, path):
+        """the locked choices as JSON (problem key -> configuration): a later process replays exactly this kernel mix with
+        `load_plan` -- e.g. the rocprofv3 counter passes of the tuned step, which must not contain tuner trials"""
+        import json
+        with open(path, "w") as f:
+            json.dump([[list(k), int(v)] for k, v in cls.table.items()], f)
+
+    @classmethod
+    def load_plan(cls, path, freeze=True):
+        import json
+        with open(path) as f:
+            for k, v in json.load(f):
+                cls.table[tuple(bool(x) if isinstance(x, bool) else int(x) for x in k)] = int(v)
+        cls.frozen = bool(freeze)     # keys the plan does not know take the cost model (no trials)
 
     @classmethod
     def summary(cls):

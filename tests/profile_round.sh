@@ -15,19 +15,24 @@ BENCH="python $REPO/bench.py --no-cpu-baseline --no-eager-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_step -f csv -- $BENCH --steps 3 --warmup 1 --no-roofline > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 python $REPO/tests/prof_summary.py $OUT/${TAG}_prof_step $OUT/${TAG}_step_summary.txt > /dev/null 2>&1
 cp $(find $OUT/${TAG}_prof_step -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null
-# 2. GEMM traffic: one step with the cost-model configuration (no tuner trials), FETCH and WRITE in separate passes
+# 2. GEMM traffic of the TUNED step: the tuner's locked choices are saved by an ordinary run and replayed (no trials) under the
+#    counters, FETCH and WRITE in separate passes; the same run writes the per-shape breakdown the algorithmic bytes come from
+DVLA_GEMM_BREAKDOWN=$OUT/${TAG}_gemm_breakdown.json $BENCH --steps 3 --warmup 1 --save-plan $OUT/${TAG}_gemm_plan.json > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_err.log
 for C in FETCH_SIZE WRITE_SIZE; do
-  DVLA_GEMM_AUTOTUNE=0 rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$C -f csv -- $BENCH --steps 1 --warmup 0 --tune-steps 0 --no-roofline > $OUT/${TAG}_pmc_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$C -f csv -- $BENCH --steps 1 --warmup 1 --plan $OUT/${TAG}_gemm_plan.json --no-roofline > $OUT/${TAG}_pmc_$C.log 2>&1
   python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_$C $OUT/${TAG}_pmc_$C.json > $OUT/${TAG}_pmc_$C.txt 2>&1
 done
+# 2b. GEMM matrix-pipe busy over the tuned step
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_gemm_mfma -f csv -- $BENCH --steps 1 --warmup 1 --plan $OUT/${TAG}_gemm_plan.json --no-roofline > $OUT/${TAG}_pmc_gemm_mfma.log 2>&1
+python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_gemm_mfma $OUT/${TAG}_pmc_gemm_mfma.json > $OUT/${TAG}_pmc_gemm_mfma.txt 2>&1
 # 3. attention: matrix-pipe busy per kernel
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_attn -f csv -- python $REPO/tests/gpu_pmc_attn.py > $OUT/${TAG}_pmc_attn.log 2>&1
 python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_attn $OUT/${TAG}_pmc_attn.json > $OUT/${TAG}_pmc_attn.txt 2>&1
 # 4. LayerNorm: HBM bytes on > 256 MiB working sets
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_ln_$C -f csv -- python $REPO/tests/gpu_pmc_ln.py > $OUT/${TAG}_pmc_ln_$C.log 2>&1
-  python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_ln_$C $OUT/${TAG}_pmc_ln_$C.json > $OUT/${TAG}_pmc_ln_$C.txt 2>&1
+  python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_ln_$C $OUT/${TAG}_pmc_ln_$C.json --by-grid > $OUT/${TAG}_pmc_ln_$C.txt 2>&1
 done
 # keep the merge small: drop the raw traces
-rm -rf $OUT/${TAG}_prof_step $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_attn $OUT/${TAG}_pmc_ln_FETCH_SIZE $OUT/${TAG}_pmc_ln_WRITE_SIZE
+rm -rf $OUT/${TAG}_pmc_gemm_mfma $OUT/${TAG}_prof_step $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_attn $OUT/${TAG}_pmc_ln_FETCH_SIZE $OUT/${TAG}_pmc_ln_WRITE_SIZE
 ls -la $OUT | head -40
