@@ -742,7 +742,7 @@ inline int epi_class(const GemmKArgs& a) {
   if (a.split_k > 1 || a.c_f32) return EPI_F32;
   const bool dact = a.dact_aux != nullptr, res = a.residual != nullptr;
   if (!dact && !res) return a.act == ACT_NONE ? EPI_P0 : a.act == ACT_GELU_ERF ? EPI_P_ERF : a.act == ACT_GELU_TANH ? EPI_P_TANH : EPI_GEN;
-  if (a.act != ACT_NONE || (dact && res)) return EPI_GEN;
+  if (a.act != ACT_NONE || (dact && res) || a.preact != nullptr) return EPI_GEN;
   if (res) return EPI_A0;
   return a.dact == ACT_GELU_ERF ? EPI_A_ERF : a.dact == ACT_GELU_TANH ? EPI_A_TANH : EPI_GEN;
 }
@@ -754,6 +754,38 @@ __device__ __forceinline__ void act_fwd4_sel(float (&z)[4], int runtime_act) {
 template <int ACT>
 __device__ __forceinline__ void act_bwd8_mul_sel(float (&v)[8], const float (&a)[8], int runtime_act) {
   if constexpr (ACT > 0) act_bwd8_mul_c<ACT>(v, a); else act_bwd8_mul(v, a, runtime_act);
+}
+
+// ---- whole-line stores.  After the half-wave exchange a lane holds, per 32-row slab, four 16-byte PIECES of its row: piece c
+// (c = 2 i + q: column group i, quad pair q) covers bytes 16 (2c + g) .. + 15 of the row's 128-byte line (a wave's 64 bf16
+// columns ARE one cache line per row).  Stored as they are, one instruction writes 32 rows x 32 B: 32 partial lines.  Measured
+// with tests/probes/store_probe.cpp --percu (round 3): that pattern sustains 17.7 B/clk per CU however idle the rest of the chip
+// is, against 55 B/clk for instructions that write 8 whole lines -- the store tail of a 256 x 256 tile (128 KiB, 256 KiB with a
+// pre-activation) is bound by the CU's OWN store path, not by HBM, and the main loop's in-order vmcnt waits expose all of it
+// (a wave cannot wait for a DMA piece issued after its stores without waiting for the stores: gemm_phase.h).
+// quad_transpose exchanges the piece index c with the two low lane bits inside every quad of lanes (two rounds of DPP
+// quad_perm + select: 32 VALU, no LDS): afterwards lane 4a + b holds in P[c] piece 2b + g of ROW 4a + c, i.e. instruction c
+// writes rows {4a + c} x all 8 pieces = 8 whole lines.  The same exchange (an involution) turns whole-line LOADS of a
+// store-layout operand (residual, act' operand) into the per-row pieces the accumulator layout needs.
+__device__ __forceinline__ uint32_t dpp_quad_xor1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t dpp_quad_xor2(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false); }
+__device__ __forceinline__ void quad_transpose(u32x4 (&P)[4], int lane) {
+  const bool o0 = (lane & 1) != 0, o1 = (lane & 2) != 0;
+  u32x4 T[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t t = dpp_quad_xor1(P[c ^ 1][d]);
+      T[c][d] = (((c & 1) != 0) != o0) ? t : P[c][d];
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t t = dpp_quad_xor2(T[c ^ 2][d]);
+      P[c][d] = (((c & 2) != 0) != o1) ? t : T[c][d];
+    }
 }
 
 template <int TM, int EPI>
@@ -769,6 +801,133 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
   const bool has_res = epi_res(EPI) > 0 || (epi_res(EPI) < 0 && p.residual != nullptr);
   const bool has_bias = !split_out && p.bias != nullptr;
   const bool two_aux = has_dact && has_res;   // none of the model's GEMMs has both: the act' operand is then read late
+
+  // ================= whole-line path: every bf16 class except EPI_GEN (see quad_transpose above) =================
+  if constexpr (EPI != EPI_F32 && EPI != EPI_GEN) {
+    const int qb = lane & 3, qa = l31 >> 2;
+    const int64_t ncol_line = n_base + 8 * (2 * qb + g);      // this lane's 16 bytes of a line in the store / load pattern
+    // the bias goes into the accumulators once, up front (no live bias registers, no load behind a store)
+    if (has_bias) {
+      static_for<2>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        float bf[4][4];
+        if (p.bias_f32) {
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
+            bf[rq][0] = b.x; bf[rq][1] = b.y; bf[rq][2] = b.z; bf[rq][3] = b.w;
+          }
+        } else {
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.bias) + n_base + 32 * i + 8 * rq + 4 * g);
+            unpack2(b.x, bf[rq][0], bf[rq][1]); unpack2(b.y, bf[rq][2], bf[rq][3]);
+          }
+        }
+        static_for<TM>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * rq + e] += bf[rq][e];
+        });
+      });
+    }
+    // whole lines of the store-layout operand of row slab j: instruction c reads rows {4a + c}, this lane's piece 2b + g
+    auto load_aux_lines = [&](int j, u32x4 (&L)[4]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int64_t m = m_base + j * 32 + 4 * qa + c;
+        const int64_t mc = m < p.M ? m : p.M - 1;
+        const int64_t rr = (has_res && p.res_rows > 0) ? (int64_t)((uint32_t)mc % (uint32_t)p.res_rows) : mc;
+        const bf16_t* src = has_res ? p.residual + rr * p.ld_res : p.dact_aux + mc * p.ld_dact;
+        L[c] = *reinterpret_cast<const u32x4*>(src + ncol_line);
+      }
+    };
+    u32x4 nx[AUXV ? 4 : 1];      // raw lines of the NEXT row slab: requested one slab ahead, in front of this slab's stores
+    if constexpr (AUXV) load_aux_lines(0, nx);
+    static_for<TM>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      u32x4 ax[AUXV ? 4 : 1];
+      if constexpr (AUXV) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ax[c] = nx[c];
+        quad_transpose(ax, lane);            // -> ax[c] = bytes 16 (2c + g) .. of THIS lane's row (the old store-layout vector)
+      }
+      const int64_t m = m_base + j * 32 + l31;
+      uint32_t rowkey = 0;
+      if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
+      u32x4 PC[4], PP[4];
+      static_for<4>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, i = c >> 1, q = c & 1;
+        float z0[4], z1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { z0[e] = acc[i][j][8 * q + e]; z1[e] = acc[i][j][8 * q + 4 + e]; }
+        if (p.preact) {
+          uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
+          // the activation sees the stored (bf16) pre-activation
+          unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
+          swap_halves(a0, b0); swap_halves(a1, b1);
+          PP[c] = u32x4{a0, a1, b0, b1};
+        }
+        act_fwd4_sel<epi_act(EPI)>(z0, p.act);
+        act_fwd4_sel<epi_act(EPI)>(z1, p.act);
+        if (p.has_drop) {
+          const uint32_t n = (uint32_t)(n_base + 32 * i + 16 * q + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t h0 = drop_hash_rk(rowkey, n + e), h1 = drop_hash_rk(rowkey, n + 8 + e);
+            z0[e] = (h0 >= p.drop_thr) ? z0[e] * p.drop_scale : 0.f;
+            z1[e] = (h1 >= p.drop_thr) ? z1[e] * p.drop_scale : 0.f;
+          }
+        }
+        uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
+        if constexpr (AUXV) {
+          // act' / residual are applied to the ROUNDED branch value (the reference materialises it as a bf16 tensor)
+          unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
+          uint32_t ux = ax[c][0], uy = ax[c][1], uz = ax[c][2], uw = ax[c][3];
+          swap_halves(ux, uz); swap_halves(uy, uw);   // -> accumulator layout: (x, y) = quad 2q, (z, w) = quad 2q+1
+          if (has_dact) {
+            float a8[8];
+            unpack2(ux, a8[0], a8[1]); unpack2(uy, a8[2], a8[3]); unpack2(uz, a8[4], a8[5]); unpack2(uw, a8[6], a8[7]);
+            float v8[8] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3]};
+            act_bwd8_mul_sel<epi_dact(EPI)>(v8, a8, p.dact);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { z0[e] = v8[e]; z1[e] = v8[4 + e]; }
+          } else {
+            float r0, r1;
+            unpack2(ux, r0, r1); z0[0] += r0; z0[1] += r1;
+            unpack2(uy, r0, r1); z0[2] += r0; z0[3] += r1;
+            unpack2(uz, r0, r1); z1[0] += r0; z1[1] += r1;
+            unpack2(uw, r0, r1); z1[2] += r0; z1[3] += r1;
+          }
+          a0 = pack2bf(z0[0], z0[1]); a1 = pack2bf(z0[2], z0[3]); b0 = pack2bf(z1[0], z1[1]); b1 = pack2bf(z1[2], z1[3]);
+        }
+        swap_halves(a0, b0); swap_halves(a1, b1);
+        PC[c] = u32x4{a0, a1, b0, b1};
+        // the next slab's lines are requested HALF WAY through this one: column group 0's accumulators and operand pieces are
+        // dead by now (a full slab of look-ahead next to 128 accumulators spilled 15-22 registers), and the request still sits
+        // in front of this slab's stores, so waiting for it never waits for them
+        if constexpr (AUXV && c == 1 && j + 1 < TM) load_aux_lines(j + 1, nx);
+      });
+      if (p.preact) {
+        quad_transpose(PP, lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t mr = m_base + j * 32 + 4 * qa + c;
+          if (mr < p.M) *reinterpret_cast<u32x4*>(p.preact + mr * p.ld_preact + ncol_line) = PP[c];
+        }
+      }
+      quad_transpose(PC, lane);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int64_t mr = m_base + j * 32 + 4 * qa + c;
+        if (mr < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + mr * p.ldc + ncol_line) = PC[c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    return;
+  }
 
   // Store-layout operand vectors (EPI_AUX): requested per BATCH of JB = 2 row slabs (8 vectors = 32 VGPRs per lane) before
   // that batch's first store.  A 128-row wave block (TM = 4) therefore has ONE point per tile where loads follow stores

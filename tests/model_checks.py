@@ -11,6 +11,17 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 BF = torch.bfloat16
 
 
+def report(results):
+    """append every metric of a check to $DVLA_PARITY_REPORT (JSON lines) -- the measured values DESIGN.md quotes come from it"""
+    path = os.environ.get("DVLA_PARITY_REPORT")
+    if not path:
+        return
+    import json
+    with open(path, "a") as f:
+        for r in results:
+            f.write(json.dumps({k: v for k, v in r.items() if isinstance(v, (int, float, str, bool, list, type(None)))}) + "\n")
+
+
 def rel_l2(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     if not torch.isfinite(a).all():
@@ -62,20 +73,25 @@ def output_tolerances(fx, fallback):
     for i in range(len(OUTPUT_NAMES)):
         ds = [r[i] for r in recs if r is not None and i < len(r) and r[i] is not None]
         if not ds:
-            out.append((fallback, None))
+            out.append((fallback, None, None))
         else:
             rel = max(d["rel_l2"] for d in ds)
             mab = max(d["max_abs"] for d in ds)
-            out.append((max(TOL_FLOOR, REF_DEV_FACTOR * rel), max(1.5 * mab, 3.0 * 2.0 ** -8 * ds[0]["absmax"])))
+            out.append((max(TOL_FLOOR, REF_DEV_FACTOR * rel), max(1.5 * mab, 3.0 * 2.0 ** -8 * ds[0]["absmax"]), rel))
     return out
+
+
+SMALL_OUTPUT = 256          # elements
+SMALL_OUTPUT_FACTOR = 2.0   # an output of a dozen values (fixture A's gripper action: B * S * 3 = 12) is a 12-sample estimate of
+                            # the deviation: its rel-L2 scatters by tens of per cent from run to run -- 2 x instead of 1.25 x there
 
 
 def compare_outputs(got, want_list, tol, tag, fx=None):
     """got: 10-tuple of tensors/None; want_list: golden list (tensors, None or sampled dicts) -> list of metric dicts.
     With `fx` the tolerance of each output comes from the fixture (output_tolerances); `tol` is the fallback."""
-    tols = output_tolerances(fx, tol) if fx is not None else [(tol, None)] * len(OUTPUT_NAMES)
+    tols = output_tolerances(fx, tol) if fx is not None else [(tol, None, None)] * len(OUTPUT_NAMES)
     res = []
-    for nm, g, w, (t_rel, t_abs) in zip(OUTPUT_NAMES, got, want_list, tols):
+    for nm, g, w, (t_rel, t_abs, dev) in zip(OUTPUT_NAMES, got, want_list, tols):
         if w is None:
             assert g is None, f"{tag}.{nm}: expected None"
             continue
@@ -92,6 +108,8 @@ def compare_outputs(got, want_list, tol, tag, fx=None):
             st = t_rel if fx is None else max(t_rel, 3e-3)
             res.append({"name": f"{tag}.{nm}", "rel_l2": r, "tol": st, "ok": r <= st})
             continue
+        if dev is not None and gv.numel() < SMALL_OUTPUT:
+            t_rel = max(t_rel, SMALL_OUTPUT_FACTOR * dev)
         r = rel_l2(gv, wv)
         max_abs = float((gv - wv).abs().max())
         ok = r <= t_rel and (t_abs is None or max_abs <= t_abs)
@@ -294,14 +312,17 @@ def hip_model_batch32_checks():
         o_r = M.dreamvla_forward(sd32, cfg, inp["image_primary"][b:b + 1], inp["image_wrist"][b:b + 1], inp["state"][b:b + 1],
                                  inp["text_token"][b:b + 1], action_label=lab[b:b + 1], mode="train",
                                  dit_noise=noise[rows_b], dit_timestep=tstep[rows_b])
-        for nm, o_h, o_o, (t_rel, t_abs) in zip(OUTPUT_NAMES, out, o_r, tols):
+        for nm, o_h, o_o, (t_rel, t_abs, _dev) in zip(OUTPUT_NAMES, out, o_r, tols):
             if o_o is None or o_h is None:
                 continue
             if o_o.dim() == 0:
                 if nm == "arm_action":       # (slot 1 is the same scalar)
+                    # (another sample than the one the reference's deviation was recorded on: a 1176-value mean of squared errors
+                    #  whose bf16 deviation varies from sample to sample -- 2 x the recorded one instead of 1.25 x)
                     gb, wb = dit_loss(rows_b), float(o_o)
-                    res.append({"name": f"hip.C@B32.row{b}.action_mse_err (oracle)", "rel_l2": abs(gb - wb), "tol": tol,
-                                "ok": abs(gb - wb) <= tol, "want": wb, "got": gb})
+                    tol_b = max(1e-3 * max(1.0, abs(wb)), 2.0 * ref_dev)
+                    res.append({"name": f"hip.C@B32.row{b}.action_mse_err (oracle)", "rel_l2": abs(gb - wb), "tol": tol_b,
+                                "ok": abs(gb - wb) <= tol_b, "want": wb, "got": gb})
                 continue
             gh = o_h[b * S:(b + 1) * S]
             rr = rel_l2(gh, o_o)

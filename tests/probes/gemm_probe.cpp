@@ -230,6 +230,15 @@ int main(int argc, char** argv) {
       CK(hipDeviceSynchronize());
       std::vector<unsigned long long> h(512);
       CK(hipMemcpy(h.data(), q.ws.p, 512 * 8, hipMemcpyDeviceToHost));
+      if (getenv("DVLA_STAMPS_ALL")) {   // every recorded K-tile: start (relative to K-tile 0), length, gap to the next one (tile boundaries show up as gaps)
+        for (int g = 0; g < 2; ++g)
+          for (int kt = 0; kt < 31; ++kt) {
+            const unsigned long long* e = &h[g * 256 + kt * 8];
+            printf("variant %d group %d K-tile %2d: start %7lld  length %5lld  gap-to-next %6lld\n", v, g, kt, (long long)(e[0] - h[g * 256]),
+                   (long long)(e[7] - e[0]), (long long)(e[8] - e[7]));
+          }
+        continue;
+      }
       for (int g = 0; g < 2; ++g)
         for (int kt = 3; kt < 7; ++kt) {
           const unsigned long long* e = &h[g * 256 + kt * 8];

@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
@@ -22,9 +23,13 @@ template <int PAT>
 __global__ __launch_bounds__(512) void store_kernel(unsigned short* C, int64_t M, int64_t N, int tiles_m, int tiles_n, int reps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave & 1, wn = wave >> 1;             // 2 x 4 waves of 128 x 64
-  const int nitems = tiles_m * tiles_n;
-  const int grid = gridDim.x;
-  const int perm = (grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const bool one_xcd = (reps >> 30) & 1;     // --percu: only the workgroups of XCD 0 (blockIdx % 8 == 0) work
+  if (one_xcd && (blockIdx.x & 7) != 0) return;
+  const int nitems = ((reps >> 8) & 0x3fffff) ? ((reps >> 8) & 0x3fffff) : tiles_m * tiles_n;   // (--percu: item limit in the upper bits)
+  reps &= 0xff;
+  const int grid = one_xcd ? (int)gridDim.x / 8 : (int)gridDim.x;
+  const int perm = one_xcd ? (int)(blockIdx.x >> 3)
+                           : ((grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
   const uint4 v = make_uint4(0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + wave);
   const u32x4 vv = {v.x, v.y, v.z, v.w};
   for (int it = 0;; ++it) {
@@ -100,9 +105,48 @@ static void run(const char* name, unsigned short* C, int64_t M, int64_t N, int c
   fflush(stdout);
 }
 
-int main() {
+// --percu: what ONE CU can push when the others are idle (is the epilogue's store tail bound by the CU's own store path or by
+// the chip's write bandwidth?): G workgroups (G = 8 ... 256) each write 64 tiles of a 20832 x 4096 matrix; GB/s per workgroup.
+template <int PAT>
+static void run_percu(const char* name, unsigned short* C, int64_t M, int64_t N, int G, bool one_xcd = false) {
+  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  const int items = 64 * G < tiles_m * tiles_n ? 64 * G : tiles_m * tiles_n;
+  for (int r = 0; r < 5; ++r) {
+    CK(hipEventRecord(e0, 0));
+    // tiles_m / tiles_n describe the whole matrix; only the first `items` tile ids are visited (grid = G)
+    hipLaunchKernelGGL(store_kernel<PAT>, dim3(one_xcd ? G * 8 : G), dim3(512), 0, 0, C, M, N, tiles_m, tiles_n,
+                       1 | (items << 8) | (one_xcd ? (1 << 30) : 0));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r && ms < best) best = ms;
+  }
+  const double bytes = (double)items * 256 * 256 * 2;
+  printf("{\"percu\": \"%s%s\", \"workgroups\": %d, \"min_us\": %.1f, \"GBps_per_workgroup\": %.1f, \"TBps_total\": %.2f}\n", name, one_xcd ? " [all on ONE XCD]" : "", G, best * 1e3,
+         bytes / G / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 1e12);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
+  if (argc > 1 && !strcmp(argv[1], "--percu")) {
+    const int64_t M = 20832, N = 4096;
+    unsigned short* C; CK(hipMalloc(&C, (size_t)(M + 256) * N * 2));
+    for (int G : {8, 16, 32, 64, 128, 256}) {
+      run_percu<3>("contiguous 128-KiB blocks", C, M, N, G);
+      run_percu<1>("8 rows x 128 B per instruction", C, M, N, G);
+      run_percu<0>("32 rows x 32 B per instruction (half exchange)", C, M, N, G);
+      run_percu<2>("32 rows x 16 B per instruction (8-byte stores)", C, M, N, G);
+    }
+    for (int G : {4, 16, 32}) {      // the same number of workgroups packed onto one XCD: is the limit the XCD's path to the fabric?
+      run_percu<1>("8 rows x 128 B per instruction", C, M, N, G, true);
+      run_percu<0>("32 rows x 32 B per instruction (half exchange)", C, M, N, G, true);
+    }
+    CK(hipFree(C));
+    return 0;
+  }
   const int64_t shapes[][2] = {{20832, 4096}, {20832, 1024}, {88256, 3072}, {88256, 768}};
   for (auto& sh : shapes) {
     const int64_t M = sh[0], N = sh[1];

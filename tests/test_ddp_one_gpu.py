@@ -90,13 +90,15 @@ def _worker(rank, world, port, fixture, q):
         if step == 0:
             fired = {id(bp) for b in red.buckets for bp, f in zip(b["params"], b["fired"]) if f}
             unused = sorted(n for n, p in m.named_parameters() if p.requires_grad and id(p) not in fired)
-        grads = {n: red.grad_of(p).detach().float().cpu().clone() for n, p in m.named_parameters() if p.requires_grad} if step == 0 else None
+        # (numpy, not tensors: a tensor put on a multiprocessing queue is shared through a file the SENDER owns, and the sender
+        #  may be gone before the parent reads it)
+        grads = {n: red.grad_of(p).detach().float().cpu().numpy().copy() for n, p in m.named_parameters() if p.requires_grad} if step == 0 else None
         if step == 0 and rank == 0:
             q.put(("grads", grads))
         opt.step()
     torch.cuda.synchronize()
     if rank == 0:
-        q.put(("final", {n: p.detach().float().cpu().clone() for n, p in m.named_parameters() if p.requires_grad}))
+        q.put(("final", {n: p.detach().float().cpu().numpy().copy() for n, p in m.named_parameters() if p.requires_grad}))
         q.put(("meta", {"early": early, "buckets": len(red.buckets), "unused": unused, "copied": red.copied}))
     dist.barrier()
     dist.destroy_process_group()
@@ -153,7 +155,7 @@ def test_two_ranks_on_one_gpu_match_the_full_batch_run(fixture):
     worst = (0.0, "")
     n = 0
     for name, g_ref in ref_grads.items():
-        g = got["grads"][name]
+        g = torch.from_numpy(got["grads"][name])
         den = float(g_ref.norm())
         if den == 0.0:
             assert float(g.norm()) == 0.0, name
@@ -171,8 +173,9 @@ def test_two_ranks_on_one_gpu_match_the_full_batch_run(fixture):
     # mis-homed flat buffer or a stale shadow is O(1)), and parameters without a gradient must not have moved at all
     num = den = 0.0
     for name, p_ref in ref_final.items():
-        num += float((got["final"][name] - p_ref).norm()) ** 2
+        fin = torch.from_numpy(got["final"][name])
+        num += float((fin - p_ref).norm()) ** 2
         den += float((p_ref - init[name]).norm()) ** 2
         if name in meta["unused"]:
-            assert torch.equal(got["final"][name], init[name]) and torch.equal(p_ref, init[name]), name
+            assert torch.equal(fin, init[name]) and torch.equal(p_ref, init[name]), name
     assert den > 0 and (num / den) ** 0.5 < 0.35, (num, den)

@@ -6,6 +6,7 @@ from tests import model_checks as C
 
 
 def _assert_all(results):
+    C.report(results)
     bad = [r for r in results if not r["ok"]]
     assert not bad, bad
 
