@@ -844,11 +844,11 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
         L[c] = *reinterpret_cast<const u32x4*>(src + ncol_line);
       }
     };
-    u32x4 nx[AUXV ? 4 : 1];      // raw lines of the NEXT row slab: requested one slab ahead, in front of this slab's stores
+    u32x4 nx[4];      // (unused, and removed by the compiler, in the classes without a store-layout operand) raw lines of the NEXT row slab: requested one slab ahead, in front of this slab's stores
     if constexpr (AUXV) load_aux_lines(0, nx);
     static_for<TM>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      u32x4 ax[AUXV ? 4 : 1];
+      u32x4 ax[4];
       if constexpr (AUXV) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) ax[c] = nx[c];
