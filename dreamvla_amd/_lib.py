@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvla_hip.so")
+# DVLA_LIB: load another build of the library (same-box A/B measurements of kernel changes; not a product knob)
+LIB_PATH = os.environ.get("DVLA_LIB") or os.path.join(_HERE, "libdvla_hip.so")
 
 DT_BF16, DT_F32 = 0, 1
 ABI_VERSION = 3          # DVLA_ABI_VERSION of include/dvla.h
