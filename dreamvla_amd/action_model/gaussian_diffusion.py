@@ -138,6 +138,30 @@ class GaussianDiffusion:
         return img
 
 
+class FMDiffusion:
+    """Euler integrator of the flow-matching head (/root/reference/models/action_model/respace.py:118-191): starts from FRESH
+    noise (the `noise` the caller passes is ignored, as upstream: its positional slot is swallowed by *args), forces the
+    guidance scale to 1 and takes num_timesteps steps x <- x + u(x, i / n) / n.  Upstream hard-codes device='cuda' for the
+    start noise; here it is drawn on `device` (the same thing on a GPU box)."""
+
+    def __init__(self, num_timesteps):
+        self.num_timesteps = int(num_timesteps)
+
+    def ddim_sample_loop(self, model, shape, *args, noise=None, clip_denoised=True, model_kwargs=None, device=None,
+                         progress=False, **kwargs):
+        model_kwargs = dict(model_kwargs or {})
+        if "cfg_scale" in model_kwargs:
+            model_kwargs["cfg_scale"] = 1.0
+        final = th.randn(*shape, device=device)
+        delta = 1.0 / self.num_timesteps
+        for i in range(self.num_timesteps):
+            t = th.full((shape[0],), float(i) / self.num_timesteps, device=device, dtype=th.float32)
+            with th.no_grad():
+                ut = model(final, t, **model_kwargs)
+            final = final + delta * ut.to(final.dtype)
+        return final
+
+
 class SpacedDiffusion(GaussianDiffusion):
     """respace.py:67-116,193-205: keep a subset of timesteps, re-derive betas, feed the model ORIGINAL indices."""
 

@@ -123,6 +123,10 @@ FULL_CFGS = {
 }
 
 
+# the flow-matching action head (--use_fm, eval_libero.py:76 / train.py:96; models/action_model/action_model.py:86-170)
+FULL_CFGS["F"] = dict(FULL_CFGS["B"], use_fm=True)
+
+
 # the BENCHMARKED configuration (BASELINE configs[1], scripts/CALVIN_ABC_D/DreamVLA/finetune.sh): S = 7, 24 layers, head set
 # C = obs + depth + sam dream heads + DiT action head; L = 651, key compaction 651 -> 378 on the HIP side
 FULL_CFGS["C"] = dict(finetune_type="calvin", sequence_length=7, num_resampler_query=16, num_obs_token_per_image=9,
@@ -169,7 +173,7 @@ def full_fixture(name):
         g = torch.Generator().manual_seed(99)
         n_rep = 8 * B * S
         noise = torch.randn(n_rep, 3, 7, generator=g).to(BF).float()
-        tstep = torch.randint(0, 100, (n_rep,), generator=g)
+        tstep = torch.randint(0, 10 if cfg.get("use_fm") else 100, (n_rep,), generator=g)
         test_noise = torch.randn(B * S, 3, 7, generator=g).to(BF).float()
         fx.update(dit_noise=noise, dit_timestep=tstep, test_noise=test_noise)
         torch.randn_like = lambda x, **k: noise.clone()
@@ -181,7 +185,13 @@ def full_fixture(name):
             fx["train"] = [None if o is None else o.detach().clone() for o in out]
             if cfg["use_dit_head"]:
                 torch.randn_like, torch.randint = real["randn_like"], real["randint"]
-                torch.randn = lambda *a, **k: test_noise.clone()
+                # DDIM: the model draws (bs, 3, 7) and doubles it.  Flow matching: FMDiffusion ignores that and draws its own
+                # (2 bs, 3, 7) start noise -- on device='cuda', hard-coded (respace.py:139): the patched randn ignores the device
+                # and hands out the same noise for both halves
+                def fake_randn(*a, **k):
+                    n0 = a[0][0] if isinstance(a[0], (tuple, list, torch.Size)) else a[0]
+                    return test_noise.clone() if n0 == B * S else torch.cat([test_noise, test_noise], 0)
+                torch.randn = fake_randn
                 out = m(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], mode="test")
                 fx["test"] = [None if o is None else o.detach().clone() for o in out]
                 # the reference's OWN bf16 path (train.py --precision amp_bf16 -> autocast) on the same inputs / noise, five
@@ -223,6 +233,10 @@ def _patch_q_sample(m):
         return
     orig = am.diffusion.q_sample
     am.diffusion.q_sample = lambda x, t, noise=None: orig(x, t, noise).to(x.dtype)
+    if type(am).__name__ == "ActionModelFM":
+        # same defect in the flow-matching loss (action_model.py:127-131): the float32 `timestep` promotes x_t to float32
+        net_fwd = am.net.forward
+        am.net.forward = lambda x, t, z: net_fwd(x.to(next(am.net.parameters()).dtype), t, z)
 
 
 def _out_rel(a, b):

@@ -137,6 +137,33 @@ def dit_loss(sd, p, x, z, noise, timestep, depth=12, heads=12):
     return ((dit(sd, p, x_t, timestep, z, depth, heads) - noise) ** 2).mean()
 
 
+def fm_loss(sd, p, x, z, noise, timestep, steps=10, depth=12, heads=12):
+    """ActionModelFM.loss with injected noise / integer timesteps (action_model.py:121-141): t = i / steps (float, into the
+    timestep embedder as is), x_t = t x + (1 - t) eps, target velocity x - eps."""
+    t = timestep.float() / steps
+    tv = t.view(-1, 1, 1)
+    x_t = tv * x + (1 - tv) * noise
+    return ((dit(sd, p, x_t, t, z, depth, heads) - (x - noise)) ** 2).mean()
+
+
+def fm_sample(sd, p, cond, start, steps=10, depth=12, heads=12):
+    """DreamVLA.forward mode='test' with ActionModelFM (dreamvla_model.py:935-987 -> respace.py:122-156): CFG-doubled batch,
+    guidance scale forced to 1 (so the result is the conditional half), Euler steps of 1 / steps from `start` (the fresh noise
+    FMDiffusion draws; (2 bs, 3, 7))."""
+    bs = cond.shape[0]
+    unc = sd[p + ".z_embedder.uncondition"].unsqueeze(0).expand(bs, cond.shape[1], -1)
+    z = torch.cat([cond, unc], 0)
+    x = start.clone()
+    for i in range(steps):
+        t = torch.full((2 * bs,), float(i) / steps)
+        half = x[:bs]
+        out = dit(sd, p, torch.cat([half, half], 0), t, z, depth, heads)
+        ce, ue = out[:bs], out[bs:]
+        he = ue + 1.0 * (ce - ue)
+        x = x + (1.0 / steps) * torch.cat([he, he], 0)
+    return x[:bs]
+
+
 def ddim_sample(sd, p, cond, noise, cfg_scale=1.5, depth=12, heads=12, steps=100, ddim=10):
     """DreamVLA.forward mode='test' branch (dreamvla_model.py:935-987): CFG-doubled batch, 10-step DDIM, eta 0."""
     import numpy as np
@@ -251,10 +278,11 @@ def dreamvla_forward(sd, cfg, image_primary, image_wrist, state, text_token, act
         elif mode == "train":
             feat = af[:, :cfg["sequence_length"] - int(cfg.get("atten_goal", 0))].flatten(0, 1)
             labels = action_label.flatten(0, 1)
-            arm_pred = dit_loss(sd, "action_model.net", labels.repeat(8, 1, 1), feat.repeat(8, 1, 1), dit_noise, dit_timestep)
+            lossfn = fm_loss if cfg.get("use_fm") else dit_loss
+            arm_pred = lossfn(sd, "action_model.net", labels.repeat(8, 1, 1), feat.repeat(8, 1, 1), dit_noise, dit_timestep)
             grip_pred = arm_pred
         else:
-            smp = ddim_sample(sd, "action_model.net", af.flatten(0, 1), dit_noise)
+            smp = (fm_sample if cfg.get("use_fm") else ddim_sample)(sd, "action_model.net", af.flatten(0, 1), dit_noise)
             arm_pred, grip_pred = smp.unsqueeze(0)[..., :6], smp.unsqueeze(0)[..., 6:]
     return (arm_pred, grip_pred, res["image_pred"], None, None, None, res["depth_pred"], res["traj_pred"], res["dino_pred"],
             res["sam_pred"])

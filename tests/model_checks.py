@@ -239,7 +239,12 @@ def hip_full_model_checks(name):
             m.action_model._injected = None
             real = torch.randn
             tn = fx["test_noise"].to("cuda")
-            torch.randn = lambda *a, **k: tn.clone()
+            bs_ = tn.shape[0]
+
+            def fake_randn(*a, **k):      # DDIM: the model draws (bs, 3, 7) and doubles it; flow matching draws (2 bs, 3, 7) itself
+                n0 = a[0][0] if isinstance(a[0], (tuple, list, torch.Size)) else a[0]
+                return tn.clone() if n0 == bs_ else torch.cat([tn, tn], 0)
+            torch.randn = fake_randn
             try:
                 out = m(*args, mode="test")
             finally:

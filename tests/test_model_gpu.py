@@ -17,7 +17,7 @@ def test_hip_modules_vs_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["A", "B", "E", "C"])
+@pytest.mark.parametrize("name", ["A", "B", "E", "F", "C"])
 def test_hip_full_model_vs_golden(name):
     """C = the benchmarked configuration (S = 7, 24 layers, head set C, L = 651 with key compaction 651 -> 378), B = 1;
     per-output tolerance = max(1e-3, 1.25 x the real reference's own bf16 deviation) recorded in the fixture"""
