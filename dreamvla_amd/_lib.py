@@ -84,6 +84,7 @@ SYMBOLS = {
     "dvla_set_gemm_variant": (None, [C.c_int]),
     "dvla_last_gemm_variant": (C.c_int, []),
     "dvla_set_gemm_schedule": (None, [C.c_int, C.c_int]),
+    "dvla_get_gemm_schedule": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dvla_layernorm_fwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I64, _I64, _F, _P]),
     "dvla_layernorm_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "dvla_layernorm_bwd_add": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _P]),

@@ -217,6 +217,11 @@ extern "C" void dvla_set_gemm_schedule(int oversubscribe, int stream_k) {
   if (stream_k >= 0) g_streamk = stream_k ? 1 : 0;
 }
 
+extern "C" void dvla_get_gemm_schedule(int* oversubscribe, int* stream_k) {
+  if (oversubscribe) *oversubscribe = dvla_gemm::gemm_oversubscribe();
+  if (stream_k) *stream_k = streamk_enabled() ? 1 : 0;
+}
+
 extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!q || !q->A || !q->B || !q->C) return DVLA_ERR_ARG;

@@ -38,7 +38,16 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, params, bucket_bytes=256 << 20, process_group=None, static_unused=True, direct_grads=False):
+    def __init__(self, params, bucket_bytes=256 << 20, process_group=None, static_unused=True, direct_grads=False,
+                 last_bucket_bytes=64 << 20, robust_gemm_schedule=None):
+        """last_bucket_bytes: size cap of the bucket that is filled LAST (the gradients of the model's first parameters: token
+        embeddings, resampler, trunk layer 0 ...): its all-reduce cannot start before backward ends, so it is the exposed tail
+        of the exchange -- 64 MiB is ~0.5 ms over xGMI where a 256-MiB bucket would be ~2 ms.
+        robust_gemm_schedule: while a collective is outstanding, run the persistent GEMMs under the schedule that does not
+        assume every workgroup is co-resident (dvla_set_gemm_schedule(8, 0): equal-sized short-lived workgroups, no stream-K):
+        an RCCL kernel holds CUs for the whole transfer and the one-workgroup-per-CU schedules then wait for the workgroups
+        that cannot start (+65 % per GEMM launch with 16 of 256 CUs taken; +0 ... 9 % under the robust schedule:
+        profiles/r02_gemm_cu_contention.txt).  Default: on for the "nccl" (= RCCL) backend, off otherwise."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.static_unused = bool(static_unused)
@@ -49,20 +58,31 @@ class GradBucketReducer:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []       # dicts: flat, params, pending
         order = list(reversed(self.params))
+        sizes = [p.numel() * p.element_size() for p in order]
+        remaining = sum(sizes)
+        tail_cut = False       # the cut that opens the (small) last bucket has been made
         cur, cur_bytes, cur_key = [], 0, None
-        for p in order:
+        for p, nbytes in zip(order, sizes):
             key = (p.dtype, p.device)
-            nbytes = p.numel() * p.element_size()
-            if cur and (key != cur_key or cur_bytes + nbytes > bucket_bytes):
+            cut = bool(cur) and (key != cur_key or cur_bytes + nbytes > bucket_bytes)
+            if (not cut and cur and not tail_cut and last_bucket_bytes and remaining <= last_bucket_bytes
+                    and cur_bytes + remaining > last_bucket_bytes):
+                cut = tail_cut = True
+            if cut:
                 self._make_bucket(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
             cur_key = key
+            remaining -= nbytes
         if cur:
             self._make_bucket(cur)
         self._handles = []
         self._hooks = []
+        if robust_gemm_schedule is None:
+            robust_gemm_schedule = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        self.robust_gemm_schedule = bool(robust_gemm_schedule)
+        self._saved_schedule = None
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b["params"]):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, pi)))
@@ -125,10 +145,27 @@ class GradBucketReducer:
                 return
             self._launch(b)
 
+    def _gemm_schedule(self, robust):
+        """switch the GEMM schedule for the time collectives are outstanding (see __init__) and back"""
+        if not self.robust_gemm_schedule:
+            return
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        if robust and self._saved_schedule is None:
+            k, sk = ctypes.c_int(0), ctypes.c_int(0)
+            lib.dvla_get_gemm_schedule(ctypes.byref(k), ctypes.byref(sk))
+            self._saved_schedule = (k.value, sk.value)
+            lib.dvla_set_gemm_schedule(8, 0)
+        elif not robust and self._saved_schedule is not None:
+            lib.dvla_set_gemm_schedule(*self._saved_schedule)
+            self._saved_schedule = None
+
     def _launch(self, b):
         b["launched"] = True
         self._next_launch += 1
         if self.world > 1:
+            self._gemm_schedule(True)
             op = dist.ReduceOp.AVG if self._avg_in_collective() else dist.ReduceOp.SUM
             flat = b["flat"]
             if flat.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -199,6 +236,7 @@ class GradBucketReducer:
             if host is not None:
                 flat.copy_(host)
         self._handles = []
+        self._gemm_schedule(False)
         if self.world > 1 and not self._avg_in_collective():
             for b in self.buckets:
                 b["flat"].div_(self.world)

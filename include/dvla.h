@@ -95,6 +95,10 @@ int dvla_last_gemm_variant(void);
  *     bucket all-reduces (0.99 GB per step) occupy CUs for a few milliseconds of a 165-ms step.
  *   stream_k = 0 / 1: forbid / allow the stream-K schedule (needs every workgroup co-resident); -1 / oversubscribe < 1: keep. */
 void dvla_set_gemm_schedule(int oversubscribe, int stream_k);
+/* the schedule in force (either pointer may be NULL).  dreamvla_amd.ddp.GradBucketReducer switches to (8, 0) -- equal-sized,
+ * short-lived workgroups, no co-residency assumption -- while its RCCL all-reduces are outstanding (their kernels hold CUs for
+ * the whole transfer) and back afterwards. */
+void dvla_get_gemm_schedule(int* oversubscribe, int* stream_k);
 
 /* ---------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (rows x cols, bf16 in/out, fp32 statistics).

@@ -40,20 +40,32 @@ def _worker(rank, world, port, q, direct):
     from dreamvla_amd.ddp import GradBucketReducer
     torch.manual_seed(0)
     m = Tiny()
-    red = GradBucketReducer(m.parameters(), bucket_bytes=1500, direct_grads=direct)      # force several buckets
+    # robust_gemm_schedule=True: what the RCCL backend switches on by default (checked below through the C ABI's getter)
+    red = GradBucketReducer(m.parameters(), bucket_bytes=1500, direct_grads=direct, robust_gemm_schedule=True)   # several buckets
     assert len(red.buckets) >= 3 and red.grads_are_views()
     g = torch.Generator().manual_seed(5)
     X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
     xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
     out = {}
     early = {}
+
+    def _schedule():
+        import ctypes
+        from dreamvla_amd import _lib
+        k, sk = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.load().dvla_get_gemm_schedule(ctypes.byref(k), ctypes.byref(sk))
+        return k.value, sk.value
+    sched0 = _schedule()
     for it in range(5):                 # steps 0-2: `unused` gets no gradient (learned after step 0); 3-4: it does
         m.use_extra = it >= 3
         red.zero_grad()
         loss = ((m(xs) - ys) ** 2).mean()
         loss.backward()
         early[it] = [b["launched"] for b in red.buckets]             # launched during backward, before finish()
+        if any(early[it]):       # collectives outstanding: the GEMMs run under the schedule that needs no co-residency
+            assert _schedule() == (8, 0), _schedule()
         red.finish()
+        assert _schedule() == sched0, (_schedule(), sched0)          # ... and back once every handle has been waited for
         assert red.grads_are_views()
         out[it] = {n: red.grad_of(p).clone() for n, p in m.named_parameters()}
         if direct:      # parameters without a gradient keep p.grad = None; the others were adopted into their bucket slot
