@@ -42,7 +42,8 @@ BF16_PEAK_TFLOPS = 2500.0
 def model_cfg(heads, S, layers=24, phase="finetune"):
     cfg = dict(finetune_type="calvin", sequence_length=S, num_resampler_query=16, num_obs_token_per_image=9,
                action_pred_steps=3, transformer_layers=layers, hidden_dim=1024, transformer_heads=16, phase=phase,
-               attn_implementation="sdpa")
+               attn_implementation="sdpa",
+               track_label_patch_size=8)     # the CLI default train.py passes (utils/arguments_utils.py:227), not the ctor's 4
     cfg.update(HEAD_SETS[heads])
     return cfg
 

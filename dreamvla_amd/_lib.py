@@ -91,6 +91,8 @@ SYMBOLS = {
     "dvla_layernorm_bwd_partial_rows": (_I64, []),
     "dvla_attn_fwd": (C.c_int, [C.POINTER(AttnParams), _P]),
     "dvla_attn_bwd": (C.c_int, [C.POINTER(AttnParams), _P]),
+    "dvla_attn_small_fwd": (C.c_int, [C.POINTER(AttnParams), _I32, _P]),
+    "dvla_attn_small_bwd": (C.c_int, [C.POINTER(AttnParams), _I32, _P]),
     "dvla_colsum": (C.c_int, [_P, _I64, _I64, _I64, _P, _P, _P]),
     "dvla_colsum_dt": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P, _P]),
     "dvla_colsum_partial_rows": (_I64, []),

@@ -7,7 +7,7 @@ from .models import DiT
 
 
 def DiT_S(**kwargs):
-    return DiT(depth=6, hidden_size=384, num_heads=4, **kwargs)   # head_dim 96: rejected by the head_dim-64 attention kernels
+    return DiT(depth=6, hidden_size=384, num_heads=4, **kwargs)   # head_dim 96: the short-sequence kernel (csrc/attention_small.hip)
 
 
 def DiT_B(**kwargs):

@@ -61,11 +61,13 @@ class Mlp(nn.Module):
 
 
 class Attention(nn.Module):
-    """timm Attention: fused qkv Linear -> (B,N,3,h,d) -> SDPA (scale d^-0.5) -> proj.  head_dim must be 64."""
+    """timm Attention: fused qkv Linear -> (B,N,3,h,d) -> SDPA (scale d^-0.5) -> proj.  head_dim 64 runs on the MFMA kernels
+    (csrc/attention.hip); any other head_dim <= 128 (DiT-S: 96) on the short-sequence kernel (csrc/attention_small.hip,
+    sequences of at most 64 tokens, no mask) -- ops.self_attention raises for anything else."""
 
     def __init__(self, dim, num_heads=8, qkv_bias=False):
         super().__init__()
-        assert dim % num_heads == 0 and dim // num_heads == 64, "HIP attention kernels are specialised for head_dim 64"
+        assert dim % num_heads == 0, "dim must be a multiple of num_heads"
         self.num_heads = num_heads
         self.head_dim = dim // num_heads
         self.scale = self.head_dim ** -0.5
@@ -74,7 +76,7 @@ class Attention(nn.Module):
 
     def forward(self, x, residual=None):
         qkv = self.qkv(x)
-        o = ops.self_attention(qkv, self.num_heads, scale=self.scale)
+        o = ops.self_attention(qkv, self.num_heads, scale=self.scale, head_dim=self.head_dim)
         return self.proj(o, residual=residual)
 
 

@@ -1004,6 +1004,63 @@ class _SelfAttention(torch.autograd.Function):
         return dqkv, None, None, None, None
 
 
+class _SelfAttentionSmall(torch.autograd.Function):
+    """Packed self-attention with head_dim != 64 on short sequences (dvla_attn_small_fwd / _bwd: L <= 64, head_dim <= 128, no
+    mask, no dropout) -- the DiT-S action head (head_dim 96, 6 tokens).  qkv (B, L, 3*H*D) -> (B, L, H*D)."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, D, scale):
+        lib = _lib.load()
+        _req(qkv, "attention.qkv")
+        B, L, W = qkv.shape
+        if W != 3 * H * D:
+            raise ValueError("attention: qkv width must be 3 * heads * head_dim")
+        if L > 64 or D > 128 or D % 8:
+            raise _lib.DvlaError(f"attention with head_dim {D}: only sequences of <= 64 tokens and head_dim <= 128 (multiple of 8) "
+                                 f"are supported off the head_dim-64 MFMA kernels (got L = {L})")
+        if not qkv.is_contiguous():
+            qkv = qkv.contiguous()
+        v5 = qkv.view(B, L, 3, H, D)
+        o = torch.empty((B, L, H, D), dtype=BF16, device=qkv.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+        p = _SelfAttentionSmall._params(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], o, H, L, scale, lse)
+        check(lib.dvla_attn_small_fwd(C.byref(p), D, _stream()), "dvla_attn_small_fwd")
+        ctx.H, ctx.D, ctx.scale = H, D, scale
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(qkv, o, lse)
+        return o.view(B, L, H * D)
+
+    @staticmethod
+    def _params(q, k, v, o, H, L, scale, lse):
+        p = AttnParams()
+        p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+        for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+            setattr(p, name + "_stride_b", t.stride(0)); setattr(p, name + "_stride_t", t.stride(1)); setattr(p, name + "_stride_h", t.stride(2))
+        p.B, p.H, p.Lq, p.Lk = q.shape[0], H, L, L
+        p.scale = float(scale)
+        p.lse = lse.data_ptr()
+        return p
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        qkv, o, lse = ctx.saved_tensors
+        B, L, _ = qkv.shape
+        H, D = ctx.H, ctx.D
+        v5 = qkv.view(B, L, 3, H, D)
+        dqkv = torch.empty_like(qkv)
+        d5 = dqkv.view(B, L, 3, H, D)
+        do = _req(dout, "attention.grad_output").contiguous().view(B, L, H, D)
+        p = _SelfAttentionSmall._params(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], o, H, L, ctx.scale, lse)
+        p.dout = do.data_ptr()
+        p.do_stride_b, p.do_stride_t, p.do_stride_h = do.stride(0), do.stride(1), do.stride(2)
+        p.dq, p.dk, p.dv = d5[:, :, 0].data_ptr(), d5[:, :, 1].data_ptr(), d5[:, :, 2].data_ptr()
+        for name, t in (("dq", d5[:, :, 0]), ("dk", d5[:, :, 1]), ("dv", d5[:, :, 2])):
+            setattr(p, name + "_stride_b", t.stride(0)); setattr(p, name + "_stride_t", t.stride(1)); setattr(p, name + "_stride_h", t.stride(2))
+        check(lib.dvla_attn_small_bwd(C.byref(p), D, _stream()), "dvla_attn_small_bwd")
+        return dqkv, None, None, None
+
+
 _PACK_TABLES = {}
 
 
@@ -1019,16 +1076,20 @@ def _packed_block_diagonal(G, L, device):
     return mt
 
 
-def self_attention(qkv, num_heads, *, scale=None, mask_tables=None, dropout_p=0.0):
-    """qkv (B, L, 3 * H * 64) -> (B, L, H * 64).
+def self_attention(qkv, num_heads, *, scale=None, mask_tables=None, dropout_p=0.0, head_dim=64):
+    """qkv (B, L, 3 * H * 64) -> (B, L, H * 64).  head_dim != 64: the short-sequence kernel (_SelfAttentionSmall).
     Very short sequences (the DiT action head: L = 6, B = 1792) are PACKED: G consecutive sequences are handed to the
     kernels as one sequence of G * L tokens under a block-diagonal mask (a view -- the batch is contiguous -- plus a cached
     table): the kernels work on 32 x 32 score tiles and 128-query workgroups, so one 6 x 6 problem per workgroup used
     3.5 % of a tile and paid a whole prologue (272 us per backward for 0.1 GFLOP).  Masked scores contribute exactly zero;
     only the fp32 summation order of a sequence that straddles a tile boundary changes."""
-    scale = (1.0 / math.sqrt(64.0)) if scale is None else scale
+    scale = (1.0 / math.sqrt(float(head_dim))) if scale is None else scale
     qkv = to_compute(qkv)
     B, L = qkv.shape[0], qkv.shape[1]
+    if head_dim != 64:
+        if mask_tables is not None or dropout_p > 0.0:
+            raise _lib.DvlaError(f"attention with head_dim {head_dim}: masks / dropout need the head_dim-64 kernels")
+        return _SelfAttentionSmall.apply(qkv, int(num_heads), int(head_dim), float(scale))
     if mask_tables is None and dropout_p == 0.0 and 1 < L <= 16 and B >= 64 and qkv.is_contiguous():
         G = 128 // L
         while G > 1 and B % G != 0:

@@ -170,6 +170,11 @@ typedef struct dvla_attn_params {
 } dvla_attn_params;
 int dvla_attn_fwd(const dvla_attn_params* p, void* stream);
 int dvla_attn_bwd(const dvla_attn_params* p, void* stream);
+/* The same attention for SHORT sequences (Lq == Lk <= 64) with ANY head_dim <= 128 (multiple of 8), no mask, no dropout: one
+ * wave per (batch, head).  The only head_dim != 64 the reference can produce is the DiT-S action head (models/action_model/
+ * action_model.py:12-14: 384 / 4 = 96) on 6-token sequences.  Same parameter block; `delta` is not used. */
+int dvla_attn_small_fwd(const dvla_attn_params* p, int32_t head_dim, void* stream);
+int dvla_attn_small_bwd(const dvla_attn_params* p, int32_t head_dim, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Small HBM-bound helpers (bf16 unless noted).

@@ -63,6 +63,11 @@ def loss_case_tensors(case):
         preds["sam"] = r(n, 2, PRED_NUM, 256, 256)
     if case["trajectory_pred"]:
         preds["traj"] = r(n, 2, PRED_NUM, 196, 8)
+    # every floating input is bf16-representable: the bf16 HIP loss kernels then see EXACTLY the values the real training loop
+    # saw in fp32, and can be compared with the loop's loss values / gradients directly (one hop, tests/gpu_checks.py)
+    rb = lambda t: t.to(torch.bfloat16).to(t.dtype)
+    batch = {k: (rb(v) if torch.is_tensor(v) and torch.is_floating_point(v) else v) for k, v in batch.items()}
+    preds = {k: (rb(v) if v.dim() > 0 else v) for k, v in preds.items()}
     return batch, preds
 
 

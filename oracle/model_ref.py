@@ -66,16 +66,33 @@ def perceiver(sd, p, x, depth=3, heads=8):
     return _ln(sd, p + ".norm", lat, 1e-5)
 
 
-def gpt2(sd, p, x, mask, layers, heads, drop=None):
-    """GPT2Model.forward in eval mode (gpt2.py:450-480, blocks 306-339, _attn 61-84, MLP 288-302)."""
+def gpt2(sd, p, x, mask, layers, heads, drop=None, drop_cols=None):
+    """GPT2Model.forward (gpt2.py:450-480, blocks 306-339, _attn 61-84, MLP 288-302).  drop = None: eval mode.
+    drop = (p, first_seed_counter, seed_hi): TRAINING mode with the product's stateless hash dropout (R.drop_keep_mask; the
+    reference's ATen Philox stream cannot be reproduced) at the four places GPT-2 drops -- the embedding (gpt2.py:435), the
+    attention probabilities (:79), and the two residual branches (:172-173, :301) -- each with the next per-call seed counter,
+    in the order dreamvla_amd/gpt2.py issues them: embd, then per layer attention, c_proj, mlp.  Element indices: (flattened
+    token row, feature) for the elementwise ones, ((b H + h) L + i, compacted key) for the probabilities."""
+    H = x.shape[-1]
+    seed = None
+    if drop is not None:
+        pd, c0, hi = drop
+        seed = iter((c0 + 1 + i, hi) for i in range(1 + 3 * layers))
+        x = R.dropout_elementwise(x.reshape(-1, H), pd, next(seed)).view(x.shape)
     for i in range(layers):
         b = f"{p}.h.{i}"
         h = _ln(sd, b + ".ln_1", x, 1e-5)
         q, k, v = R.split_qkv(_lin(sd, b + ".attn.c_attn", h, conv1d=True), heads)
-        a = R.merge_heads(R.attention(q, k, v, mask=mask))
-        x = x + _lin(sd, b + ".attn.c_proj", a, conv1d=True)
+        a = R.merge_heads(R.attention(q, k, v, mask=mask, drop=None if drop is None else (pd, next(seed)), drop_cols=drop_cols))
+        z = _lin(sd, b + ".attn.c_proj", a, conv1d=True)
+        if drop is not None:
+            z = R.dropout_elementwise(z.reshape(-1, H), pd, next(seed)).view(z.shape)
+        x = x + z
         h = _ln(sd, b + ".ln_2", x, 1e-5)
-        x = x + _lin(sd, b + ".mlp.c_proj", R.act(_lin(sd, b + ".mlp.c_fc", h, conv1d=True), "gelu_new"), conv1d=True)
+        z = _lin(sd, b + ".mlp.c_proj", R.act(_lin(sd, b + ".mlp.c_fc", h, conv1d=True), "gelu_new"), conv1d=True)
+        if drop is not None:
+            z = R.dropout_elementwise(z.reshape(-1, H), pd, next(seed)).view(z.shape)
+        x = x + z
     return _ln(sd, p + ".ln_f", x, 1e-5)
 
 

@@ -356,6 +356,32 @@ def check_self_attention(B, H, L, mask_kind="none", dropout_p=0.0, grad=True, se
     return out
 
 
+def check_self_attention_small(B, H, L, D, seed=0):
+    """the short-sequence, generic-head_dim kernel (csrc/attention_small.hip: DiT-S, head_dim 96) against the same two oracles"""
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(27 + seed)
+    qkv = rnd((B, L, 3 * H * D), g)
+    do = rnd((B, L, H * D), g)
+    qd = qkv.to(DEV, BF).requires_grad_(True)
+    o = ops.self_attention(qd, H, head_dim=D)
+    o.backward(do.to(DEV, BF))
+    t = qkv.view(B, L, 3, H, D).permute(2, 0, 3, 1, 4)
+    do4 = do.view(B, L, H, D).permute(0, 2, 1, 3)
+    of, _, dq, dk, dv = R.attention_bf16(t[0], t[1], t[2], dout=do4)
+    W = H * D
+    tag = f"self_attn_small B{B} H{H} L{L} D{D}"
+    out = [metrics(tag + " o", o, R.merge_heads(of), TOL_ATTN),
+           metrics(tag + " dq", qd.grad[..., :W], R.merge_heads(dq), TOL_ATTN_GRAD),
+           metrics(tag + " dk", qd.grad[..., W:2 * W], R.merge_heads(dk), TOL_ATTN_GRAD),
+           metrics(tag + " dv", qd.grad[..., 2 * W:], R.merge_heads(dv), TOL_ATTN_GRAD)]
+    qr = qkv.clone().requires_grad_(True)
+    t = qr.view(B, L, 3, H, D).permute(2, 0, 3, 1, 4)
+    orf = R.merge_heads(R.attention(t[0], t[1], t[2]))
+    orf.backward(do)
+    out += [metrics(tag + " o (fp32 oracle)", o, orf, TOL_ATTN_F32), metrics(tag + " dqkv (fp32 oracle)", qd.grad, qr.grad, TOL_GRAD)]
+    return out
+
+
 def check_cross_attention(B, H, Lq, Lk, seed=0):
     from dreamvla_amd import ops
     g = torch.Generator().manual_seed(17 + seed)
@@ -562,6 +588,7 @@ def all_checks(quick=False):
     L += [(check_flat_adamw, dict()), (check_direct_grads, dict()), (check_assemble_tokens, dict()),
           (check_concat_shared_suffix, dict()), (check_concat_shared_suffix, dict(n=5, nq=9, ns=256, D=3072, seed=1))]
     L += [(check_fused_losses, dict(case_name=c)) for c in ("C_calvin_dit", "E_libero_all_heads", "E_atten_goal")]
+    L += [(check_fused_losses_vs_training_loop, dict(case_name=c)) for c in ("C_calvin_dit", "A_mlp_head", "E_libero_all_heads", "E_atten_goal")]
     L += [
         (check_layernorm, dict(rows=37, cols=768, eps=1e-6)),
         (check_layernorm, dict(rows=1000, cols=1024)),
@@ -600,6 +627,9 @@ def all_checks(quick=False):
         (check_self_attention, dict(B=448, H=16, L=265, rows=10, period=9, seed=1)),
         (check_self_attention, dict(B=448, H=12, L=197, rows=8, period=7, grad=False)),
         (check_self_attention, dict(B=1792, H=12, L=6, rows=32, period=48)),
+        (check_self_attention_small, dict(B=5, H=4, L=6, D=96)),
+        (check_self_attention_small, dict(B=3, H=2, L=33, D=128, seed=1)),
+        (check_self_attention_small, dict(B=2, H=3, L=64, D=40, seed=2)),
         (check_cross_attention, dict(B=3, H=8, Lq=16, Lk=212)),
         (check_cross_attention, dict(B=2, H=2, Lq=40, Lk=33)),
     ]
@@ -649,6 +679,46 @@ def check_fused_losses(case_name):
     for k in ("image", "depth", "dino", "sam"):
         if k in ga:
             out.append(metrics(f"{tag} d{k}", gf[k], ga[k].cpu(), TOL_GRAD, round_ref=False))
+    return out
+
+
+def check_fused_losses_vs_training_loop(case_name):
+    """ONE hop (round-2 VERDICT: a12 was HIP <-> product ATen code <-> real loop): the HIP loss kernels on the GPU against the
+    loss values and prediction gradients of the REAL reference training loop (utils/train_utils.py:train_one_epoch_calvin run
+    on CPU by oracle/make_golden_losses.py -> tests/golden/losses.pt).  The fixture's inputs are bf16-representable, so the
+    bf16 kernels see exactly the numbers the loop saw: loss terms differ by fp32 summation order only, the bf16 prediction
+    gradients by their final rounding."""
+    import os
+    from dreamvla_amd import losses
+    from oracle.make_golden_losses import loss_case_tensors
+    fx = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses.pt"), map_location="cpu")["cases"][case_name]
+    case = fx["case"]
+    batch, preds = loss_case_tensors(case)
+    batch["actions"][..., 6:] = (batch["actions"][..., 6:] + 1) // 2
+    S, ag = case["S"], case.get("atten_goal", 0)
+    dev_batch = {k: (v.to(DEV, BF) if torch.is_floating_point(v) else v.to(DEV)) for k, v in batch.items()}
+    lab = losses.label_actions(dev_batch["actions"], S, 3, atten_goal=ag)
+    leaves = {k: v.to(DEV, BF).clone().requires_grad_(True) for k, v in preds.items()}
+    if case["use_dit_head"]:
+        leaves["arm"] = preds["arm"].to(DEV).float().requires_grad_(True)
+    g = leaves.get
+    o = (leaves["arm"], g("gripper", leaves["arm"]), g("image"), None, None, None, g("depth"), g("traj"), g("dino"), g("sam"))
+    total, parts = losses.calvin_losses(o, dev_batch, sequence_length=S, atten_goal=ag, use_dit_head=case["use_dit_head"],
+                                        label_action=lab, flow_as_mask=case["flow_as_mask"], fused=None)
+    total.backward()
+    want = fx["losses"]
+    names = {"loss_arm_action": "arm_action", "loss_gripper_action": "gripper_action", "loss_image": "image", "loss_depth": "depth",
+             "loss_dino_feat": "dino", "loss_sam_feat": "sam", "loss_pred_trajectory": "trajectory"}
+    tag = f"HIP losses vs real training loop {case_name}"
+    out = [metrics(tag + " total", total.detach().float().reshape(1), torch.tensor([want["loss"]]), 3e-5, round_ref=False)]
+    for k_ref, k in names.items():
+        if want[k_ref] != 0.0:
+            out.append(metrics(f"{tag} {k}", parts[k].detach().float().reshape(1), torch.tensor([want[k_ref]]), 3e-5, round_ref=False))
+    for k, smp in fx["grads"].items():
+        if leaves[k].grad is None or leaves[k].dim() == 0:
+            continue
+        gv = leaves[k].grad.detach().float().cpu().flatten()[smp["idx"]]
+        out.append(metrics(f"{tag} d{k}", gv, smp["vals"], TOL_FWD if leaves[k].dtype == BF else 1e-5, round_ref=leaves[k].dtype == BF))
     return out
 
 

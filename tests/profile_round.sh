@@ -28,11 +28,14 @@ python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_gemm_mfma $OUT/${TAG}_pmc_gemm
 # 3. attention: matrix-pipe busy per kernel
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_attn -f csv -- python $REPO/tests/gpu_pmc_attn.py > $OUT/${TAG}_pmc_attn.log 2>&1
 python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_attn $OUT/${TAG}_pmc_attn.json > $OUT/${TAG}_pmc_attn.txt 2>&1
-# 4. LayerNorm: HBM bytes on > 256 MiB working sets
+# 4. LayerNorm: HBM bytes on > 256 MiB working sets, ONE SHAPE PER PASS (0: 353024 x 768, 1: 166656 x 1024)
+for SH in 0 1; do
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_ln_$C -f csv -- python $REPO/tests/gpu_pmc_ln.py > $OUT/${TAG}_pmc_ln_$C.log 2>&1
-  python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_ln_$C $OUT/${TAG}_pmc_ln_$C.json --by-grid > $OUT/${TAG}_pmc_ln_$C.txt 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_ln${SH}_$C -f csv -- python $REPO/tests/gpu_pmc_ln.py $SH > $OUT/${TAG}_pmc_ln${SH}_$C.log 2>&1
+  python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_ln${SH}_$C $OUT/${TAG}_pmc_ln${SH}_$C.json > $OUT/${TAG}_pmc_ln${SH}_$C.txt 2>&1
+  rm -rf $OUT/${TAG}_pmc_ln${SH}_$C
+done
 done
 # keep the merge small: drop the raw traces
-rm -rf $OUT/${TAG}_pmc_gemm_mfma $OUT/${TAG}_prof_step $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_attn $OUT/${TAG}_pmc_ln_FETCH_SIZE $OUT/${TAG}_pmc_ln_WRITE_SIZE
+rm -rf $OUT/${TAG}_pmc_gemm_mfma $OUT/${TAG}_prof_step $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_attn
 ls -la $OUT | head -40

@@ -25,6 +25,11 @@ def test_hip_full_model_vs_golden(name):
 
 
 @pytest.mark.gpu
+def test_hip_trunk_module_with_dropout_on():
+    _assert_all(C.hip_gpt2_dropout_checks())
+
+
+@pytest.mark.gpu
 def test_hip_full_model_at_benchmark_batch():
     """fixture C's sample as row 0 of a B = 32 batch (the benchmark's batch: 20832-row trunk GEMMs, stream-K / phase kernel
     configurations, the timed attention grids): row 0 vs the real reference's golden outputs, rows 13 / 31 vs the oracle"""
