@@ -132,10 +132,14 @@ def main():
     ap.add_argument("--torch-profile", default=None, metavar="FILE",
                     help="diagnostics: after the timed region, one more step under torch.profiler; ATen / autograd operators by "
                          "device time (with input shapes) are written to FILE")
+    ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency leg (counter passes: whole steps only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true",
                     help="skip the eager PyTorch-ROCm comparator (rank 0, N = 1 only; ~10 s after the timed region)")
+    ap.add_argument("--no-rollout", action="store_true",
+                    help="skip the closed-loop rollout leg (BASELINE configs[4]: 64 episodes in lock-step through the hipGraph-"
+                         "captured engine, S = 10, DDIM-10; rank 0, N = 1 only; ~15 s after the timed region)")
     ap.add_argument("--torch-ddp", action="store_true", help="use torch DDP instead of dreamvla_amd.ddp.GradBucketReducer")
     ap.add_argument("--torch-adamw", action="store_true",
                     help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of dreamvla_amd.optim.FlatAdamW (HIP, flat buffers)")
@@ -261,7 +265,7 @@ def main():
 
     # forward-only latency (train mode, autograd graph recorded, no backward)
     fwd_ms = None
-    if rank == 0 or world > 1:
+    if (rank == 0 or world > 1) and not args.no_fwd:
         for _ in range(1):
             forward_loss()
         torch.cuda.synchronize()
@@ -324,6 +328,21 @@ def main():
         except Exception as e:  # noqa: BLE001
             eager = {"value": None, "unit": "samples/s", "sample": f"failed: {e!r}"}
 
+    rollout = None
+    if rank == 0 and world == 1 and not args.no_rollout and args.heads == "C":
+        try:
+            from tests import gpu_rollout_bench
+            torch.cuda.empty_cache()
+            r = gpu_rollout_bench.run(Bs=(64, 1), naive=False, eager_engine=False, steps=12)
+            rows = {row["B"]: row for row in r["rows"]}
+            rollout = {"metric": "closed-loop control steps/s (BASELINE configs[4]: eval rollout, 64 episodes in lock-step, S = 10 "
+                                 "history, DiT head with DDIM-10 + CFG, hipGraph-captured encode / decode, per-frame token cache)",
+                       "value": rows[64]["episode_steps_per_s"]["graph"], "unit": "episode-steps/s", "episodes": 64,
+                       "ms_per_lockstep": rows[64]["graph_ms_per_step"], "single_episode_ms_per_step": rows[1]["graph_ms_per_step"],
+                       "dtype": "bf16", "data": "synthetic"}
+        except Exception as e:  # noqa: BLE001
+            rollout = {"value": None, "sample": f"failed: {e!r}"}
+
     if rank == 0:
         line = {
             "metric": "train samples/sec (CALVIN ABC->D, seq_len=7)", "value": value, "unit": "samples/s",
@@ -337,7 +356,7 @@ def main():
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "trainable_params_M": n_train / 1e6, "loss": loss_val,
                        "grad_exchange": grad_exchange, "optimizer": optimizer_name},
-            "roofline": roofline, "cpu_baseline": cpu, "eager_rocm_baseline": eager,
+            "roofline": roofline, "cpu_baseline": cpu, "eager_rocm_baseline": eager, "rollout": rollout,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -307,6 +307,35 @@ def amp_deviation(name, runs=2):
     fx["ref_bf16_cast_deviation"] = [None if r is None else
                                      dict(rel_l2=_out_rel(o, r), max_abs=float((o.float() - r).abs().max()), absmax=float(r.abs().max()))
                                      for o, r in zip(o16, ref)]
+    # the evaluation path (mode="test": DDIM-10 + CFG or the flow-matching Euler loop): the reference's own bf16 runs --
+    # autocast on the fp32 module, then the bf16-cast module -- against its fp32 samples (fx["test"]) with the same start noise.
+    # Ten sampler steps feed the denoiser its own output, so bf16 noise is amplified: this record, not a guess, sets the
+    # tolerance of the GPU test-mode checks (tests/model_checks.py)
+    if "test" in fx and cfg["use_dit_head"]:
+        tn, bs_ = fx["test_noise"], fx["test_noise"].shape[0]
+
+        def fake_randn(*a, **k):
+            n0 = a[0][0] if isinstance(a[0], (tuple, list, torch.Size)) else a[0]
+            t = tn.clone() if n0 == bs_ else torch.cat([tn, tn], 0)
+            return t.to(k["dtype"]) if k.get("dtype") is not None else t
+        real_randn = torch.randn
+        m32 = build_reference_model(cfg)        # (`m` was cast to bf16 in place above)
+        torch.randn = fake_randn
+        try:
+            devs = []
+            with torch.no_grad():
+                with torch.autocast("cpu", dtype=BF):
+                    o_amp = m32(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], mode="test")
+                o_cast = m16(b["image_primary"].to(BF), b["image_wrist"].to(BF), b["state"].to(BF), b["text_token"], mode="test")
+            for o16 in (o_amp, o_cast):
+                devs.append([None if r is None else dict(rel_l2=_out_rel(o, r), max_abs=float((o.float() - r).abs().max()),
+                                                         absmax=float(r.abs().max())) for o, r in zip(o16, fx["test"])])
+            fx["ref_test_bf16_deviation"] = [None if devs[0][i] is None else
+                                             dict(rel_l2=max(d[i]["rel_l2"] for d in devs), max_abs=max(d[i]["max_abs"] for d in devs),
+                                                  absmax=devs[0][i]["absmax"]) for i in range(len(fx["test"]))]
+            print(name, "test-mode bf16", [None if w is None else round(w["rel_l2"], 5) for w in fx["ref_test_bf16_deviation"]])
+        finally:
+            torch.randn = real_randn
     torch.save(fx, path)
     print(name, "autocast", [None if w is None else round(w["rel_l2"], 5) for w in worst])
     print(name, "bf16 cast", [None if w is None else round(w["rel_l2"], 5) for w in fx["ref_bf16_cast_deviation"]])

@@ -15,10 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def run(Bs=(1, 64), naive=True, eager_engine=True, steps=20):
+    """-> {"config": ..., "rows": [...]}; bench.py's `rollout` leg calls it with naive=False, eager_engine=False (graph only)"""
     from dreamvla_amd.dreamvla_model import DreamVLA
     from dreamvla_amd.rollout import RolloutEngine
-    Bs = [int(a) for a in sys.argv[1:]] or [1, 64]
     S, BF, dev = 10, torch.bfloat16, "cuda"
     cfg = dict(finetune_type="calvin", sequence_length=S, num_resampler_query=16, num_obs_token_per_image=9,
                action_pred_steps=3, transformer_layers=24, hidden_dim=1024, transformer_heads=16, phase="finetune",
@@ -38,21 +38,22 @@ def main():
         win = [torch.stack([frames[i % 4][k] for i in range(S)], dim=1) for k in range(3)]
         tt = text.unsqueeze(1).repeat(1, S, 1)
         with torch.no_grad():
-            for _ in range(6):            # GEMM tuner settles
+            for _ in range(6 if naive else 0):            # GEMM tuner settles
                 m(win[0], win[1], win[2], tt, mode="test")
             torch.cuda.synchronize()
             n = 5
             t0 = time.perf_counter()
-            for _ in range(n):
+            for _ in range(n if naive else 0):
                 m(win[0], win[1], win[2], tt, mode="test")
             torch.cuda.synchronize()
-            row["naive_ms_per_step"] = (time.perf_counter() - t0) / n * 1e3
-        for name, graph in (("engine", False), ("graph", True)):
+            if naive:
+                row["naive_ms_per_step"] = (time.perf_counter() - t0) / n * 1e3
+        for name, graph in ((("engine", False),) if eager_engine else ()) + (("graph", True),):
             eng = RolloutEngine(m, B, use_graph=graph, warmup_decodes=6)
             for i in range(S + 8):
                 eng.step(*frames[i % 4], text)
             torch.cuda.synchronize()
-            n = 20
+            n = steps
             t0 = time.perf_counter()
             for i in range(n):
                 eng.step(*frames[i % 4], text)
@@ -62,6 +63,13 @@ def main():
                 row["graph_captured"] = eng.graphs_captured
         row["episode_steps_per_s"] = {k[:-12]: B * 1e3 / v for k, v in row.items() if k.endswith("_ms_per_step")}
         out["rows"].append(row)
+    return out
+
+
+def main():
+    Bs = [int(a) for a in sys.argv[1:]] or [1, 64]
+    out = run(Bs)
+    for row in out["rows"]:
         print(json.dumps(row), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "rollout_bench.json"), "w") as f:

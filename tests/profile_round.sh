@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-eager-baseline"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-eager-baseline --no-rollout"
 # 1. kernel trace + stats of the bench command (3 timed steps)
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_step -f csv -- $BENCH --steps 3 --warmup 1 --no-roofline > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 python $REPO/tests/prof_summary.py $OUT/${TAG}_prof_step $OUT/${TAG}_step_summary.txt > /dev/null 2>&1
@@ -19,11 +19,11 @@ cp $(find $OUT/${TAG}_prof_step -name "*kernel_stats.csv" | head -1) $OUT/${TAG}
 #    counters, FETCH and WRITE in separate passes; the same run writes the per-shape breakdown the algorithmic bytes come from
 DVLA_GEMM_BREAKDOWN=$OUT/${TAG}_gemm_breakdown.json $BENCH --steps 3 --warmup 1 --save-plan $OUT/${TAG}_gemm_plan.json > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_err.log
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$C -f csv -- $BENCH --steps 1 --warmup 1 --plan $OUT/${TAG}_gemm_plan.json --no-roofline > $OUT/${TAG}_pmc_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$C -f csv -- $BENCH --steps 2 --warmup 0 --plan $OUT/${TAG}_gemm_plan.json --no-roofline --no-fwd --no-rollout > $OUT/${TAG}_pmc_$C.log 2>&1
   python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_$C $OUT/${TAG}_pmc_$C.json > $OUT/${TAG}_pmc_$C.txt 2>&1
 done
 # 2b. GEMM matrix-pipe busy over the tuned step
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_gemm_mfma -f csv -- $BENCH --steps 1 --warmup 1 --plan $OUT/${TAG}_gemm_plan.json --no-roofline > $OUT/${TAG}_pmc_gemm_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_gemm_mfma -f csv -- $BENCH --steps 2 --warmup 0 --plan $OUT/${TAG}_gemm_plan.json --no-roofline --no-fwd --no-rollout > $OUT/${TAG}_pmc_gemm_mfma.log 2>&1
 python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_gemm_mfma $OUT/${TAG}_pmc_gemm_mfma.json > $OUT/${TAG}_pmc_gemm_mfma.txt 2>&1
 # 3. attention: matrix-pipe busy per kernel
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_attn -f csv -- python $REPO/tests/gpu_pmc_attn.py > $OUT/${TAG}_pmc_attn.log 2>&1
