@@ -75,6 +75,16 @@ inline int gemm_variant() {
 inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 
+// tile counts of a configuration + the reciprocals ring_item decodes with (d == 1: 2^32 - 1, the correction makes it exact)
+template <int BM, int BN, int GH>
+void set_tiles(GemmKArgs& a) {
+  a.tiles_m = (int)((a.M + BM - 1) / BM);
+  a.tiles_n = (int)((a.N + BN - 1) / BN);
+  auto inv = [](int64_t d) { return d <= 1 ? 0xffffffffu : (uint32_t)((1ull << 32) / (uint64_t)d); };
+  a.inv_ntiles = inv((int64_t)a.tiles_m * a.tiles_n);
+  a.inv_per_panel = inv((int64_t)GH * a.tiles_n);
+}
+
 template <class CF>
 void launch_cfg(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
   a.tiles_m = (int)((a.M + CF::BM - 1) / CF::BM);
@@ -102,8 +112,7 @@ void launch_ring_epi(const GemmKArgs& a, int split_k, hipStream_t stream) {
 }
 template <class RC>
 void launch_ring(GemmKArgs& a, int combo, int split_k, hipStream_t stream) {
-  a.tiles_m = (int)((a.M + RC::BM - 1) / RC::BM);
-  a.tiles_n = (int)((a.N + RC::BN - 1) / RC::BN);
+  set_tiles<RC::BM, RC::BN, RC::GH>(a);
   switch (combo) {
     case 0: launch_ring_epi<RC, false, false>(a, split_k, stream); break;
     case 1: launch_ring_epi<RC, false, true>(a, split_k, stream); break;
@@ -172,8 +181,7 @@ inline int streamk_tiles(int64_t tiles, int cus, bool full = false) {
 }
 // stream_k: 0 = plain schedule, 1 = hybrid (partial rounds only), 2 = full
 void launch_phase(GemmKArgs& a, int combo, int split_k, hipStream_t stream, int stream_k = 0) {
-  a.tiles_m = (int)((a.M + PCfg::BM - 1) / PCfg::BM);
-  a.tiles_n = (int)((a.N + PCfg::BN - 1) / PCfg::BN);
+  set_tiles<PCfg::BM, PCfg::BN, PCfg::GH>(a);
   a.sk_tiles = 0;
   if (stream_k && split_k == 1) {
     const int groups = num_cus();
@@ -320,7 +328,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       case 6: launch_phase(a, combo, split_k, stream, 1); break;   // falls back to the plain schedule when stream-K does not apply
       case 7: launch_phase(a, combo, split_k, stream, 2); break;
       case 81: case 83: case 84: case 85: case 86: case 89:   // ablations (plain bf16 epilogue only): 81 no MFMA, 83 no MFMA + no reads, 84 no DMA, 85 no epilogue, 86 raw stores only
-        a.tiles_m = (int)((a.M + 255) / 256); a.tiles_n = (int)((a.N + 255) / 256);
+        set_tiles<PCfg::BM, PCfg::BN, PCfg::GH>(a);
         if (epi_class(a) != EPI_P0) return DVLA_ERR_UNSUPPORTED;
         if (choice == 81) launch_phase_one<false, false, 0, 1>(a, split_k, stream);
         else if (choice == 83) launch_phase_one<false, false, 0, 3>(a, split_k, stream);

@@ -80,6 +80,9 @@ struct GemmKArgs {
   int split_k; int64_t k_per_split; float* workspace;
   int a_vec, b_vec, c_vec, aux_vec, epi_vec;
   int tiles_m, tiles_n;
+  // floor(2^32 / (tiles_m * tiles_n)) and floor(2^32 / (GH * tiles_n)) of the launching configuration (set_tiles): the
+  // ring / phase kernels decode a work item with a multiply-high and one correction instead of integer divisions
+  uint32_t inv_ntiles, inv_per_panel;
   // stream-K hybrid schedule of the phase kernel (gemm_phase.h): the first sk_tiles tiles are cut into gridDim.x equal
   // K-iteration ranges, the others run one tile per workgroup and round; 0 = plain schedule
   int sk_tiles; float* sk_slabs; unsigned* sk_flags;
@@ -676,15 +679,23 @@ __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)"
 
 // work item -> (tile origin, K range).  Consecutive ids sweep groups of GH tile rows column by column.
 struct RingItem { int64_t m0, n0, k_begin; int ns, split; };
+// n / d for 0 <= n < 2^31, d >= 2, inv = floor(2^32 / d): the multiply-high is the quotient or one short of it
+// (n * (2^32/d - inv) / 2^32 < 1), so one compare settles it.  Uniform operands: ~6 scalar instructions instead of the
+// ~35 of an integer division, and a work item needs three of them four times per tile (two cursors, loop top, epilogue).
+__device__ __forceinline__ int div_by(int n, int d, uint32_t inv) {
+  int q = (int)__umulhi((uint32_t)n, inv);
+  return (n - q * d >= d) ? q + 1 : q;
+}
 template <class RC>
 __device__ __forceinline__ RingItem ring_item(const GemmKArgs& p, int id) {
+  static_assert((RC::GH & (RC::GH - 1)) == 0, "GH is a power of two");
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int split = id / ntiles, tile = id - split * ntiles;
+  const int split = p.split_k > 1 ? div_by(id, ntiles, p.inv_ntiles) : 0, tile = id - split * ntiles;
   const int per_panel = RC::GH * p.tiles_n;
-  const int panel = tile / per_panel, r = tile - panel * per_panel;
+  const int panel = div_by(tile, per_panel, p.inv_per_panel), r = tile - panel * per_panel;
   const int left = p.tiles_m - panel * RC::GH;
   const int gh = left < RC::GH ? left : RC::GH;
-  const int tn = r / gh, tm = panel * RC::GH + (r - tn * gh);
+  const int tn = gh == RC::GH ? (int)((unsigned)r / (unsigned)RC::GH) : r / gh, tm = panel * RC::GH + (r - tn * gh);   // only the ragged last panel divides
   RingItem it;
   it.m0 = (int64_t)tm * RC::BM; it.n0 = (int64_t)tn * RC::BN; it.split = split;
   it.k_begin = (int64_t)split * p.k_per_split;
@@ -769,24 +780,47 @@ __device__ __forceinline__ void act_bwd8_mul_sel(float (&v)[8], const float (&a)
 // store-layout operand (residual, act' operand) into the per-row pieces the accumulator layout needs.
 __device__ __forceinline__ uint32_t dpp_quad_xor1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false); }
 __device__ __forceinline__ uint32_t dpp_quad_xor2(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false); }
-__device__ __forceinline__ void quad_transpose(u32x4 (&P)[4], int lane) {
-  const bool o0 = (lane & 1) != 0, o1 = (lane & 2) != 0;
-  u32x4 T[4];
+// One exchange stage for two of the four pieces = 8 dwords: O = lane in MASK ? OWN : quad_perm(OTHER), as ONE
+// v_cndmask_b32_dpp per dword.  (The compiler keeps select conditions in arbitrary SGPR pairs, i.e. the VOP3 form of
+// v_cndmask, which has no DPP encoding on gfx9: it emits v_mov_b32_dpp + v_cndmask_b32, twice the VALU slots; the epilogue
+// is VALU-bound -- the matrix pipe idles while it runs.)  The two s_mov_b32 are also the two wait states a DPP read
+// needs after a VALU write of its source.
+#define DVLA_QT_STAGE(QP, MLO, O, OTH, OWN)                                                                          \
+  asm("s_mov_b32 vcc_lo, " MLO "\n\ts_mov_b32 vcc_hi, " MLO "\n\t"                                                    \
+      "v_cndmask_b32_dpp %0, %8, %16, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                      \
+      "v_cndmask_b32_dpp %1, %9, %17, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                      \
+      "v_cndmask_b32_dpp %2, %10, %18, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_cndmask_b32_dpp %3, %11, %19, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_cndmask_b32_dpp %4, %12, %20, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_cndmask_b32_dpp %5, %13, %21, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_cndmask_b32_dpp %6, %14, %22, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_cndmask_b32_dpp %7, %15, %23, vcc " QP " row_mask:0xf bank_mask:0xf"                                          \
+      : "=&v"(O[0]), "=&v"(O[1]), "=&v"(O[2]), "=&v"(O[3]), "=&v"(O[4]), "=&v"(O[5]), "=&v"(O[6]), "=&v"(O[7])         \
+      : "v"(OTH[0]), "v"(OTH[1]), "v"(OTH[2]), "v"(OTH[3]), "v"(OTH[4]), "v"(OTH[5]), "v"(OTH[6]), "v"(OTH[7]),        \
+        "v"(OWN[0]), "v"(OWN[1]), "v"(OWN[2]), "v"(OWN[3]), "v"(OWN[4]), "v"(OWN[5]), "v"(OWN[6]), "v"(OWN[7])         \
+      : "vcc")
+__device__ __forceinline__ void quad_transpose(u32x4 (&P)[4], int /*lane*/) {
+  // flat views: pieces {a, b} -> 8 dwords
+  auto gather = [&](uint32_t (&v)[8], const u32x4& a, const u32x4& b) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+    for (int d = 0; d < 4; ++d) { v[d] = a[d]; v[4 + d] = b[d]; }
+  };
+  uint32_t ev[8], od[8], te[8], to[8];
+  // stage 1 (lane xor 1): T[c] = odd(c) != odd(lane) ? xor1(P[c ^ 1]) : P[c]; v_cndmask takes OWN where the vcc bit is set
+  gather(ev, P[0], P[2]);                     // even pieces, their partners are the odd ones
+  gather(od, P[1], P[3]);
+  DVLA_QT_STAGE("quad_perm:[1,0,3,2]", "0x55555555", te, od, ev);   // even c keeps its own on even lanes
+  DVLA_QT_STAGE("quad_perm:[1,0,3,2]", "0xaaaaaaaa", to, ev, od);   // odd c keeps its own on odd lanes
+  // te = {T0, T2}, to = {T1, T3}.  stage 2 (lane xor 2): P[c] = (c & 2) != (lane & 2) ? xor2(T[c ^ 2]) : T[c]
+  uint32_t lo[8], hi[8], plo[8], phi[8];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const uint32_t t = dpp_quad_xor1(P[c ^ 1][d]);
-      T[c][d] = (((c & 1) != 0) != o0) ? t : P[c][d];
-    }
+  for (int d = 0; d < 4; ++d) { lo[d] = te[d]; lo[4 + d] = to[d]; hi[d] = te[4 + d]; hi[4 + d] = to[4 + d]; }   // {T0, T1}, {T2, T3}
+  DVLA_QT_STAGE("quad_perm:[2,3,0,1]", "0x33333333", plo, hi, lo);  // c = 0, 1 keep their own where lane & 2 == 0
+  DVLA_QT_STAGE("quad_perm:[2,3,0,1]", "0xcccccccc", phi, lo, hi);
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const uint32_t t = dpp_quad_xor2(T[c ^ 2][d]);
-      P[c][d] = (((c & 2) != 0) != o1) ? t : T[c][d];
-    }
+  for (int d = 0; d < 4; ++d) { P[0][d] = plo[d]; P[1][d] = plo[4 + d]; P[2][d] = phi[d]; P[3][d] = phi[4 + d]; }
 }
+#undef DVLA_QT_STAGE
 
 template <int TM, int EPI>
 __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], int lane, int64_t m_base,

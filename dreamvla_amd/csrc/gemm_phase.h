@@ -198,6 +198,14 @@ void gemm_phase_kernel(GemmKArgs p) {
       if (stamps && kt_global < 32 && lane == 0) stamps[kt_global * 8 + e] = __builtin_amdgcn_s_memtime();
     }
   };
+  // tile-boundary stamps (uint64[2][16][4] behind the K-tile stamps): 0 = K loop left, 1 = groups re-aligned, 2 = epilogue
+  // code done (all stores issued), 3 = the next tile's K loop entered
+  auto stamp_tile = [&](int tile, int e) {
+    if constexpr ((DBG & 64) != 0) {
+      if (stamps && tile < 16 && lane == 0)
+        (reinterpret_cast<uint64_t*>(p.workspace) + 512 + (wave >> 2) * 64)[tile * 4 + e] = __builtin_amdgcn_s_memtime();
+    }
+  };
   int u = 0, ua = 0;   // global K-tile counter of the multiply, and u % 3
   for (int it = 0;; ++it) {
     int seg_ns;
@@ -217,6 +225,7 @@ void gemm_phase_kernel(GemmKArgs p) {
 
     if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one segment behind group 0
     __builtin_amdgcn_sched_barrier(0);
+    if (it > 0) stamp_tile(it - 1, 3);
 
     for (int kt = 0; kt < seg_ns; ++kt, ++u, ua = (ua == PCfg::NA - 1 ? 0 : ua + 1)) {
       const char* bufA = smem + ua * PCfg::A_BYTES;                         // ua = u % 3
@@ -318,8 +327,10 @@ void gemm_phase_kernel(GemmKArgs p) {
       stamp(u, 7);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
     }
+    stamp_tile(it, 0);
     if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align: both groups run the epilogue together
     __builtin_amdgcn_sched_barrier(0);
+    stamp_tile(it, 1);
     Seg w;
     int lane_e = lane;
     {
@@ -391,6 +402,8 @@ void gemm_phase_kernel(GemmKArgs p) {
       }
       reg_epilogue<4, EPI>(p, acc, lane_e, w.m0 + grp * 128, w.n0 + wc * 64, w.split);
     }
+    if constexpr ((DBG & 64) != 0) __builtin_amdgcn_sched_barrier(0);
+    stamp_tile(it, 2);
   }
 }
 

@@ -996,7 +996,9 @@ class _SelfAttention(torch.autograd.Function):
         else:
             dqkv = torch.empty_like(qkv)
             if dead is not None and dead.numel():
-                dqkv.view(B, L, 3, H * 64)[:, dead, 1:] = 0   # dk / dv of the never-visible keys (a few rows, not the buffer)
+                # dk / dv of the never-visible keys (a few rows, not the buffer); index_fill_, not `[...] = 0`: the indexed
+                # assignment uploads its scalar from the host every call (a copy + 60 us of idle GPU per layer)
+                dqkv.view(B, L, 3, H * 64)[:, :, 1:].index_fill_(1, dead, 0)
         d5 = dqkv.view(B, L, 3, H, 64)
         do = _req(dout, "attention.grad_output").contiguous().view(B, L, H, 64)
         attn_bwd_raw(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], o, lse, do, d5[:, :, 0], d5[:, :, 1], d5[:, :, 2],

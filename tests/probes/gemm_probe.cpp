@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -106,15 +107,20 @@ struct Problem {
   void release() { for (Buf* b : {&A, &B, &C, &bias, &preact, &dact, &res, &ws}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } }
 };
 
+// DVLA_PROBE_PAD_C / DVLA_PROBE_PAD_AB (elements): leading dimensions of C (and the epilogue operands) / of A and B are padded
+// by that much -- does a power-of-two row stride cost anything (channel camping)?  Timing only: the checks assume ld = width.
+static int64_t env_pad(const char* name) { const char* e = getenv(name); return e ? atoll(e) : 0; }
 static Problem make_problem(const Case& c, int64_t M) {
   Problem q; memset(&q.p, 0, sizeof(q.p));
-  const int64_t N = c.N, K = c.K;
-  q.A = dalloc((size_t)M * K * 2); q.B = dalloc((size_t)N * K * 2);
+  const int64_t K = c.K, padC = env_pad("DVLA_PROBE_PAD_C"), padAB = env_pad("DVLA_PROBE_PAD_AB");
+  const int64_t N = c.N + padC;   // allocation / leading-dimension width of the C-shaped operands (p.N stays c.N)
+  const int64_t lda = (c.at ? M : K) + padAB, ldb = (c.bt ? c.N : K) + padAB;
+  q.A = dalloc((size_t)(c.at ? K : M) * lda * 2); q.B = dalloc((size_t)(c.bt ? K : c.N) * ldb * 2);
   fill(q.A, 1u, 1.0f); fill(q.B, 2u, 0.06f);
   dvla_gemm_params& p = q.p;
-  p.A = q.A.p; p.lda = c.at ? M : K; p.a_trans = c.at;
-  p.B = q.B.p; p.ldb = c.bt ? N : K; p.b_trans = c.bt;
-  p.M = M; p.N = N; p.K = K; p.split_k = c.split_k;
+  p.A = q.A.p; p.lda = lda; p.a_trans = c.at;
+  p.B = q.B.p; p.ldb = ldb; p.b_trans = c.bt;
+  p.M = M; p.N = c.N; p.K = K; p.split_k = c.split_k;
   const bool f32 = c.epi == "f32";
   q.C = dalloc((size_t)M * N * (f32 ? 4 : 2));
   p.C = q.C.p; p.ldc = N; p.c_dtype = f32 ? DVLA_DT_F32 : DVLA_DT_BF16;
@@ -220,16 +226,33 @@ int main(int argc, char** argv) {
   if (stamps) {   // timeline of the phase kernel (variants 89 / 97 / 98): s_memtime at the 8 segment edges of the first 32 K-tiles, waves 0 and 4
     Case c{"stamps", 20832, 4096, stamps_k, 0, 0, "plain", 1};
     Problem q = make_problem(c, c.M);
-    q.ws = dalloc(2 * 256 * 8); q.p.workspace = q.ws.p;
+    q.ws = dalloc((2 * 256 + 2 * 64) * 8); q.p.workspace = q.ws.p;
     printf("# s_memtime ticks (shader cycles, MI355X_MICROARCH.md); segments of K-tiles 3..6: LOAD1 | wait+barrier | MFMA1 | barrier | LOAD2 | wait+barrier | MFMA2(+vmcnt) ; period\n");
     for (int v : stamp_variants) {
       CK(hipMemset(q.ws.p, 0, q.ws.bytes));
       dvla_set_gemm_variant(v);
       for (int it = 0; it < 3; ++it) (void)dvla_gemm_bf16(&q.p, nullptr);
+      if (hog > 0) {   // --hog N --stamps: the stamped launch shares the chip with N LDS-hogging workgroups, i.e. runs on 256 - N CUs
+        hipStream_t hs; int* sink; CK(hipStreamCreateWithFlags(&hs, hipStreamNonBlocking)); CK(hipMalloc(&sink, 64));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(hog_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        CK(hipDeviceSynchronize());
+        CK(hipMemset(q.ws.p, 0, q.ws.bytes));
+        hipLaunchKernelGGL(hog_kernel, dim3(hog), dim3(256), 96 * 1024, hs, 12000000LL, sink);
+        usleep(500);
+        (void)dvla_gemm_bf16(&q.p, nullptr);
+      }
       dvla_set_gemm_variant(0);
       CK(hipDeviceSynchronize());
-      std::vector<unsigned long long> h(512);
-      CK(hipMemcpy(h.data(), q.ws.p, 512 * 8, hipMemcpyDeviceToHost));
+      std::vector<unsigned long long> h(512 + 128);
+      CK(hipMemcpy(h.data(), q.ws.p, (512 + 128) * 8, hipMemcpyDeviceToHost));
+      if (getenv("DVLA_STAMPS_ALL")) {
+        for (int g = 0; g < 2; ++g)
+          for (int tile = 0; tile < 4; ++tile) {
+            const unsigned long long* e = &h[512 + g * 64 + tile * 4];
+            printf("variant %d group %d tile %d boundary: re-align %5lld | epilogue code (conversion + store issue) %6lld | to next K loop %5lld   total %6lld\n", v, g, tile,
+                   (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[3] - e[0]));
+          }
+      }
       if (getenv("DVLA_STAMPS_ALL")) {   // every recorded K-tile: start (relative to K-tile 0), length, gap to the next one (tile boundaries show up as gaps)
         for (int g = 0; g < 2; ++g)
           for (int kt = 0; kt < 31; ++kt) {

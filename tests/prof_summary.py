@@ -68,6 +68,26 @@ def main():
              f"{'kernel':<50}{'calls':>6}{'ms':>10}{'%':>7}{'avg us':>10}"]
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lines.append(f"{n:<50}{c:>6}{t / 1e6:>10.2f}{100.0 * t / busy:>7.1f}{t / c / 1e3:>10.1f}")
+    # where the GPU idles inside the window: gaps between the end of one kernel and the start of the next
+    win = [(s, e, n) for s, e, n in rows if s >= w0 and e <= w1]
+    gaps, by_prev, t_end, prev = [], defaultdict(lambda: [0, 0]), None, None
+    for s, e, n in win:
+        if t_end is not None and s > t_end:
+            gaps.append((s - t_end, prev, n, (t_end - w0) / 1e6))
+            by_prev[prev + " -> " + n][0] += 1
+            by_prev[prev + " -> " + n][1] += s - t_end
+        if t_end is None or e > t_end:
+            t_end, prev = e, n
+    idle = sum(g[0] for g in gaps)
+    lines.append("")
+    lines.append(f"idle inside the window: {idle / 1e6:.2f} ms in {len(gaps)} gaps (median {sorted(g[0] for g in gaps)[len(gaps) // 2] / 1e3:.1f} us); "
+                 f"gaps > 20 us: {sum(g[0] for g in gaps if g[0] > 20000) / 1e6:.2f} ms in {sum(1 for g in gaps if g[0] > 20000)}")
+    lines.append("largest gaps (us, at ms into the step, after kernel -> before kernel):")
+    for g in sorted(gaps, reverse=True)[:15]:
+        lines.append(f"  {g[0] / 1e3:>8.1f}  @{g[3]:>7.2f}  {g[1]} -> {g[2]}")
+    lines.append("idle by kernel pair (ms, count):")
+    for k, (c, t) in sorted(by_prev.items(), key=lambda kv: -kv[1][1])[:15]:
+        lines.append(f"  {t / 1e6:>7.2f} {c:>5}  {k}")
     txt = "\n".join(lines)
     print(txt)
     if len(sys.argv) > 2:
