@@ -36,6 +36,7 @@
 #pragma once
 #include "common.h"
 #include "../../include/dvla.h"
+#include <type_traits>
 
 namespace dvla_gemm {
 
@@ -752,6 +753,8 @@ constexpr int epi_res(int e) {    // residual: 0 = none, 1 = present, -1 = runti
 inline int epi_class(const GemmKArgs& a) {
   if (a.split_k > 1 || a.c_f32) return EPI_F32;
   const bool dact = a.dact_aux != nullptr, res = a.residual != nullptr;
+  // dropout is compiled into the residual class only (the model drops in front of residual additions); elsewhere -> generic
+  if (a.has_drop && !(res && !dact)) return EPI_GEN;
   if (!dact && !res) return a.act == ACT_NONE ? EPI_P0 : a.act == ACT_GELU_ERF ? EPI_P_ERF : a.act == ACT_GELU_TANH ? EPI_P_TANH : EPI_GEN;
   if (a.act != ACT_NONE || (dact && res) || a.preact != nullptr) return EPI_GEN;
   if (res) return EPI_A0;
@@ -822,9 +825,10 @@ __device__ __forceinline__ void quad_transpose(u32x4 (&P)[4], int /*lane*/) {
 }
 #undef DVLA_QT_STAGE
 
-template <int TM, int EPI>
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };   // timeline builds pass a recorder instead
+template <int TM, int EPI, class ST = NoStamp>
 __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], int lane, int64_t m_base,
-                                             int64_t n_base, int split) {
+                                             int64_t n_base, int split, ST st = ST()) {
   if (n_base >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
   constexpr bool AUXV = epi_aux(EPI);            // store-layout operand vectors are prefetched (bf16 outputs)
   constexpr bool AUX = AUXV || EPI == EPI_F32;   // the class may read an act' operand / a residual / old C values at all
@@ -878,88 +882,105 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
         L[c] = *reinterpret_cast<const u32x4*>(src + ncol_line);
       }
     };
-    u32x4 nx[4];      // (unused, and removed by the compiler, in the classes without a store-layout operand) raw lines of the NEXT row slab: requested one slab ahead, in front of this slab's stores
-    if constexpr (AUXV) load_aux_lines(0, nx);
-    static_for<TM>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      u32x4 ax[4];
-      if constexpr (AUXV) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ax[c] = nx[c];
-        quad_transpose(ax, lane);            // -> ax[c] = bytes 16 (2c + g) .. of THIS lane's row (the old store-layout vector)
-      }
-      const int64_t m = m_base + j * 32 + l31;
-      uint32_t rowkey = 0;
-      if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
-      u32x4 PC[4], PP[4];
-      static_for<4>([&](auto cc) {
-        constexpr int c = decltype(cc)::value, i = c >> 1, q = c & 1;
-        float z0[4], z1[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { z0[e] = acc[i][j][8 * q + e]; z1[e] = acc[i][j][8 * q + 4 + e]; }
-        if (p.preact) {
-          uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
-          // the activation sees the stored (bf16) pre-activation
-          unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
-          swap_halves(a0, b0); swap_halves(a1, b1);
-          PP[c] = u32x4{a0, a1, b0, b1};
-        }
-        act_fwd4_sel<epi_act(EPI)>(z0, p.act);
-        act_fwd4_sel<epi_act(EPI)>(z1, p.act);
-        if (p.has_drop) {
-          const uint32_t n = (uint32_t)(n_base + 32 * i + 16 * q + 4 * g);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t h0 = drop_hash_rk(rowkey, n + e), h1 = drop_hash_rk(rowkey, n + 8 + e);
-            z0[e] = (h0 >= p.drop_thr) ? z0[e] * p.drop_scale : 0.f;
-            z1[e] = (h1 >= p.drop_thr) ? z1[e] * p.drop_scale : 0.f;
-          }
-        }
-        uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
+    st(0);
+    // dropout and the pre-activation store are COMPILE-TIME inside the slab loop: as run-time flags they were tested once per
+    // column group (32 uniform branches per tile, each re-deriving its condition from a spilled SGPR: a slab's conversion took
+    // 720-1700 cycles by the s_memtime slab stamps of the timeline build, 410-510 without them); a class holds at most two
+    // copies of the loop (P classes: with / without pre-activation; residual class: with / without dropout)
+    auto slabs = [&](auto dropc, auto prec) {
+      constexpr bool DROP = decltype(dropc)::value, PRE = decltype(prec)::value;
+      u32x4 nx[4];      // (unused, and removed by the compiler, in the classes without a store-layout operand) raw lines of the NEXT row slab: requested one slab ahead, in front of this slab's stores
+      if constexpr (AUXV) load_aux_lines(0, nx);
+      static_for<TM>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        u32x4 ax[4];
         if constexpr (AUXV) {
-          // act' / residual are applied to the ROUNDED branch value (the reference materialises it as a bf16 tensor)
-          unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
-          uint32_t ux = ax[c][0], uy = ax[c][1], uz = ax[c][2], uw = ax[c][3];
-          swap_halves(ux, uz); swap_halves(uy, uw);   // -> accumulator layout: (x, y) = quad 2q, (z, w) = quad 2q+1
-          if (has_dact) {
-            float a8[8];
-            unpack2(ux, a8[0], a8[1]); unpack2(uy, a8[2], a8[3]); unpack2(uz, a8[4], a8[5]); unpack2(uw, a8[6], a8[7]);
-            float v8[8] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3]};
-            act_bwd8_mul_sel<epi_dact(EPI)>(v8, a8, p.dact);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { z0[e] = v8[e]; z1[e] = v8[4 + e]; }
-          } else {
-            float r0, r1;
-            unpack2(ux, r0, r1); z0[0] += r0; z0[1] += r1;
-            unpack2(uy, r0, r1); z0[2] += r0; z0[3] += r1;
-            unpack2(uz, r0, r1); z1[0] += r0; z1[1] += r1;
-            unpack2(uw, r0, r1); z1[2] += r0; z1[3] += r1;
-          }
-          a0 = pack2bf(z0[0], z0[1]); a1 = pack2bf(z0[2], z0[3]); b0 = pack2bf(z1[0], z1[1]); b1 = pack2bf(z1[2], z1[3]);
+          for (int c = 0; c < 4; ++c) ax[c] = nx[c];
+          quad_transpose(ax, lane);            // -> ax[c] = bytes 16 (2c + g) .. of THIS lane's row (the old store-layout vector)
         }
-        swap_halves(a0, b0); swap_halves(a1, b1);
-        PC[c] = u32x4{a0, a1, b0, b1};
-        // the next slab's lines are requested HALF WAY through this one: column group 0's accumulators and operand pieces are
-        // dead by now (a full slab of look-ahead next to 128 accumulators spilled 15-22 registers), and the request still sits
-        // in front of this slab's stores, so waiting for it never waits for them
-        if constexpr (AUXV && c == 1 && j + 1 < TM) load_aux_lines(j + 1, nx);
-      });
-      if (p.preact) {
-        quad_transpose(PP, lane);
+        const int64_t m = m_base + j * 32 + l31;
+        uint32_t rowkey = 0;
+        if constexpr (DROP) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)m);
+        u32x4 PC[4], PP[4];
+        static_for<4>([&](auto cc) {
+          constexpr int c = decltype(cc)::value, i = c >> 1, q = c & 1;
+          float z0[4], z1[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { z0[e] = acc[i][j][8 * q + e]; z1[e] = acc[i][j][8 * q + 4 + e]; }
+          if constexpr (PRE) {
+            uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
+            // the activation sees the stored (bf16) pre-activation
+            unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
+            swap_halves(a0, b0); swap_halves(a1, b1);
+            PP[c] = u32x4{a0, a1, b0, b1};
+          }
+          act_fwd4_sel<epi_act(EPI)>(z0, p.act);
+          act_fwd4_sel<epi_act(EPI)>(z1, p.act);
+          if constexpr (DROP) {
+            const uint32_t n = (uint32_t)(n_base + 32 * i + 16 * q + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t h0 = drop_hash_rk(rowkey, n + e), h1 = drop_hash_rk(rowkey, n + 8 + e);
+              z0[e] = (h0 >= p.drop_thr) ? z0[e] * p.drop_scale : 0.f;
+              z1[e] = (h1 >= p.drop_thr) ? z1[e] * p.drop_scale : 0.f;
+            }
+          }
+          uint32_t a0 = pack2bf(z0[0], z0[1]), a1 = pack2bf(z0[2], z0[3]), b0 = pack2bf(z1[0], z1[1]), b1 = pack2bf(z1[2], z1[3]);
+          if constexpr (AUXV) {
+            // act' / residual are applied to the ROUNDED branch value (the reference materialises it as a bf16 tensor)
+            unpack2(a0, z0[0], z0[1]); unpack2(a1, z0[2], z0[3]); unpack2(b0, z1[0], z1[1]); unpack2(b1, z1[2], z1[3]);
+            uint32_t ux = ax[c][0], uy = ax[c][1], uz = ax[c][2], uw = ax[c][3];
+            swap_halves(ux, uz); swap_halves(uy, uw);   // -> accumulator layout: (x, y) = quad 2q, (z, w) = quad 2q+1
+            if (has_dact) {
+              float a8[8];
+              unpack2(ux, a8[0], a8[1]); unpack2(uy, a8[2], a8[3]); unpack2(uz, a8[4], a8[5]); unpack2(uw, a8[6], a8[7]);
+              float v8[8] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3]};
+              act_bwd8_mul_sel<epi_dact(EPI)>(v8, a8, p.dact);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { z0[e] = v8[e]; z1[e] = v8[4 + e]; }
+            } else {
+              float r0, r1;
+              unpack2(ux, r0, r1); z0[0] += r0; z0[1] += r1;
+              unpack2(uy, r0, r1); z0[2] += r0; z0[3] += r1;
+              unpack2(uz, r0, r1); z1[0] += r0; z1[1] += r1;
+              unpack2(uw, r0, r1); z1[2] += r0; z1[3] += r1;
+            }
+            a0 = pack2bf(z0[0], z0[1]); a1 = pack2bf(z0[2], z0[3]); b0 = pack2bf(z1[0], z1[1]); b1 = pack2bf(z1[2], z1[3]);
+          }
+          swap_halves(a0, b0); swap_halves(a1, b1);
+          PC[c] = u32x4{a0, a1, b0, b1};
+          // the next slab's lines are requested HALF WAY through this one: column group 0's accumulators and operand pieces are
+          // dead by now (a full slab of look-ahead next to 128 accumulators spilled 15-22 registers), and the request still sits
+          // in front of this slab's stores, so waiting for it never waits for them
+          if constexpr (AUXV && c == 1 && j + 1 < TM) load_aux_lines(j + 1, nx);
+        });
+        if constexpr (PRE) {
+          quad_transpose(PP, lane);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int64_t mr = m_base + j * 32 + 4 * qa + c;
+            if (mr < p.M) *reinterpret_cast<u32x4*>(p.preact + mr * p.ld_preact + ncol_line) = PP[c];
+          }
+        }
+        quad_transpose(PC, lane);
+        st(1 + 2 * j);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int64_t mr = m_base + j * 32 + 4 * qa + c;
-          if (mr < p.M) *reinterpret_cast<u32x4*>(p.preact + mr * p.ld_preact + ncol_line) = PP[c];
+          if (mr < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + mr * p.ldc + ncol_line) = PC[c];
         }
-      }
-      quad_transpose(PC, lane);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int64_t mr = m_base + j * 32 + 4 * qa + c;
-        if (mr < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + mr * p.ldc + ncol_line) = PC[c];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
+        __builtin_amdgcn_sched_barrier(0);
+        st(2 + 2 * j);
+      });
+    };
+    if constexpr (EPI == EPI_A0) {
+      if (p.has_drop) slabs(std::true_type{}, std::false_type{}); else slabs(std::false_type{}, std::false_type{});
+    } else if constexpr (AUXV) {
+      slabs(std::false_type{}, std::false_type{});
+    } else {
+      if (p.preact) slabs(std::false_type{}, std::true_type{}); else slabs(std::false_type{}, std::false_type{});
+    }
     return;
   }
 

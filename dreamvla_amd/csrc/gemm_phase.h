@@ -400,7 +400,19 @@ void gemm_phase_kernel(GemmKArgs p) {
             }
         }
       }
-      reg_epilogue<4, EPI>(p, acc, lane_e, w.m0 + grp * 128, w.n0 + wc * 64, w.split);
+      if constexpr ((DBG & 64) != 0) {
+        // slab stamps of tile 1 (uint64[2][16] behind the boundary stamps): 0 = entry, 1 + 2j = slab j converted and transposed,
+        // 2 + 2j = slab j's stores issued
+        auto st = [&](int idx) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (stamps && it == 1 && lane == 0)
+            (reinterpret_cast<uint64_t*>(p.workspace) + 640 + (wave >> 2) * 16)[idx] = __builtin_amdgcn_s_memtime();
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        reg_epilogue<4, EPI>(p, acc, lane_e, w.m0 + grp * 128, w.n0 + wc * 64, w.split, st);
+      } else {
+        reg_epilogue<4, EPI>(p, acc, lane_e, w.m0 + grp * 128, w.n0 + wc * 64, w.split);
+      }
     }
     if constexpr ((DBG & 64) != 0) __builtin_amdgcn_sched_barrier(0);
     stamp_tile(it, 2);

@@ -226,7 +226,7 @@ int main(int argc, char** argv) {
   if (stamps) {   // timeline of the phase kernel (variants 89 / 97 / 98): s_memtime at the 8 segment edges of the first 32 K-tiles, waves 0 and 4
     Case c{"stamps", 20832, 4096, stamps_k, 0, 0, "plain", 1};
     Problem q = make_problem(c, c.M);
-    q.ws = dalloc((2 * 256 + 2 * 64) * 8); q.p.workspace = q.ws.p;
+    q.ws = dalloc((2 * 256 + 2 * 64 + 32) * 8); q.p.workspace = q.ws.p;
     printf("# s_memtime ticks (shader cycles, MI355X_MICROARCH.md); segments of K-tiles 3..6: LOAD1 | wait+barrier | MFMA1 | barrier | LOAD2 | wait+barrier | MFMA2(+vmcnt) ; period\n");
     for (int v : stamp_variants) {
       CK(hipMemset(q.ws.p, 0, q.ws.bytes));
@@ -243,8 +243,8 @@ int main(int argc, char** argv) {
       }
       dvla_set_gemm_variant(0);
       CK(hipDeviceSynchronize());
-      std::vector<unsigned long long> h(512 + 128);
-      CK(hipMemcpy(h.data(), q.ws.p, (512 + 128) * 8, hipMemcpyDeviceToHost));
+      std::vector<unsigned long long> h(512 + 128 + 32);
+      CK(hipMemcpy(h.data(), q.ws.p, (512 + 128 + 32) * 8, hipMemcpyDeviceToHost));
       if (getenv("DVLA_STAMPS_ALL")) {
         for (int g = 0; g < 2; ++g)
           for (int tile = 0; tile < 4; ++tile) {
@@ -252,6 +252,14 @@ int main(int argc, char** argv) {
             printf("variant %d group %d tile %d boundary: re-align %5lld | epilogue code (conversion + store issue) %6lld | to next K loop %5lld   total %6lld\n", v, g, tile,
                    (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[3] - e[0]));
           }
+      }
+      if (getenv("DVLA_STAMPS_ALL")) {   // inside tile 1's epilogue: per 32-row slab, conversion + transposition | store issue
+        for (int g = 0; g < 2; ++g) {
+          const unsigned long long* e = &h[640 + g * 16];
+          printf("variant %d group %d tile 1 epilogue slabs (convert | stores):", v, g);
+          for (int j = 0; j < 4; ++j) printf("  %5lld | %5lld", (long long)(e[1 + 2 * j] - e[2 * j]), (long long)(e[2 + 2 * j] - e[1 + 2 * j]));
+          printf("   (entry at +%lld after re-align)\n", (long long)(e[0] - h[512 + g * 64 + 4 + 1]));
+        }
       }
       if (getenv("DVLA_STAMPS_ALL")) {   // every recorded K-tile: start (relative to K-tile 0), length, gap to the next one (tile boundaries show up as gaps)
         for (int g = 0; g < 2; ++g)

@@ -65,6 +65,22 @@ __global__ __launch_bounds__(512) void store_kernel(unsigned short* C, int64_t M
             if (PAT == 4) __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(dst)); else *dst = v;
           }
         }
+      } else if (PAT == 6 || PAT == 7) {
+        // 6: the whole-line mapping of reg_epilogue after the quad transposition (round 3): instruction c of slab j writes rows
+        //    4a + c; a row's 8 pieces come from lanes 4a + b (pieces 2b) and 32 + 4a + b (pieces 2b + 1): whole lines per
+        //    instruction, but a quad of lanes covers every OTHER 16 bytes of its line
+        // 7: pieces in lane order: lane = (m0, m4, m3, piece[2:0]), instruction = (m1, m2): 8 consecutive lanes = one line
+        const int l31 = lane & 31, g = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            int row, piece;
+            if (PAT == 6) { row = 4 * (l31 >> 2) + c; piece = 2 * (lane & 3) + g; }
+            else { row = (lane >> 5) | ((c & 1) << 1) | ((c >> 1) << 2) | (((lane >> 3) & 1) << 3) | (((lane >> 4) & 1) << 4); piece = lane & 7; }
+            const int64_t m = m0 + 32 * j + row;
+            if (m < M) *reinterpret_cast<uint4*>(C + m * N + n0 + 8 * piece) = v;
+          }
       } else if (PAT == 2) {
         const int l31 = lane & 31, g = lane >> 5;
 #pragma unroll
@@ -137,6 +153,8 @@ int main(int argc, char** argv) {
     for (int G : {8, 16, 32, 64, 128, 256}) {
       run_percu<3>("contiguous 128-KiB blocks", C, M, N, G);
       run_percu<1>("8 rows x 128 B per instruction", C, M, N, G);
+      run_percu<6>("whole lines, quad-sparse lane order (reg_epilogue round 3)", C, M, N, G);
+      run_percu<7>("whole lines, pieces in lane order", C, M, N, G);
       run_percu<0>("32 rows x 32 B per instruction (half exchange)", C, M, N, G);
       run_percu<2>("32 rows x 16 B per instruction (8-byte stores)", C, M, N, G);
     }
