@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVLA_LIB") or os.path.join(_HERE, "libdvla_hip.so")
 
 DT_BF16, DT_F32 = 0, 1
-ABI_VERSION = 3          # DVLA_ABI_VERSION of include/dvla.h
+ABI_VERSION = 4          # DVLA_ABI_VERSION of include/dvla.h
 ACT = {"none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "gelu_new": 2, "relu": 3, "silu": 4,
        "quick_gelu": 5, "tanh": 6, "sigmoid": 7}
 
@@ -36,6 +36,7 @@ class GemmParams(C.Structure):
         ("residual", C.c_void_p), ("ld_res", C.c_int64), ("res_rows", C.c_int64),
         ("accumulate", C.c_int32),
         ("split_k", C.c_int32), ("workspace", C.c_void_p),
+        ("ksum", C.c_void_p), ("ksum_dtype", C.c_int32), ("ksum_operand", C.c_int32), ("ksum_workspace", C.c_void_p),
     ]
 
 
@@ -81,6 +82,7 @@ _P, _I64, _I32, _F, _U32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint
 SYMBOLS = {
     "dvla_abi_version": (C.c_int, []),
     "dvla_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), _P]),
+    "dvla_gemm_ksum_partial_rows": (C.c_int64, [C.c_int32]),
     "dvla_set_gemm_variant": (None, [C.c_int]),
     "dvla_last_gemm_variant": (C.c_int, []),
     "dvla_set_gemm_schedule": (None, [C.c_int, C.c_int]),

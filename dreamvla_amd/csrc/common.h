@@ -234,3 +234,5 @@ static inline int dvla_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DVLA_OK : DVLA_ERR_LAUNCH;
 }
+// elementwise.hip: out[c] = sum of nrows fp32 partial rows (deterministic order); out bf16 or fp32
+int dvla_reduce_partial_rows(const float* partial, int nrows, int64_t cols, int64_t stride, void* out, int out_bf16, hipStream_t stream);

@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmArgs a) {
 extern "C" int dvla_abi_version(void) { return DVLA_ABI_VERSION; }
 extern "C" int64_t dvla_colsum_partial_rows(void) { return CS_BLOCKS; }
 
+// out[c] = sum of `nrows` fp32 partial rows (row stride `stride`): stage 2 alone -- the k-sum partials of a GEMM (gemm.hip)
+int dvla_reduce_partial_rows(const float* partial, int nrows, int64_t cols, int64_t stride, void* out, int out_bf16, hipStream_t stream) {
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, stream, partial, out, out_bf16, nrows, cols, stride);
+  return dvla_check_launch();
+}
+
 extern "C" int dvla_colsum_dt(const void* x, int64_t ld, int64_t rows, int64_t cols, void* out, int32_t out_dtype,
                               float* partial, void* stream_);
 extern "C" int dvla_colsum(const void* x, int64_t ld, int64_t rows, int64_t cols, float* out, float* partial, void* stream_) {

@@ -20,8 +20,33 @@ namespace {
 // split-K reduction: C[m,n] (+)= sum_s ws[s][m][n].  HBM-bound (splits x 4 B read + 2 or 4 B written per element): a thread
 // owns 8 consecutive n of one row -- two 16-byte loads per slice, one 16-byte bf16 store (or two fp32 stores); the scalar
 // fallback takes ragged / unaligned outputs.  (Round 1's one-element-per-thread version ran at ~1.3 TB/s: 2.5 ms per step.)
+// The k-sum partials of the same launch (dvla.h ksum_*) are reduced by extra workgroups of the same kernel (blockIdx >= main):
+// no second reduction launch per weight gradient.
+struct KsumJob { const float* partial; void* out; int64_t len; int rows; int out_bf16; unsigned main_blocks; };
+// a tail workgroup = 16 columns x 16 row parts (a thread adds rows / 16 partial rows: one batch of loads in flight, not a chain
+// of `rows` dependent ones), combined through LDS in a fixed order: deterministic
+__device__ __forceinline__ bool ksum_tail(const KsumJob& kj) {
+  if (blockIdx.x < kj.main_blocks) return false;
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int64_t c = (int64_t)(blockIdx.x - kj.main_blocks) * 16 + cl;
+  float s = 0.f;
+  if (c < kj.len)
+#pragma unroll 4
+    for (int r = part; r < kj.rows; r += 16) s += kj.partial[(int64_t)r * kj.len + c];
+  red[part][cl] = s;
+  __syncthreads();
+  if (part == 0 && c < kj.len) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][cl];
+    if (kj.out_bf16) reinterpret_cast<bf16_t*>(kj.out)[c] = f2bf(tot); else reinterpret_cast<float*>(kj.out)[c] = tot;
+  }
+  return true;
+}
 __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, void* C, int64_t ldc, int c_f32, int accumulate,
-                                         int64_t M, int64_t N, int splits) {
+                                         int64_t M, int64_t N, int splits, KsumJob kj) {
+  if (ksum_tail(kj)) return;
   const int64_t octs = N >> 3;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * octs) return;
@@ -48,7 +73,8 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, void* C, 
   }
 }
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* C, int64_t ldc, int c_f32, int accumulate,
-                                     int64_t M, int64_t N, int splits) {
+                                     int64_t M, int64_t N, int splits, KsumJob kj) {
+  if (ksum_tail(kj)) return;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * N) return;
   const int64_t m = idx / N, n = idx % N;
@@ -206,6 +232,13 @@ bool ring_ok(const GemmKArgs& a, int combo) {
   return true;
 }
 
+// the phase kernel addresses its operands as base + 32-bit byte offset: both must span less than 4 GiB
+bool phase_ok(const GemmKArgs& a, int combo) {
+  if (!ring_ok<PCfg>(a, combo)) return false;
+  const int64_t a_rows = (combo & 2) ? a.K : a.M, b_rows = (combo & 1) ? a.K : a.N;
+  return a_rows * a.lda * 2 < (1ll << 32) && b_rows * a.ldb * 2 < (1ll << 32);
+}
+
 // fraction of workgroup slots kept busy when `tiles` workgroups run `slots` at a time
 inline double fill(int64_t tiles, int64_t slots) {
   const int64_t rounds = (tiles + slots - 1) / slots;
@@ -230,6 +263,11 @@ extern "C" void dvla_get_gemm_schedule(int* oversubscribe, int* stream_k) {
   if (stream_k) *stream_k = streamk_enabled() ? 1 : 0;
 }
 
+extern "C" int64_t dvla_gemm_ksum_partial_rows(int32_t split_k) {
+  const int64_t fused = (int64_t)(split_k > 1 ? split_k : 1) * dvla_gemm::KSUM_PARTS, fallback = dvla_colsum_partial_rows();
+  return fused > fallback ? fused : fallback;
+}
+
 extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!q || !q->A || !q->B || !q->C) return DVLA_ERR_ARG;
@@ -242,8 +280,13 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     if (!q->workspace || q->bias || q->act || q->preact || q->dact_aux || q->residual || q->dropout_p > 0.f)
       return DVLA_ERR_ARG;
   }
+  if (q->ksum_operand != 0) {
+    if ((q->ksum_operand != 1 && q->ksum_operand != 2) || !q->ksum || !q->ksum_workspace) return DVLA_ERR_ARG;
+    if (q->ksum_dtype != DVLA_DT_F32 && q->ksum_dtype != DVLA_DT_BF16) return DVLA_ERR_ARG;
+  }
   GemmKArgs a;
   a.sk_tiles = 0; a.sk_slabs = nullptr; a.sk_flags = nullptr;
+  a.ksum_ws = q->ksum_workspace; a.ksum_op = 0;   // set below, once the configuration is known to carry the summing code
   a.A = reinterpret_cast<const bf16_t*>(q->A); a.lda = q->lda;
   a.B = reinterpret_cast<const bf16_t*>(q->B); a.ldb = q->ldb;
   a.C = q->C; a.ldc = q->ldc; a.c_f32 = (q->c_dtype == DVLA_DT_F32);
@@ -303,7 +346,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       if (ring_ok<RCfgS>(a, combo)) consider(3, 128, 128, 2, 2.9, 0.58);
       if (ring_ok<RCfgM64>(a, combo)) consider(4, 256, 128, 1, 3.6, 0.49);
       if (ring_ok<RCfgL>(a, combo)) consider(1, 256, 256, 1, 5.8, 0.85);
-      if (ring_ok<PCfg>(a, combo)) {
+      if (phase_ok(a, combo)) {
         consider(5, 256, 256, 1, 6.6, 0.775);
         // stream-K hybrid of the same kernel: fractional rounds, plus one slab write + one slab read per workgroup and the
         // less regular operand reuse of the shared round (~18 us measured over the plain schedule at equal round counts)
@@ -316,10 +359,14 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     } else if (variant == 4 && ring_ok<RCfgL>(a, combo)) choice = 1;
     else if (variant == 6 && ring_ok<RCfgS>(a, combo)) choice = 3;
     else if (variant == 7 && ring_ok<RCfgM64>(a, combo)) choice = 4;
-    else if (variant == 8 && ring_ok<PCfg>(a, combo)) choice = 5;
-    else if (variant == 9 && ring_ok<PCfg>(a, combo)) choice = 6;
-    else if (variant == 10 && ring_ok<PCfg>(a, combo)) choice = 7;
-    else if (variant > 80 && variant < 90 && combo == 0 && ring_ok<PCfg>(a, combo)) choice = 80 + (variant - 80);
+    else if (variant == 8 && phase_ok(a, combo)) choice = 5;
+    else if (variant == 9 && phase_ok(a, combo)) choice = 6;
+    else if (variant == 10 && phase_ok(a, combo)) choice = 7;
+    else if (variant > 80 && variant < 90 && combo == 0 && phase_ok(a, combo)) choice = 80 + (variant - 80);
+    // k-sums ride on the ring kernels of the fp32-output class (split-K partial sums or fp32 C: the weight gradients); the
+    // other configurations get the column-sum kernel below
+    const bool ksum_fused = q->ksum_operand != 0 && (choice == 1 || choice == 3 || choice == 4) && epi_class(a) == EPI_F32;
+    if (ksum_fused) a.ksum_op = q->ksum_operand;
     switch (choice) {
       case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;
       case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
@@ -344,16 +391,34 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   }
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
+  KsumJob kj{nullptr, nullptr, 0, 0, 0, 0xffffffffu};
+  if (q->ksum_operand != 0) {
+    const int64_t len = q->ksum_operand == 1 ? q->M : q->N;
+    if (a.ksum_op != 0) {
+      if (split_k > 1) kj = KsumJob{a.ksum_ws, q->ksum, len, split_k * KSUM_PARTS, q->ksum_dtype == DVLA_DT_BF16, 0u};   // rides on the split-K reduction below
+      else rc = dvla_reduce_partial_rows(a.ksum_ws, split_k * KSUM_PARTS, len, len, q->ksum, q->ksum_dtype == DVLA_DT_BF16, stream);
+    } else {
+      // this configuration does not sum: the column-sum kernel over the operand as it lies in memory (k-major layouts only)
+      const bool kmajor = q->ksum_operand == 1 ? q->a_trans != 0 : q->b_trans != 0;
+      if (!kmajor) return DVLA_ERR_UNSUPPORTED;
+      rc = dvla_colsum_dt(q->ksum_operand == 1 ? q->A : q->B, q->ksum_operand == 1 ? q->lda : q->ldb, q->K, len, q->ksum,
+                          q->ksum_dtype, q->ksum_workspace, stream_);
+    }
+    if (rc != DVLA_OK) return rc;
+  }
   if (split_k > 1) {
     const int64_t total = q->M * q->N;
     const bool vec = (q->N & 7) == 0 && aligned(a.workspace, 16) && aligned(q->C, 16) &&
                      (a.c_f32 ? (q->ldc & 3) == 0 : (q->ldc & 7) == 0);
+    const unsigned main_blocks = (unsigned)(((vec ? total / 8 : total) + 255) / 256);
+    const unsigned tail_blocks = kj.partial ? (unsigned)((kj.len + 15) / 16) : 0u;
+    if (kj.partial) kj.main_blocks = main_blocks;
     if (vec)
-      hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, stream,
-                         a.workspace, q->C, q->ldc, a.c_f32, q->accumulate, q->M, q->N, split_k);
+      hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, stream,
+                         a.workspace, q->C, q->ldc, a.c_f32, q->accumulate, q->M, q->N, split_k, kj);
     else
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                         a.workspace, q->C, q->ldc, a.c_f32, q->accumulate, q->M, q->N, split_k);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, stream,
+                         a.workspace, q->C, q->ldc, a.c_f32, q->accumulate, q->M, q->N, split_k, kj);
     rc = dvla_check_launch();
   }
   return rc;

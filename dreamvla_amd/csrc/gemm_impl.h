@@ -87,7 +87,41 @@ struct GemmKArgs {
   // stream-K hybrid schedule of the phase kernel (gemm_phase.h): the first sk_tiles tiles are cut into gridDim.x equal
   // K-iteration ranges, the others run one tile per workgroup and round; 0 = plain schedule
   int sk_tiles; float* sk_slabs; unsigned* sk_flags;
+  // k-sums of an operand (dvla.h ksum_*): fp32 partials [split][KSUM_PARTS][len], len = M (op 1) or N (op 2); EPI_F32 kernels only
+  float* ksum_ws; int ksum_op;
 };
+constexpr int KSUM_PARTS = 8;   // (up to 4 waves that share the operand rows, each taking every 4th k16-step) x (2 half-waves)
+
+// acc += sel . (the eight bf16 of a fragment), sel = two bf16 ones or 0 (adds nothing): four v_dot2c_f32_bf16 as pure builtins, no
+// branch -- in the compiler-scheduled ring loop a volatile asm or a branch between the k16-steps keeps the scheduler from
+// overlapping the next step's fragment reads with this step's MFMAs (measured: +10 % per launch).  (Element pairs spelled out:
+// indexing a bit-cast uint32x4 copy of f inside an unrolled loop made hipcc use dword 0 four times.)
+__device__ __forceinline__ float ksum_add_sel(bf16x8 f, uint32_t sel, float acc) {
+  typedef __attribute__((ext_vector_type(2))) short s2;
+  const hw_bf16x2 o = __builtin_bit_cast(hw_bf16x2, sel);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hw_bf16x2, s2{f[0], f[1]}), o, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hw_bf16x2, s2{f[2], f[3]}), o, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hw_bf16x2, s2{f[4], f[5]}), o, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hw_bf16x2, s2{f[6], f[7]}), o, acc, false);
+  return acc;
+}
+// a wave's k-sums of 32-row blocks -> the partial buffer.  pgroup < nshare: which of the nshare waves that hold the same operand
+// rows this is; the pgroups nobody owns (nshare .. 3) are zero-filled by pgroup 0.
+template <int NB, int NS>
+__device__ __forceinline__ void ksum_store(const GemmKArgs& p, const float (&sum)[NS], int lane, int split, int pgroup, int nshare,
+                                           int64_t idx0, int64_t len) {
+  static_assert(NB <= NS, "block count");
+  const int l31 = lane & 31, g = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int64_t idx = idx0 + b * 32 + l31;
+    if (idx < len) {
+      p.ksum_ws[((int64_t)split * KSUM_PARTS + pgroup * 2 + g) * len + idx] = sum[b];
+      if (pgroup == 0)
+        for (int z = nshare; z < KSUM_PARTS / 2; ++z) p.ksum_ws[((int64_t)split * KSUM_PARTS + z * 2 + g) * len + idx] = 0.f;
+    }
+  }
+}
 
 // Row-major image of a k-contiguous operand: row r = 128 B = 8 slots of 16 B; k-octet o of row r lives in slot
 // o ^ ((r >> 1) & 7).  Unpadded and conflict-free for ds_read_b128: in every 16-lane read group the rows of equal
@@ -649,6 +683,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// the same from a wave-uniform base (SGPR pair) + a per-lane 32-bit byte offset
+__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -1235,6 +1276,11 @@ void gemm_ring_kernel(GemmKArgs p) {
 #pragma unroll
   for (int d = 0; d < PD; ++d) issue_next();
 
+  // k-sums (dvla.h ksum_*): of the waves that hold the same operand rows (same wm: WN of them; same wn: WM), wave x sums the
+  // k16-steps ks with ks % W == x (ks_wn / ks_wm = -1: this launch does not sum that operand)
+  constexpr bool KSUM = EPI == EPI_F32 && RC::WM <= 4 && RC::WN <= 4;
+  const int ks_wn = (KSUM && p.ksum_op == 1) ? wn : -1, ks_wm = (KSUM && p.ksum_op == 2) ? wm : -1;
+
   int cslot = 0;
   for (int it = 0;; ++it) {
     const int id = item_of(it);
@@ -1248,6 +1294,11 @@ void gemm_ring_kernel(GemmKArgs p) {
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float ksa[TM], ksb[TN];          // k-sums of this wave's operand rows (EPI_F32 kernels; dead code elsewhere)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) ksa[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) ksb[i] = 0.f;
 
     for (int s = 0; s < w.ns; ++s) {
       // this wave's pieces of the oldest stage in flight have landed; the younger ones stay in flight
@@ -1272,9 +1323,20 @@ void gemm_ring_kernel(GemmKArgs p) {
 #pragma unroll
           for (int j = 0; j < TM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+        if constexpr (KSUM) {   // selector 0 in the waves whose k16-step this is not (and in launches that do not sum)
+          const uint32_t sa = ks_wn == ks % RC::WN ? 0x3f803f80u : 0u, sb = ks_wm == ks % RC::WM ? 0x3f803f80u : 0u;
+#pragma unroll
+          for (int j = 0; j < TM; ++j) ksa[j] = ksum_add_sel(fa[j], sa, ksa[j]);
+#pragma unroll
+          for (int i = 0; i < TN; ++i) ksb[i] = ksum_add_sel(fb[i], sb, ksb[i]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       cslot = (cslot + 1 == NS) ? 0 : cslot + 1;
+    }
+    if constexpr (KSUM) {
+      if (p.ksum_op == 1 && w.n0 == 0) ksum_store<TM, TM>(p, ksa, lane, w.split, wn, RC::WN < 4 ? RC::WN : 4, w.m0 + wm * (TM * 32), p.M);
+      if (p.ksum_op == 2 && w.m0 == 0) ksum_store<TN, TN>(p, ksb, lane, w.split, wm, RC::WM < 4 ? RC::WM : 4, w.n0 + wn * 64, p.N);
     }
     reg_epilogue<TM, EPI>(p, acc, lane, w.m0 + wm * (TM * 32), w.n0 + wn * 64, w.split);
   }

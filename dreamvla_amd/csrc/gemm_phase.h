@@ -125,19 +125,24 @@ void gemm_phase_kernel(GemmKArgs p) {
 
   // ---- DMA cursors: cursor X walks the K-tiles of the work-item list for operand X; this wave owns pieces
   // 4*wave .. 4*wave+3 of every 32-piece operand image.  nA / nB = number of tiles issued so far (buffer = n & 1). ----
-  const bf16_t* srcA[CPW];
-  const bf16_t* srcB[CPW];
+  // per-lane source of piece i as a 32-bit BYTE offset from the operand base (a scalar pair): one VGPR and one 32-bit add per
+  // piece instead of a 64-bit pointer -- 8 VGPRs of a loop that sits at the register limit (launch_phase takes operands that
+  // span less than 4 GiB; the others go to the ring kernels)
+  uint32_t srcA[CPW];
+  uint32_t srcB[CPW];
   int itA = 0, ktA = 0, nkA = 0, nA = 0; bool liveA = false;   // nA = slot (mod 3) of the next A image to issue
   int itB = 0, ktB = 0, nkB = 0, nB = 0; bool liveB = false;
-  const int64_t stepA = A_T ? (int64_t)BKS * p.lda : (int64_t)BKS;
-  const int64_t stepB = B_T ? (int64_t)BKS * p.ldb : (int64_t)BKS;
+  const uint32_t stepA = (uint32_t)(2 * (A_T ? (int64_t)BKS * p.lda : (int64_t)BKS));
+  const uint32_t stepB = (uint32_t)(2 * (B_T ? (int64_t)BKS * p.ldb : (int64_t)BKS));
   auto openA = [&](int it) {
     Seg w;
     liveA = seg_of(it, w);
     if (!liveA) return;
     nkA = w.ns; ktA = 0;
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) srcA[i] = dma_src<A_T, BM, BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, wave * CPW + i, lane);
+    for (int i = 0; i < CPW; ++i)
+      srcA[i] = (uint32_t)(reinterpret_cast<const char*>(dma_src<A_T, BM, BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, wave * CPW + i, lane)) -
+                           reinterpret_cast<const char*>(p.A));
   };
   auto openB = [&](int it) {
     Seg w;
@@ -145,7 +150,9 @@ void gemm_phase_kernel(GemmKArgs p) {
     if (!liveB) return;
     nkB = w.ns; ktB = 0;
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) srcB[i] = dma_src<B_T, BN, BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, wave * CPW + i, lane);
+    for (int i = 0; i < CPW; ++i)
+      srcB[i] = (uint32_t)(reinterpret_cast<const char*>(dma_src<B_T, BN, BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, wave * CPW + i, lane)) -
+                           reinterpret_cast<const char*>(p.B));
   };
   // one DMA piece (i = 0..3) of the next A / B image; *_done advances the cursor after the 4th.  Split like this so that
   // the pieces can be issued BETWEEN the MFMAs of a multiply segment: an LDS-DMA issue (M0 write + VMEM issue) costs
@@ -153,13 +160,13 @@ void gemm_phase_kernel(GemmKArgs p) {
   // them in the LOAD segments: those then took ~900 cycles against the partner's 512-cycle MFMA segment and paced the loop).
   auto pieceA = [&](int i) {
     const uint32_t dst = smem_base + (uint32_t)(nA * PCfg::A_BYTES + wave * (CPW * 1024) + i * 1024);
-    glds16(srcA[i], __builtin_amdgcn_readfirstlane(dst));
+    glds16s(p.A, srcA[i], __builtin_amdgcn_readfirstlane(dst));
     srcA[i] += stepA;
   };
   auto doneA = [&]() { nA = nA == PCfg::NA - 1 ? 0 : nA + 1; if (++ktA == nkA) openA(++itA); };
   auto pieceB = [&](int i) {
     const uint32_t dst = smem_base + (uint32_t)(PCfg::B_BASE + (nB & 1) * PCfg::B_BYTES + wave * (CPW * 1024) + i * 1024);
-    glds16(srcB[i], __builtin_amdgcn_readfirstlane(dst));
+    glds16s(p.B, srcB[i], __builtin_amdgcn_readfirstlane(dst));
     srcB[i] += stepB;
   };
   auto doneB = [&]() { ++nB; if (++ktB == nkB) openB(++itB); };
@@ -206,14 +213,21 @@ void gemm_phase_kernel(GemmKArgs p) {
         (reinterpret_cast<uint64_t*>(p.workspace) + 512 + (wave >> 2) * 64)[tile * 4 + e] = __builtin_amdgcn_s_memtime();
     }
   };
+  // (k-sums, dvla.h ksum_*: not in this kernel.  Tried three ways in round 3 -- dots after every k16-step in every wave, one block
+  // of dots at the end of a multiply segment in the wave whose k16-step it is, two dots behind every MFMA in per-operand copies of
+  // the segments: +5 ... +18 % per launch, or spills; tests/probes/ksum_probe.sh.  The ring kernels carry them for +2 %; asked for
+  // k-sums this kernel's launches get the column-sum kernel over the operand from dvla_gemm_bf16.)
   int u = 0, ua = 0;   // global K-tile counter of the multiply, and u % 3
   for (int it = 0;; ++it) {
-    int seg_ns;
-    {
-      Seg w0;
-      if (!seg_of(it, w0)) break;
-      seg_ns = w0.ns;       // the segment's tile origin / kind are recomputed for the epilogue: nothing but the K-tile
-    }                       // count stays live across the K loop (the loop sits at the 256-VGPR limit)
+    // The segment's tile origin / split / kind stay live across the K loop as SCALARS (6 SGPRs, spilled to VGPR lanes when
+    // the allocator runs out: one v_readlane each) -- re-deriving them for the epilogue was ~150 dependent scalar instructions
+    // = ~800 cycles per tile with the matrix pipe idle (`entry` of the slab stamps).  Everything per-lane is still derived
+    // from lane_e after the loop (the loop sits at the 256-VGPR limit).
+    Seg w;
+    if (!seg_of(it, w)) break;
+    w.m0 = __builtin_amdgcn_readfirstlane(w.m0); w.n0 = __builtin_amdgcn_readfirstlane(w.n0);
+    w.split = __builtin_amdgcn_readfirstlane(w.split); w.kind = __builtin_amdgcn_readfirstlane(w.kind);
+    const int seg_ns = w.ns;
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -331,14 +345,9 @@ void gemm_phase_kernel(GemmKArgs p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align: both groups run the epilogue together
     __builtin_amdgcn_sched_barrier(0);
     stamp_tile(it, 1);
-    Seg w;
     int lane_e = lane;
-    {
-      int it2 = it;
-      asm volatile("" : "+s"(it2));               // (keeps the compiler from carrying the first evaluation across the loop;
-      asm volatile("" : "+v"(lane_e));            //  likewise the per-lane epilogue addresses it would hoist out of the
-      (void)seg_of(it2, w);                       //  segment loop and spill: they are re-derived per tile from lane_e)
-    }
+    asm volatile("" : "+v"(lane_e));              // (the per-lane epilogue addresses the compiler would hoist out of the segment
+                                                  //  loop and spill are re-derived per tile from lane_e)
     if (DBG & 16) {        // no epilogue at all (keep the accumulators alive)
 #pragma unroll
       for (int i = 0; i < 2; ++i)

@@ -222,9 +222,11 @@ class GemmTuner:
 
 def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=False, dact_aux=None, dact=0,
          dropout_p=0.0, seed=(0, 0), residual=None, res_rows=0, out_dtype=BF16, out=None, accumulate=False, split_k=1,
-         variant=None):
+         variant=None, ksum=None):
     """C[M,N] = epilogue(A . B^T); see include/dvla.h.  `variant` forces a kernel configuration (tests / sweeps)
     instead of asking the tuner.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
+    ksum = ("a" | "b", out): also out[i] = sum over k of that operand's row i (the bias gradient of a weight-gradient GEMM,
+    summed from the fragments the kernel multiplies anyway); out: 1-D, M (a) or N (b) long, bf16 or fp32.
     Returns C (and the pre-activation tensor if want_preact)."""
     lib = _lib.load()
     _req(a, "gemm.a"); _req(b, "gemm.b")
@@ -275,6 +277,12 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
         p.residual, p.ld_res, p.res_rows = residual.data_ptr(), residual.stride(0), int(res_rows)
     p.accumulate = int(accumulate)
     p.split_k = max(1, int(split_k))
+    ksum_ws = None
+    if ksum is not None:
+        which, kout = ksum
+        klen = M if which == "a" else N
+        if which not in ("a", "b") or kout.shape != (klen,) or not kout.is_contiguous() or kout.device != a.device:
+            raise ValueError("gemm: bad `ksum`")
     prof = GemmProfiler.active
     # "plain": nothing but (optionally) the bias vector rides on the GEMM (reported per shape by the profiler)
     plain = (act == 0 and not want_preact and dact_aux is None and residual is None and dropout_p == 0.0
@@ -285,8 +293,16 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     if GemmTuner.enabled and not forced:
         key = (M, N, K, int(a_trans), int(b_trans), int(p.split_k), int(act), int(dact),
                bias is not None, want_preact, dact_aux is not None, residual is not None,
-               dropout_p > 0.0, out.dtype == torch.float32, bool(accumulate))
+               dropout_p > 0.0, out.dtype == torch.float32, bool(accumulate), 0 if ksum is None else (1 if ksum[0] == "a" else 2))
         variant, trial = GemmTuner.pick(key)
+    # k-sums: carried by the ring kernels (variants 4 / 6 / 7; 0 = the library's choice, which falls back by itself); under a
+    # configuration without the summing code the column-sum kernel runs here, AFTER the profiler's end event (it is not GEMM
+    # time) but inside the tuner's trial window (a configuration's cost includes what it leaves to other kernels)
+    ksum_here = ksum is not None and variant not in (0, 4, 6, 7)
+    if ksum is not None and not ksum_here:
+        p.ksum, p.ksum_dtype, p.ksum_operand = kout.data_ptr(), _dt(kout), 1 if which == "a" else 2
+        ksum_ws = torch.empty(lib.dvla_gemm_ksum_partial_rows(p.split_k) * klen, dtype=torch.float32, device=a.device)
+        p.ksum_workspace = ksum_ws.data_ptr()
     if prof is not None or trial is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -303,8 +319,17 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
             lib.dvla_set_gemm_variant(0)
     if prof is not None or trial is not None:
         e1.record()
+    e2 = e1 if (prof is not None or trial is not None) else None
+    if ksum_here:
+        src = a if which == "a" else b
+        if not (a_trans if which == "a" else b_trans):
+            raise _lib.DvlaError("gemm: k-sums under this configuration need the operand stored k-major (a_trans / b_trans)")
+        colsum(src, kout.dtype, out=kout)
+        if trial is not None:
+            e2 = torch.cuda.Event(enable_timing=True)
+            e2.record()
     if trial is not None:
-        trial["pending"].append((variant, e0, e1))
+        trial["pending"].append((variant, e0, e2))
     if prof is not None:
         prof.records.append((e0, e1, 2.0 * M * N * K))
         prof.shapes.append((M, N, K, int(a_trans), int(b_trans), int(p.split_k), "hip",
@@ -749,6 +774,17 @@ def _grad_dest(param, dtype=None):
     return view.view_as(view)
 
 
+# DVLA_KSUM=0: bias gradients by the separate column-sum kernel instead of riding on the weight-gradient GEMM (same-box A/B
+# measurements of the fusion; not a product knob)
+_KSUM_FUSED = os.environ.get("DVLA_KSUM", "1") != "0"
+
+
+def _bias_grad_out(b, dtype, n, device):
+    """where a bias gradient is written: the reducer's bucket slot when there is one (see _grad_dest), else a fresh vector"""
+    dst = _grad_dest(b, dtype)
+    return dst if dst is not None else torch.empty(n, dtype=dtype, device=device)
+
+
 class _Linear(torch.autograd.Function):
     """y = residual + dropout(act(x . W^T + b)).  conv1d=True: W is HF Conv1D (in, out) (models/gpt2.py:53)."""
 
@@ -791,13 +827,18 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dx[m,k] = sum_n dz[m,n] W(n,k)
             dx = gemm(dz, w, b_trans=not conv1d).view(ctx.x_shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dst = _grad_dest(w, BF16)      # the reducer's bucket slot, written in place (None: a fresh tensor)
+            ks = None
+            if want_db and _KSUM_FUSED:    # db = sum_m dz[m, :] rides on the dW GEMM, which streams dz anyway
+                db = _bias_grad_out(b, ctx.bias_dtype, N, dz.device)
+                ks = ("b" if conv1d else "a", db)
             if conv1d:   # dW[k,n] = sum_m x[m,k] dz[m,n]
-                dw = gemm(x2, dz, a_trans=True, b_trans=True, split_k=auto_split_k(K, N, M), out=dst)
+                dw = gemm(x2, dz, a_trans=True, b_trans=True, split_k=auto_split_k(K, N, M), out=dst, ksum=ks)
             else:        # dW[n,k] = sum_m dz[m,n] x[m,k]
-                dw = gemm(dz, x2, a_trans=True, b_trans=True, split_k=auto_split_k(N, K, M), out=dst)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                dw = gemm(dz, x2, a_trans=True, b_trans=True, split_k=auto_split_k(N, K, M), out=dst, ksum=ks)
+        if want_db and db is None:
             db = colsum(dz, ctx.bias_dtype, out=_grad_dest(b, ctx.bias_dtype))
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
@@ -851,19 +892,29 @@ class _Mlp(torch.autograd.Function):
         # du = (dz . W2) * act'(u)
         du = gemm(dz, w2, b_trans=not conv1d, dact_aux=u, dact=ctx.act)
         dx = dw1 = db1 = dw2 = db2 = dres = None
+        want_db2 = ctx.has_b2 and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3]:
             dst = _grad_dest(w2, BF16)
-            dw2 = (gemm(h, dz, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, N, M), out=dst) if conv1d else
-                   gemm(dz, h, a_trans=True, b_trans=True, split_k=auto_split_k(N, Hd, M), out=dst))
-        if ctx.has_b2 and ctx.needs_input_grad[4]:
+            ks = None
+            if want_db2 and _KSUM_FUSED:
+                db2 = _bias_grad_out(b2, ctx.b2_dtype, N, dz.device)
+                ks = ("b" if conv1d else "a", db2)
+            dw2 = (gemm(h, dz, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, N, M), out=dst, ksum=ks) if conv1d else
+                   gemm(dz, h, a_trans=True, b_trans=True, split_k=auto_split_k(N, Hd, M), out=dst, ksum=ks))
+        if want_db2 and db2 is None:
             db2 = colsum(dz, ctx.b2_dtype, out=_grad_dest(b2, ctx.b2_dtype))
         if ctx.needs_input_grad[0]:
             dx = gemm(du, w1, b_trans=not conv1d).view(ctx.x_shape)
+        want_db1 = ctx.has_b1 and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dst = _grad_dest(w1, BF16)
-            dw1 = (gemm(x2, du, a_trans=True, b_trans=True, split_k=auto_split_k(K, Hd, M), out=dst) if conv1d else
-                   gemm(du, x2, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, K, M), out=dst))
-        if ctx.has_b1 and ctx.needs_input_grad[2]:
+            ks = None
+            if want_db1 and _KSUM_FUSED:
+                db1 = _bias_grad_out(b1, ctx.b1_dtype, Hd, du.device)
+                ks = ("b" if conv1d else "a", db1)
+            dw1 = (gemm(x2, du, a_trans=True, b_trans=True, split_k=auto_split_k(K, Hd, M), out=dst, ksum=ks) if conv1d else
+                   gemm(du, x2, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, K, M), out=dst, ksum=ks))
+        if want_db1 and db1 is None:
             db1 = colsum(du, ctx.b1_dtype, out=_grad_dest(b1, ctx.b1_dtype))
         if ctx.has_res and ctx.needs_input_grad[5]:
             dres = dy

@@ -37,7 +37,7 @@ extern "C" {
 
 /* ABI revision of this header; dreamvla_amd/_lib.py refuses a library that reports another one (a stale prebuilt .so then fails
  * with a clear message instead of a missing-symbol error).  3 = round 3 (dvla_last_gemm_variant, variant 10, ...). */
-#define DVLA_ABI_VERSION 3
+#define DVLA_ABI_VERSION 4
 int dvla_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -67,7 +67,17 @@ typedef struct dvla_gemm_params {
   const void* residual; int64_t ld_res; int64_t res_rows; /* >0: residual row = m % res_rows (broadcast tables) */
   int32_t accumulate;
   int32_t split_k; void* workspace;
+  /* (ABI 4) k-sums of one operand, computed by the GEMM that streams it anyway -- the bias gradient db = sum_m dz[m, :] of a
+   * weight-gradient GEMM dW = dz^T x (utils/train_utils.py:599-608 leaves it to autograd's sum kernel):
+   *   ksum_operand 0: none; 1: ksum[i] = sum_k A(i, k), i < M; 2: ksum[j] = sum_k B(j, k), j < N   (fp32 accumulation of the
+   *   bf16 operand values, result in ksum_dtype = DVLA_DT_F32 / DVLA_DT_BF16).
+   *   ksum_workspace: dvla_gemm_ksum_partial_rows(split_k) x (M or N) floats.
+   * The ring / phase kernels sum the fragments they feed to the matrix pipe (one v_dot2c_f32_bf16 per dword, in the MFMA
+   * shadow); a configuration without that code runs the column-sum kernel on the operand instead, which needs the operand
+   * stored k-major (a_trans / b_trans = 1: the weight-gradient layout); otherwise DVLA_ERR_UNSUPPORTED. */
+  void* ksum; int32_t ksum_dtype; int32_t ksum_operand; float* ksum_workspace;
 } dvla_gemm_params;
+int64_t dvla_gemm_ksum_partial_rows(int32_t split_k);
 int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
 /* tuning hook: 0 = automatic kernel choice by the built-in cost model (default; env DVLA_GEMM_VARIANT overrides at load);
  * 2 = register-staged 128x128 kernel; 4 / 6 / 7 = LDS-DMA ring kernels 256x256 / 128x128 / 256x128 (K-tile 64); 8 = phase

@@ -122,6 +122,27 @@ def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", re
     return out
 
 
+def check_gemm_ksum(M, N, K, which, split_k=1, variant=None, a_trans=True, b_trans=True, out_f32=False, ksum_f32=False, seed=0):
+    """dvla_gemm_bf16 with ksum_operand: the k-sums of operand `which` ("a": sum_k A(i, k), "b": sum_k B(j, k)) next to the
+    product -- the bias gradient of a weight-gradient GEMM (utils/train_utils.py:599-608: autograd's dz.sum(0)).  Oracle: fp32
+    sums of the bf16 operand values; tolerance: the bf16 rounding of the result (or 1e-5 for fp32 output)."""
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(555 + seed)
+    A = R.bf16_round(rnd((M, K), g))
+    B = R.bf16_round(rnd((N, K), g, 1.0 / math.sqrt(max(K, 1))) + 0.01)      # a non-zero mean: the sums are not noise
+    a_dev = (A.t().contiguous() if a_trans else A).to(DEV, BF)
+    b_dev = (B.t().contiguous() if b_trans else B).to(DEV, BF)
+    klen = M if which == "a" else N
+    kout = torch.full((klen,), float("nan"), dtype=torch.float32 if ksum_f32 else BF, device=DEV)
+    got = ops.gemm(a_dev, b_dev, a_trans=a_trans, b_trans=b_trans, out_dtype=torch.float32 if out_f32 else BF, split_k=split_k,
+                   variant=variant, ksum=(which, kout))
+    ref = A @ B.t()
+    kref = (A if which == "a" else B).sum(1)
+    tag = f"gemm+ksum({which}){'' if variant is None else ' v%d' % variant} M{M} N{N} K{K} at{int(a_trans)} bt{int(b_trans)} sk{split_k} f32{int(out_f32)}"
+    return [metrics(tag, got, ref, TOL_F32 if out_f32 else TOL_FWD, round_ref=not out_f32),
+            metrics(tag + " k-sums", kout, kref, 1e-5 if ksum_f32 else TOL_FWD, round_ref=not ksum_f32)]
+
+
 # the GEMM problems of the benchmarked training step (BASELINE configs[1]: B = 32, S = 7, head set C; profiles/r02_gemm_breakdown.json)
 # at FULL size, with their real K and epilogue, under every kernel configuration the tuner locks for them (bench.py's
 # tuner_wins_by_problem_key) -- round-2 VERDICT: the forced-variant tests stopped at K <= 448 / M <= 4300, where the stream-K
@@ -564,6 +585,21 @@ def all_checks(quick=False):
             (check_gemm, dict(M=1300, N=832, K=128, bias=True, out_f32=True, residual=True, variant=v)),
             (check_gemm, dict(M=1024, N=512, K=1024, a_trans=True, variant=v)),
         ]
+    # k-sums next to the product (the bias gradient rides on the weight-gradient GEMM): both operands, every configuration
+    # (2 has no summing code: the library runs its column-sum kernel on the operand), ragged M / N, split-K and not, bf16 / fp32
+    for v in (None, 2, 4, 6, 7, 8, 9):
+        L += [
+            (check_gemm_ksum, dict(M=1024, N=768, K=4224, which="a", split_k=3, variant=v)),
+            (check_gemm_ksum, dict(M=1024, N=768, K=4224, which="b", split_k=3, variant=v)),
+            (check_gemm_ksum, dict(M=1100, N=832, K=2048, which="a", split_k=4, variant=v, ksum_f32=True)),
+            (check_gemm_ksum, dict(M=1100, N=832, K=2048, which="b", split_k=1, out_f32=True, variant=v, ksum_f32=True)),
+            (check_gemm_ksum, dict(M=300, N=4096, K=20832, which="b", split_k=4, variant=v)),
+        ]
+    L += [(check_gemm_ksum, dict(M=4096, N=1024, K=20832, which="b", split_k=4)),          # trunk fc2 dW + db (Conv1D layout)
+          (check_gemm_ksum, dict(M=1024, N=4096, K=20832, which="b", split_k=4, variant=4)),
+          (check_gemm_ksum, dict(M=4096, N=1024, K=91840, which="a", split_k=4, variant=8)),  # decoder fc1 dW + db (nn.Linear layout)
+          (check_gemm_ksum, dict(M=512, N=512, K=1024, which="a", split_k=1)),             # bf16 C, no split: not the fp32 class -> column-sum kernel
+          (check_gemm_ksum, dict(M=640, N=512, K=1024, which="a", split_k=2, a_trans=False, b_trans=False, variant=4))]   # any layout when fused (ring kernels)
     # 9 = the phase kernel's stream-K hybrid schedule: it only engages from one tile per CU upwards (328 tiles here: 20.5
     # super-tiles of 16, i.e. ragged), with tiles shared by two workgroups -- every epilogue class, both slab paths, twice in a
     # row on the same scratch (the flags must come back down)

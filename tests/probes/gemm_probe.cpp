@@ -103,8 +103,8 @@ static void fill(Buf& b, uint32_t seed, float scale) {
 }
 
 struct Problem {
-  dvla_gemm_params p; Buf A, B, C, bias, preact, dact, res, ws;
-  void release() { for (Buf* b : {&A, &B, &C, &bias, &preact, &dact, &res, &ws}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } }
+  dvla_gemm_params p; Buf A, B, C, bias, preact, dact, res, ws, ksum, ksum_ws;
+  void release() { for (Buf* b : {&A, &B, &C, &bias, &preact, &dact, &res, &ws, &ksum, &ksum_ws}) if (b->p) { (void)hipFree(b->p); b->p = nullptr; } }
 };
 
 // DVLA_PROBE_PAD_C / DVLA_PROBE_PAD_AB (elements): leading dimensions of C (and the epilogue operands) / of A and B are padded
@@ -142,6 +142,14 @@ static Problem make_problem(const Case& c, int64_t M) {
     q.dact = dalloc((size_t)M * N * 2); fill(q.dact, 5u, 2.0f); p.dact_aux = q.dact.p; p.ld_dact = N; p.dact = c.epi == "dact_tanh" ? 2 : 1;
   }
   if (c.split_k > 1) { q.ws = dalloc((size_t)c.split_k * M * N * 4); p.workspace = q.ws.p; }
+  // DVLA_PROBE_KSUM=a|b: the launch also produces the k-sums of that operand (timing of the fused bias gradient; fp32 class only)
+  if (const char* ks = getenv("DVLA_PROBE_KSUM")) {
+    if (f32 && (ks[0] == 'a' || ks[0] == 'b')) {
+      const int64_t len = ks[0] == 'a' ? M : c.N;
+      q.ksum = dalloc((size_t)len * 4); q.ksum_ws = dalloc((size_t)dvla_gemm_ksum_partial_rows(c.split_k) * len * 4);
+      p.ksum = q.ksum.p; p.ksum_dtype = DVLA_DT_F32; p.ksum_operand = ks[0] == 'a' ? 1 : 2; p.ksum_workspace = (float*)q.ksum_ws.p;
+    }
+  }
   return q;
 }
 
@@ -304,6 +312,15 @@ int main(int argc, char** argv) {
       {"square", 8192, 8192, 8192, 0, 0, "plain", 1},
       {"generic relu", 20832, 1024, 1024, 0, 0, "relu", 1},
       {"generic silu+res", 20832, 1024, 1024, 0, 1, "silu_res", 1},
+    };
+  } else if (which == "dw") {   // the weight-gradient problems (fp32 class, split-K): DVLA_PROBE_KSUM adds the bias gradient
+    cases = {
+      {"dW fc1", 1024, 4096, 20832, 1, 1, "f32", 4},
+      {"dW fc2", 4096, 1024, 20832, 1, 1, "f32", 4},
+      {"dW c_attn", 1024, 3072, 20832, 1, 1, "f32", 5},
+      {"dW c_proj", 1024, 1024, 20832, 1, 1, "f32", 16},
+      {"dW dec fc1", 4096, 1024, 91840, 1, 1, "f32", 4},
+      {"dW dec fc2", 1024, 4096, 91840, 1, 1, "f32", 4},
     };
   } else if (which == "plain") {
     cases = {
