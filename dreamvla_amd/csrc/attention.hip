@@ -1198,8 +1198,12 @@ static bool attn_force_staged() {
   return v == 1;
 }
 
-// DVLA_ATTN_DBG=<bits>: ablation builds of the forward ring kernel (timing only); re-read at every launch
-static int attn_dbg() { const char* e = getenv("DVLA_ATTN_DBG"); return e ? atoi(e) : 0; }
+// DVLA_ATTN_DBG=<bits>: ablation builds of the forward ring kernel (timing only, results garbage by design) -- compiled only
+// with -DDVLA_ATTN_ABLATION (DVLA_ABLATIONS=1 python -c 'import __graft_entry__ as g; g.build(force=True)'); the product library
+// holds the real kernel alone and never looks at the variable.
+#ifdef DVLA_ATTN_ABLATION
+static int attn_dbg() { const char* e = getenv("DVLA_ATTN_DBG"); return e ? atoi(e) : 0; }   // (re-read per launch: the sweep changes it)
+#endif
 
 extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -1210,6 +1214,9 @@ extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
   const size_t smem = fa_smem_bytes(a.nkt, a.Lk, a.key_index != nullptr, a.tile_map != nullptr && a.bits_q != nullptr);
   const bool span_kv = attn_span32(a.Lk, a.kst, a.key_index != nullptr) && attn_span32(a.Lk, a.vst, a.key_index != nullptr);
   if (smem <= 64 * 1024 && span_kv && !attn_force_staged())
+#ifndef DVLA_ATTN_ABLATION
+    hipLaunchKernelGGL(attn_fwd_ring_kernel<0>, grid, block, smem, stream, a);
+#else
     switch (attn_dbg()) {
       case 1: hipLaunchKernelGGL(attn_fwd_ring_kernel<1>, grid, block, smem, stream, a); break;
       case 2: hipLaunchKernelGGL(attn_fwd_ring_kernel<2>, grid, block, smem, stream, a); break;
@@ -1223,6 +1230,7 @@ extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
       case 64: hipLaunchKernelGGL(attn_fwd_ring_kernel<64>, grid, block, smem, stream, a); break;
       default: hipLaunchKernelGGL(attn_fwd_ring_kernel<0>, grid, block, smem, stream, a); break;
     }
+#endif
   else   // mask tables / key list too large for LDS
     hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, a);
   return dvla_check_launch();

@@ -1,4 +1,6 @@
-"""Forward attention ring kernel under its ablation builds (env DVLA_ATTN_DBG, read per launch; results garbage by design):
+"""Forward attention ring kernel under its ablation builds (env DVLA_ATTN_DBG, read per launch; results garbage by design).
+Needs a MEASUREMENT build of the library: DVLA_ABLATIONS=1 python -c 'import __graft_entry__ as g; g.build(force=True)' (the product
+library does not contain the ablation kernels):
 which part of the tile loop paces it?  GPU box only, not a test.  Prints one line per shape."""
 import os
 import sys
