@@ -881,6 +881,36 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
   const bool has_bias = !split_out && p.bias != nullptr;
   const bool two_aux = has_dact && has_res;   // none of the model's GEMMs has both: the act' operand is then read late
 
+  // ================= split-K partial sums (the weight gradients): whole 128-byte lines of fp32 =================
+  // A lane's accumulator quads (i, rq) are the 16-byte pieces 2 rq + g of its row's 32-float line of column group i: the same
+  // 4 x 4 exchange as below makes every store instruction write 8 whole lines instead of 32 rows x 32 B (the partial-line pattern
+  // sustains 17.7 B/clk per CU: 256 KiB of partials per tile = ~15 k cycles of store issue, ~5 k with whole lines).
+  if constexpr (EPI == EPI_F32) {
+    if (split_out && (p.N & 31) == 0 && (reinterpret_cast<uintptr_t>(p.workspace) & 127) == 0) {
+      const int qb = lane & 3, qa = l31 >> 2;
+      float* ws = p.workspace + (int64_t)split * p.M * p.N + n_base + 4 * (2 * qb + g);
+      static_for<TM>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        static_for<2>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          u32x4 P[4];
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+            P[rq] = u32x4{__float_as_uint(acc[i][j][4 * rq]), __float_as_uint(acc[i][j][4 * rq + 1]),
+                          __float_as_uint(acc[i][j][4 * rq + 2]), __float_as_uint(acc[i][j][4 * rq + 3])};
+          quad_transpose(P, lane);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int64_t mr = m_base + j * 32 + 4 * qa + c;
+            if (mr < p.M) *reinterpret_cast<u32x4*>(ws + mr * p.N + 32 * i) = P[c];
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      return;
+    }
+  }
+
   // ================= whole-line path: every bf16 class except EPI_GEN (see quad_transpose above) =================
   if constexpr (EPI != EPI_F32 && EPI != EPI_GEN) {
     const int qb = lane & 3, qa = l31 >> 2;

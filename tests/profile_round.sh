@@ -5,6 +5,7 @@
 # FETCH / WRITE on a working set larger than the Infinity Cache.  Copy what is to be judged into profiles/.
 set -u
 TAG=${1:-r02}
+WHAT=${2:-all}      # "gemm": only the step trace and the GEMM passes (1, 2, 2b); "all": plus attention and LayerNorm
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -25,6 +26,7 @@ done
 # 2b. GEMM matrix-pipe busy over the tuned step
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_gemm_mfma -f csv -- $BENCH --steps 2 --warmup 0 --plan $OUT/${TAG}_gemm_plan.json --no-roofline --no-fwd --no-rollout > $OUT/${TAG}_pmc_gemm_mfma.log 2>&1
 python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_gemm_mfma $OUT/${TAG}_pmc_gemm_mfma.json > $OUT/${TAG}_pmc_gemm_mfma.txt 2>&1
+if [ "$WHAT" = "all" ]; then
 # 3. attention: matrix-pipe busy per kernel
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_attn -f csv -- python $REPO/tests/gpu_pmc_attn.py > $OUT/${TAG}_pmc_attn.log 2>&1
 python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_attn $OUT/${TAG}_pmc_attn.json > $OUT/${TAG}_pmc_attn.txt 2>&1
@@ -36,6 +38,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/${TAG}_pmc_ln${SH}_$C
 done
 done
+fi
 # keep the merge small: drop the raw traces
 rm -rf $OUT/${TAG}_pmc_gemm_mfma $OUT/${TAG}_prof_step $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_attn
 ls -la $OUT | head -40
