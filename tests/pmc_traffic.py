@@ -30,9 +30,9 @@ def main():
            "launches_in_pass": launches, "algorithmic_bytes_per_launch": alg, "commit": commit,
            "per_kernel": {k: {"launches": v["launches"], "fetch_bytes_per_launch": v["fetch_bytes_per_launch"],
                               "write_bytes_per_launch": W.get(k, {}).get("write_bytes_per_launch")} for k, v in F.items()},
-           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 0 "
-                     "--tune-steps 0` with DVLA_GEMM_AUTOTUNE=0 (the cost model's configurations: no tuner trials inside the measured "
-                     "step), all hand-written GEMM dispatches of the run (tests/profile_round.sh); FETCH_SIZE (KiB) doubled as "
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 0 "
+                     "--plan <the tuner's locked choices, saved by an ordinary run of the same tree> --no-roofline --no-fwd`: two TUNED "
+                     "training steps, no tuner trials, all hand-written GEMM dispatches (tests/profile_round.sh); FETCH_SIZE (KiB) doubled as "
                      "MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950, WRITE_SIZE uncalibrated; the counters sit on the L2's "
                      "fabric side and include Infinity-Cache hits"}
     with open(out, "w") as f:
