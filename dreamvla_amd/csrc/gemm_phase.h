@@ -213,10 +213,12 @@ void gemm_phase_kernel(GemmKArgs p) {
         (reinterpret_cast<uint64_t*>(p.workspace) + 512 + (wave >> 2) * 64)[tile * 4 + e] = __builtin_amdgcn_s_memtime();
     }
   };
-  // (k-sums, dvla.h ksum_*: not in this kernel.  Tried three ways in round 3 -- dots after every k16-step in every wave, one block
+  // (k-sums, dvla.h ksum_*: not in this kernel.  Tried four ways in round 3 -- dots after every k16-step in every wave, one block
   // of dots at the end of a multiply segment in the wave whose k16-step it is, two dots behind every MFMA in per-operand copies of
-  // the segments: +5 ... +18 % per launch, or spills; tests/probes/ksum_probe.sh.  The ring kernels carry them for +2 %; asked for
-  // k-sums this kernel's launches get the column-sum kernel over the operand from dvla_gemm_bf16.)
+  // the segments, two selects + two dots behind every MFMA in one code path: +5 ... +26 % per launch, or spills.  The last one is
+  // the telling one (profiles/r03_gemm_ksum_probe_phase_dots.txt): 640 -> 807 us with a ZERO selector, i.e. v_dot2c_f32_bf16
+  // interleaved with MFMAs is not hidden by the matrix pipe at all in this loop -- the dot instructions compete with it.  The
+  // ring kernels carry the sums for 0-2 %; asked for k-sums this kernel's launches get the column-sum kernel over the operand.)
   int u = 0, ua = 0;   // global K-tile counter of the multiply, and u % 3
   for (int it = 0;; ++it) {
     // The segment's tile origin / split / kind stay live across the K loop as SCALARS (6 SGPRs, spilled to VGPR lanes when
