@@ -72,7 +72,7 @@ typedef struct dvla_gemm_params {
    *   ksum_operand 0: none; 1: ksum[i] = sum_k A(i, k), i < M; 2: ksum[j] = sum_k B(j, k), j < N   (fp32 accumulation of the
    *   bf16 operand values, result in ksum_dtype = DVLA_DT_F32 / DVLA_DT_BF16).
    *   ksum_workspace: dvla_gemm_ksum_partial_rows(split_k) x (M or N) floats.
-   * The ring / phase kernels sum the fragments they feed to the matrix pipe (one v_dot2c_f32_bf16 per dword, in the MFMA
+   * The ring kernels sum the fragments they feed to the matrix pipe (one v_dot2c_f32_bf16 per dword, in the MFMA
    * shadow); a configuration without that code runs the column-sum kernel on the operand instead, which needs the operand
    * stored k-major (a_trans / b_trans = 1: the weight-gradient layout); otherwise DVLA_ERR_UNSUPPORTED. */
   void* ksum; int32_t ksum_dtype; int32_t ksum_operand; float* ksum_workspace;
