@@ -290,6 +290,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   std::vector<Case> cases;
+  const int sk_override = getenv("DVLA_PROBE_SK") ? atoi(getenv("DVLA_PROBE_SK")) : 0;   // split-K cases: another slice count
   if (which == "model" || which == "all") {
     cases = {
       {"trunk fc1 fwd", 20832, 4096, 1024, 0, 1, "gelu_tanh_preact", 1},
@@ -357,6 +358,7 @@ int main(int argc, char** argv) {
       {"square", 8192, 8192, 8192, 0, 0, "plain", 1},
     };
   }
+  if (sk_override > 0) for (auto& c : cases) if (c.split_k > 1) c.split_k = sk_override;
   // ---- correctness: every (case layout / epilogue, variant) at a reduced M (ragged: not a tile multiple) ----
   if (!no_check) {
     for (const Case& c : cases) {
