@@ -347,7 +347,6 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   if (DBG & 64) return;                       // launch + workgroup dispatch only
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int b = blockIdx.z, h = blockIdx.y;
   const int qt0 = blockIdx.x * 4;
   const int qt = qt0 + wave;
   const int q = qt * 32 + l31;
@@ -359,19 +358,10 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   int32_t* kidx = reinterpret_cast<int32_t*>(smem + FA_RING + fa_pad16(p.nkt));
   uint32_t* bits = reinterpret_cast<uint32_t*>(smem + FA_RING + fa_pad16(p.nkt) + (p.key_index ? fa_pad16(p.Lk * 4) : 0));
 
-  const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
-  const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
-  const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
-
-  // the Q fragments are requested FIRST and waited for LAST (after the first K / V tiles are on their way): the workgroup's
-  // memory round trips -- tables, Q, first tiles -- overlap instead of queueing (short sequences are latency-bound per
-  // workgroup: the loop of L = 205 has 7 tiles)
-  bf16x8 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const uint4 u = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
-    qf[s] = *reinterpret_cast<const bf16x8*>(&u);
-  }
+  // The tables depend on the query block only: a workgroup loads them ONCE and then walks (batch, head) items blockIdx.y,
+  // blockIdx.y + gridDim.y, ... (round 2's ablation: the skeleton of this kernel -- tables, flag scan, no DMA, no arithmetic --
+  // was 44 of the trunk's 89 us with one item per workgroup; the host sizes gridDim.y for a few items per workgroup when there
+  // are tables and one item otherwise).
   for (int kt = t; kt < p.nkt; kt += AT_THREADS) {
     int f = 0;
 #pragma unroll
@@ -387,6 +377,22 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       bits[i] = qq < p.Lq ? p.bits_q[(int64_t)qq * p.nkt + kt] : 0u;
     }
   __syncthreads();
+
+  const int n_items = p.B * p.H;
+  for (int bh = blockIdx.y; bh < n_items; bh += gridDim.y) {
+  const int b = bh / p.H, h = bh - b * p.H;
+  const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
+  const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
+  const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
+
+  // the Q fragments are requested FIRST and waited for LAST (after the first K / V tiles are on their way): the item's memory
+  // round trips -- Q, first tiles -- overlap instead of queueing (short sequences are latency-bound: L = 205 has 7 tiles)
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 u = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
+    qf[s] = *reinterpret_cast<const bf16x8*>(&u);
+  }
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 oacc[2] = {zero16(), zero16()};
@@ -504,6 +510,8 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
     store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g, (p.st16 & 1) != 0);
     if (p.lse && g == 0) p.lse[rowid] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
+  }
+  __syncthreads();   // every wave is done with the ring before the next item's first DMA lands in it
   }
 }
 
@@ -1205,30 +1213,56 @@ static bool attn_force_staged() {
 static int attn_dbg() { const char* e = getenv("DVLA_ATTN_DBG"); return e ? atoi(e) : 0; }   // (re-read per launch: the sweep changes it)
 #endif
 
+// grid of the forward ring kernel: x = 128-query blocks, y = workgroups that share the (batch, head) items of a query block.
+// (Forward only: the same loop in the dQ and dK/dV ring kernels made them 40-55 % SLOWER -- 16 bytes of scratch in dQ at 128 VGPRs,
+// 186 -> 196 VGPRs in dK/dV, even at one item per workgroup -- and was taken out again; tests/gpu_attn_perf.py.)
+// With mask tables (loaded once per workgroup) a workgroup takes up to four items as long as at least three workgroups per CU (the
+// resident count) remain; without tables one item per workgroup as before.  Measured at the trunk's shape (B 32, H 16, L 651,
+// tests/gpu_attn_items.py): 1 item 91.3 us, 2 items 84.7, 4 items 80.4, 8 items (384 workgroups: the chip half empty) 129.
+// DVLA_ATTN_ITEMS=<n> forces n items per workgroup (measurement).
+static dim3 ring_items_grid(int nblk, const AttnKArgs& a) {
+  static int forced = -1, cus = 0;
+  if (forced < 0) {
+    const char* e = getenv("DVLA_ATTN_ITEMS"); forced = e ? atoi(e) : 0;
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const int nqb = nblk, items = a.B * a.H;
+  int y = items;
+  const bool tables = a.tile_map != nullptr || a.key_index != nullptr;
+  if (forced > 0) y = (items + forced - 1) / forced;
+  else if (tables) { const int by4 = (items + 3) / 4, fill = (3 * cus + nqb - 1) / nqb; y = by4 > fill ? by4 : fill; if (y > items) y = items; }
+  if (y < 1) y = 1;
+  if (y > 65535) y = 65535;
+  return dim3((unsigned)nqb, (unsigned)y, 1u);
+}
+static dim3 fwd_ring_grid(const AttnKArgs& a) { return ring_items_grid((a.nqt + 3) / 4, a); }
+
 extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   AttnKArgs a;
   int rc = fill_args(q, a);
   if (rc != DVLA_OK) return rc;
   dim3 grid((unsigned)((a.nqt + 3) / 4), (unsigned)a.H, (unsigned)a.B), block(AT_THREADS);
+  const dim3 ring_grid = fwd_ring_grid(a);
   const size_t smem = fa_smem_bytes(a.nkt, a.Lk, a.key_index != nullptr, a.tile_map != nullptr && a.bits_q != nullptr);
   const bool span_kv = attn_span32(a.Lk, a.kst, a.key_index != nullptr) && attn_span32(a.Lk, a.vst, a.key_index != nullptr);
   if (smem <= 64 * 1024 && span_kv && !attn_force_staged())
 #ifndef DVLA_ATTN_ABLATION
-    hipLaunchKernelGGL(attn_fwd_ring_kernel<0>, grid, block, smem, stream, a);
+    hipLaunchKernelGGL(attn_fwd_ring_kernel<0>, ring_grid, block, smem, stream, a);
 #else
     switch (attn_dbg()) {
-      case 1: hipLaunchKernelGGL(attn_fwd_ring_kernel<1>, grid, block, smem, stream, a); break;
-      case 2: hipLaunchKernelGGL(attn_fwd_ring_kernel<2>, grid, block, smem, stream, a); break;
-      case 4: hipLaunchKernelGGL(attn_fwd_ring_kernel<4>, grid, block, smem, stream, a); break;
-      case 8: hipLaunchKernelGGL(attn_fwd_ring_kernel<8>, grid, block, smem, stream, a); break;
-      case 16: hipLaunchKernelGGL(attn_fwd_ring_kernel<16>, grid, block, smem, stream, a); break;
-      case 14: hipLaunchKernelGGL(attn_fwd_ring_kernel<14>, grid, block, smem, stream, a); break;
-      case 15: hipLaunchKernelGGL(attn_fwd_ring_kernel<15>, grid, block, smem, stream, a); break;
-      case 31: hipLaunchKernelGGL(attn_fwd_ring_kernel<31>, grid, block, smem, stream, a); break;
-      case 63: hipLaunchKernelGGL(attn_fwd_ring_kernel<63>, grid, block, smem, stream, a); break;
-      case 64: hipLaunchKernelGGL(attn_fwd_ring_kernel<64>, grid, block, smem, stream, a); break;
-      default: hipLaunchKernelGGL(attn_fwd_ring_kernel<0>, grid, block, smem, stream, a); break;
+      case 1: hipLaunchKernelGGL(attn_fwd_ring_kernel<1>, ring_grid, block, smem, stream, a); break;
+      case 2: hipLaunchKernelGGL(attn_fwd_ring_kernel<2>, ring_grid, block, smem, stream, a); break;
+      case 4: hipLaunchKernelGGL(attn_fwd_ring_kernel<4>, ring_grid, block, smem, stream, a); break;
+      case 8: hipLaunchKernelGGL(attn_fwd_ring_kernel<8>, ring_grid, block, smem, stream, a); break;
+      case 16: hipLaunchKernelGGL(attn_fwd_ring_kernel<16>, ring_grid, block, smem, stream, a); break;
+      case 14: hipLaunchKernelGGL(attn_fwd_ring_kernel<14>, ring_grid, block, smem, stream, a); break;
+      case 15: hipLaunchKernelGGL(attn_fwd_ring_kernel<15>, ring_grid, block, smem, stream, a); break;
+      case 31: hipLaunchKernelGGL(attn_fwd_ring_kernel<31>, ring_grid, block, smem, stream, a); break;
+      case 63: hipLaunchKernelGGL(attn_fwd_ring_kernel<63>, ring_grid, block, smem, stream, a); break;
+      case 64: hipLaunchKernelGGL(attn_fwd_ring_kernel<64>, ring_grid, block, smem, stream, a); break;
+      default: hipLaunchKernelGGL(attn_fwd_ring_kernel<0>, ring_grid, block, smem, stream, a); break;
     }
 #endif
   else   // mask tables / key list too large for LDS
