@@ -46,6 +46,38 @@ def test_structs_match_header_layout():
         assert names == [f[0] for f in pystruct._fields_], cname
 
 
+def test_struct_offsets_match_the_c_compiler(tmp_path):
+    """Every ctypes mirror against the header as gcc lays it out: offsetof() of each field and sizeof() of each struct (a field of
+    the wrong width, or a missing pad, shifts everything behind it -- the name-order test above cannot see that)."""
+    import shutil
+    import subprocess
+    from dreamvla_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    structs = {"dvla_gemm_params": _lib.GemmParams, "dvla_attn_params": _lib.AttnParams, "dvla_mask_rule": _lib.MaskRule,
+               "dvla_token_src": _lib.TokenSrc, "dvla_frame_view": _lib.FrameView}
+    txt = open(os.path.join(ROOT, "include", "dvla.h")).read()
+    structs = {c: p for c, p in structs.items() if re.search(r"\}\s*%s\s*;" % c, txt)}
+    assert "dvla_gemm_params" in structs and "dvla_attn_params" in structs
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dvla.h"', 'int main(void) {']
+    for cname, py in structs.items():
+        lines.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for fname, _ in py._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    for line in out.strip().splitlines():
+        cname, field, val = line.split()
+        py = structs[cname]
+        want = ctypes.sizeof(py) if field == "sizeof" else getattr(py, field).offset
+        assert int(val) == want, f"{cname}.{field}: C {val} vs ctypes {want}"
+
+
 def test_no_cpu_fallback():
     """the product path must fail loudly on CPU tensors (no eager fallback)."""
     import torch
