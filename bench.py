@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- DreamVLA training-step throughput on MI355X (the metric of BASELINE.json).
 
-    python bench.py --gpus 1 --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank / GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU under torch.distributed.run; started
+                                                            without a launcher, the command re-executes itself under it)
 
 One "step" = one full optimizer step of the hot path on one synthetic batch that is already resident in HBM:
 DreamVLA.forward (frozen CLIP text tower + frozen ViT-B/16 on 2 views, resampler, 24-layer trunk with dropout, dream
@@ -109,6 +110,50 @@ def eager_rocm_baseline(heads, S, B, steps=5):
     return gpu_eager_baseline.run(heads, B, steps, S=S)
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_spawn(n):
+    """Re-execute `bench.py <same arguments>` as n ranks of one node (rendezvous on 127.0.0.1: the container host name may not
+    resolve); returns the launcher's exit code.  Rank 0 of the children prints the JSON line on the inherited stdout."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    port = env.get("MASTER_PORT") or str(free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_selftest(rank, world, args):
+    """`--launch-selftest`: everything of the N > 1 launch path that does not need a GPU -- environment of the launcher,
+    rendezvous (gloo), the barrier and the max-over-ranks of the timed region -- ending in the JSON line on rank 0
+    (tests/test_bench_launch.py runs it with --gpus 2 on CPU).  No model, no kernels: `value` is null."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "train samples/sec (CALVIN ABC->D, seq_len=7)", "value": None, "unit": "samples/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "launch_selftest": True,
+                          "max_over_ranks_s": dt, "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +185,8 @@ def main():
     ap.add_argument("--no-rollout", action="store_true",
                     help="skip the closed-loop rollout leg (BASELINE configs[4]: 64 episodes in lock-step through the hipGraph-"
                          "captured engine, S = 10, DDIM-10; rank 0, N = 1 only; ~15 s after the timed region)")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="CPU-only check of the N > 1 launch path (self-spawn, rendezvous, max over ranks, JSON line); no model")
     ap.add_argument("--torch-ddp", action="store_true", help="use torch DDP instead of dreamvla_amd.ddp.GradBucketReducer")
     ap.add_argument("--torch-adamw", action="store_true",
                     help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of dreamvla_amd.optim.FlatAdamW (HIP, flat buffers)")
@@ -149,9 +196,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: re-execute this very command under torch.distributed.run, one rank per
+        # GPU of this node (train.py is started the same way: scripts/CALVIN_ABC_D/DreamVLA/finetune.sh:6-8 use torchrun)
+        raise SystemExit(self_spawn(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launch_selftest:
+        return launch_selftest(rank, world, args)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
