@@ -148,11 +148,13 @@ class FMDiffusion:
         self.num_timesteps = int(num_timesteps)
 
     def ddim_sample_loop(self, model, shape, *args, noise=None, clip_denoised=True, model_kwargs=None, device=None,
-                         progress=False, **kwargs):
+                         progress=False, start_noise=None, **kwargs):
+        """`start_noise` (not upstream): the start noise as an input, for captured graphs and parity tests
+        (DreamVLA.decode_tokens(test_noise=...)); None = drawn here, as upstream."""
         model_kwargs = dict(model_kwargs or {})
         if "cfg_scale" in model_kwargs:
             model_kwargs["cfg_scale"] = 1.0
-        final = th.randn(*shape, device=device)
+        final = th.randn(*shape, device=device) if start_noise is None else start_noise.to(device=device, dtype=th.float32)
         delta = 1.0 / self.num_timesteps
         for i in range(self.num_timesteps):
             t = th.full((shape[0],), float(i) / self.num_timesteps, device=device, dtype=th.float32)

@@ -1,5 +1,5 @@
 """Loader side of the input pipeline: a drop-in for `DiskCalvinDataset.collator`
-(/root/reference/utils/data_utils.py:1308-1397) that keeps the camera frames as uint8 until they are on the device.
+(/root/reference/utils/data_utils.py:1308-1397) and `DiskLiberoDataset.collator` (2719-2798) that keeps the camera frames as uint8 until they are on the device.
 
 The reference collator runs the CLIP image transform on every PIL frame on the host (`self.image_fn` = `preprocess_image`,
 data_utils.py:175-179: Resize / CenterCrop / ToTensor / Normalize -> fp32 (3, 224, 224) = 602 KB per frame), stacks, applies
@@ -28,11 +28,15 @@ class TokenCache:
         self.hits = self.misses = 0
 
     def __call__(self, strings):
-        missing = [s for s in dict.fromkeys(strings) if s not in self.cache]
+        uniq = list(dict.fromkeys(strings))
+        missing = [s for s in uniq if s not in self.cache]
+        if missing and len(self.cache) + len(missing) > self.max_entries:
+            # full: start over WITH this batch -- every string of the batch is tokenised again, so the stack below finds all of
+            # them (round-3 ADVICE: clearing and re-inserting only `missing` lost the batch's previously cached strings)
+            self.cache.clear()
+            missing = uniq
         if missing:
             toks = self.tokenize(missing)
-            if len(self.cache) + len(missing) > self.max_entries:
-                self.cache.clear()
             for s, t in zip(missing, toks):
                 self.cache[s] = t.clone()
         self.misses += len(missing)
@@ -51,8 +55,17 @@ def depth_image_fn(depth_images, size=224):
 
 
 class DeviceCollator:
+    """dataset="calvin": DiskCalvinDataset.collator (data_utils.py:1308-1397).  dataset="libero": DiskLiberoDataset.collator
+    (data_utils.py:2719-2798) -- the same image / text / chunking code (robot_obs chunks at :2765-2772, forward_traj branch
+    at :2747-2760) with three differences: LIBERO has NO depth path (entries 6 and 7 are None whatever the samples carry,
+    :2795-2796), the track dictionary is returned whenever the samples hold `track_label` (:2798; CALVIN: when
+    `load_track_labels`), and every sample must carry an `episode_id` (:2726)."""
+
     def __init__(self, tokenize, window_size, rgb_pad=-1, gripper_pad=-1, traj_cons=False, act_step=1, n_px=224,
-                 device="cuda", load_track_labels=False, generator=None):
+                 device="cuda", load_track_labels=False, generator=None, dataset="calvin"):
+        if dataset not in ("calvin", "libero"):
+            raise ValueError(f"dataset {dataset!r}: 'calvin' or 'libero'")
+        self.dataset = dataset
         self.text_fn = tokenize if isinstance(tokenize, TokenCache) else TokenCache(tokenize)
         self.window_size, self.act_step = window_size, act_step
         self.rgb_pad, self.gripper_pad, self.traj_cons = rgb_pad, gripper_pad, traj_cons
@@ -94,8 +107,12 @@ class DeviceCollator:
         state_tensors = torch.from_numpy(np.array([np.stack(s["robot_obs"]) for s in sample]))
         image_tensors = self._camera(sample, "rgb_static", self.rgb_pad)
         gripper_tensors = self._camera(sample, "rgb_gripper", self.gripper_pad)
-        depth_static = self._depth(sample, "depth_static", self.rgb_pad) if "depth_obs" in sample[0] else None
-        depth_gripper = self._depth(sample, "depth_gripper", self.gripper_pad) if "depth_obs" in sample[0] else None
+        libero = self.dataset == "libero"
+        has_depth = (not libero) and "depth_obs" in sample[0]
+        depth_static = self._depth(sample, "depth_static", self.rgb_pad) if has_depth else None
+        depth_gripper = self._depth(sample, "depth_gripper", self.gripper_pad) if has_depth else None
+        if libero:
+            _ = [s["episode_id"] for s in sample]        # KeyError on a sample without one, like the reference
         text_tensors = self.text_fn([s["lang"] for s in sample])
         tracks = {}
         if "track_label" in sample[0]:
@@ -125,4 +142,12 @@ class DeviceCollator:
             tracks = {k: cut(v) for k, v in tracks.items()}
             dino, dino_g, sam, sam_g = cut(dino), cut(dino_g), cut(sam), cut(sam_g)
         return (image_tensors, text_tensors, action_tensors, gripper_tensors, state_tensors, robot_obs, depth_static, depth_gripper,
-                dino, dino_g, sam, sam_g, tracks if self.load_track_labels else dict())
+                dino, dino_g, sam, sam_g, tracks if (self.load_track_labels or libero) else dict())
+
+
+class LiberoDeviceCollator(DeviceCollator):
+    """drop-in for DiskLiberoDataset.collator (data_utils.py:2719-2798)"""
+
+    def __init__(self, *args, **kwargs):
+        kwargs["dataset"] = "libero"
+        super().__init__(*args, **kwargs)

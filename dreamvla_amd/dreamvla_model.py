@@ -470,9 +470,12 @@ class DreamVLA(nn.Module):
 
         return [text_embedding, state_embedding, image_primary_embedding, image_wrist_embedding, cls_primary, cls_wrist]
 
-    def decode_tokens(self, parts, action_label=None, mode='train'):
+    def decode_tokens(self, parts, action_label=None, mode='train', test_noise=None):
         """Token assembly with the prediction queries, trunk, dream heads (train) and action head
-        (dreamvla_model.py:739-991).  `parts`: the list from `encode_frames`, or one (B, S, 36, H) tensor of them."""
+        (dreamvla_model.py:739-991).  `parts`: the list from `encode_frames`, or one (B, S, 36, H) tensor of them.
+        `test_noise` (B*S, action_pred_steps, 7), mode='test' with the DiT head only: the sampler's start noise as an INPUT
+        (the reference draws it with torch.randn inside forward, dreamvla_model.py:941) -- what lets a hipGraph-captured
+        decode take fresh noise per replay and lets a parity test feed the reference's own draw."""
         if torch.is_tensor(parts):
             parts = [parts]
         else:
@@ -596,8 +599,14 @@ class DreamVLA(nn.Module):
                 bs = n
                 cond = action_pred_feature.flatten(0, 1)
                 cfg_scale = 1.5
-                noise = torch.randn(bs, self.action_pred_steps, self.action_model.in_channels,
-                                    device=cond.device).to(cond.dtype)
+                if test_noise is None:
+                    noise = torch.randn(bs, self.action_pred_steps, self.action_model.in_channels,
+                                        device=cond.device).to(cond.dtype)
+                else:
+                    if tuple(test_noise.shape) != (bs, self.action_pred_steps, self.action_model.in_channels):
+                        raise ValueError(f"test_noise {tuple(test_noise.shape)}: expected "
+                                         f"{(bs, self.action_pred_steps, self.action_model.in_channels)}")
+                    noise = test_noise.to(cond.device, cond.dtype)
                 noise = torch.cat([noise, noise], 0)
                 uncondition = self.action_model.net.z_embedder.uncondition.to(cond.dtype)
                 uncondition = uncondition.unsqueeze(0).expand(bs, self.action_pred_steps, -1)
@@ -606,7 +615,8 @@ class DreamVLA(nn.Module):
                     self.action_model.create_ddim(ddim_step=10)
                 samples = self.action_model.ddim_diffusion.ddim_sample_loop(
                     self.action_model.net.forward_with_cfg, noise.shape, noise, clip_denoised=False,
-                    model_kwargs=dict(z=z, cfg_scale=cfg_scale), progress=False, device=cond.device, eta=0.0)
+                    model_kwargs=dict(z=z, cfg_scale=cfg_scale), progress=False, device=cond.device, eta=0.0,
+                    start_noise=None if test_noise is None else noise)
                 samples, _ = samples.chunk(2, dim=0)
                 arm_pred_action, gripper_pred_action = samples.unsqueeze(0)[..., :6], samples.unsqueeze(0)[..., 6:]
 

@@ -13,7 +13,7 @@ over independent episodes) and removes the redundant work:
     the newest frame (1/S of the ViT + resampler + CLIP work), shifts the ring and decodes;
   * both halves of a step have static shapes -- the newest-frame encode (CLIP text tower, ViT on two views, resampler,
     projectors) and the decode (token assembly, 24-layer trunk under the block mask, action head incl. the 10-step DDIM
-    sampler with classifier-free guidance) -- so each is captured once into a hipGraph (`torch.cuda.CUDAGraph`; the
+    sampler with classifier-free guidance; the sampler's start noise is a graph INPUT) -- so each is captured once into a hipGraph (`torch.cuda.CUDAGraph`; the
     ctypes kernel launches go to torch's current stream, which is the capture stream) and replayed per step: ~1 700
     kernel launches of a few microseconds each at B = 1 are launch-bound otherwise.
 
@@ -74,6 +74,8 @@ class RolloutEngine:
         self.count = torch.zeros(self.B, dtype=torch.long)          # host: frames seen per episode (capped at S)
         self.use_graph = bool(use_graph)
         self.warmup_decodes = int(warmup_decodes)
+        self.needs_noise = bool(getattr(m, "use_dit_head", False))       # the MLP action head samples nothing
+        self._no_noise = torch.zeros(1, device=self.device)
         self._decode_g = _Graphed(self._decode_eager, warmup_decodes) if self.use_graph else None
         self._encode_g = _Graphed(self._encode_eager, warmup_decodes) if self.use_graph else None
 
@@ -122,28 +124,42 @@ class RolloutEngine:
         self.count = torch.clamp(k + 1, max=S)
 
     # ------------------------------------------------------------------------------------------------------------
-    def _decode_eager(self, tokens):
-        out = self.model.decode_tokens(tokens, mode="test")
+    def _decode_eager(self, tokens, noise):
+        out = self.model.decode_tokens(tokens, mode="test", test_noise=noise if self.needs_noise else None)
         return out[0], out[1]
 
     @torch.no_grad()
-    def _decode(self, tokens):
-        return (self._decode_g if self.use_graph else self._decode_eager)(tokens)
+    def _decode(self, tokens, noise):
+        return (self._decode_g if self.use_graph else self._decode_eager)(tokens, noise)
+
+    def draw_noise(self, generator=None):
+        """start noise of the action sampler for one control step, (B*S, action_pred_steps, 7) float32 on the device -- what
+        the reference draws inside forward (dreamvla_model.py:941).  It is an INPUT of the captured decode graph (a graph replays
+        its kernels, not its random draws), drawn here per step unless the caller passes its own to `step`."""
+        m = self.model
+        return torch.randn(self.B * self.S, m.action_pred_steps, m.action_model.in_channels, device=self.device,
+                           generator=generator)
 
     @property
     def graphs_captured(self):
         return self.use_graph and self._decode_g.graph is not None and self._encode_g.graph is not None
 
     @torch.no_grad()
-    def step(self, image_primary, image_wrist, state, text_token):
+    def step(self, image_primary, image_wrist, state, text_token, noise=None):
         """One control step of every episode.  Returns (action (B, 7) float32 on the device: 6 arm values and the
         gripper command in {-1, +1} as ModelWrapper.step builds it (eval_utils_calvin.py:136-146), arm (B,S,steps,6),
-        gripper (B,S,steps,1))."""
+        gripper (B,S,steps,1)).  `noise`: the DiT sampler's start noise (see draw_noise); None = drawn here."""
         dt = self.dtype
         new_tok = self.encode_newest(image_primary.to(self.device, dt), image_wrist.to(self.device, dt),
                                      state.to(self.device, dt), text_token.to(self.device))
         self._push(new_tok)
-        arm, grip = self._decode(self.tokens)
+        if not self.needs_noise:
+            noise = self._no_noise
+        elif noise is None:
+            noise = self.draw_noise()
+        else:
+            noise = noise.to(self.device, torch.float32)
+        arm, grip = self._decode(self.tokens, noise)
         B, S = self.B, self.S
         if arm.dim() == 4 and arm.shape[0] == 1 and B * S == arm.shape[1]:   # DiT test head returns (1, B*S, steps, .)
             arm, grip = arm.view(B, S, *arm.shape[2:]), grip.view(B, S, *grip.shape[2:])

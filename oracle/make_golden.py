@@ -134,6 +134,21 @@ FULL_CFGS["C"] = dict(finetune_type="calvin", sequence_length=7, num_resampler_q
                       obs_pred=True, depth_pred=True, sam_feat_pred=True, use_dit_head=True, attn_implementation="sdpa")
 
 
+# the shipped PRETRAIN configuration (scripts/CALVIN_ABC_D/DreamVLA/pretrain.sh:37-52): phase "pretrain", S = 14, 24 layers,
+# obs dream head + MLP action head, --atten_goal 4 --atten_goal_state --atten_only_obs --attn_robot_proprio_state; L = 798.
+# Besides the eval()-module outputs the fixture holds the outputs of the module in TRAINING mode -- where
+# models/dreamvla_model.py:610-628 regenerates the attention mask every forward -- with every nn.Dropout p set to 0 (the
+# dropout streams are not reproducible across implementations; the mask regeneration and the module wiring around it are)
+FULL_CFGS["P"] = dict(finetune_type="calvin", sequence_length=14, num_resampler_query=16, num_obs_token_per_image=9,
+                      action_pred_steps=3, transformer_layers=24, hidden_dim=1024, transformer_heads=16, phase="pretrain",
+                      obs_pred=True, use_dit_head=False, atten_goal=4, atten_goal_state=True, atten_only_obs=True,
+                      attn_robot_proprio_state=True, attn_implementation="sdpa")
+
+# the ROLLOUT configuration that bench.py's `rollout` leg times (BASELINE configs[4], scripts/CALVIN_ABC_D/DreamVLA/eval.sh):
+# S = 10 history, 24 layers, head set C weights, DiT head sampled with DDIM-10 + CFG; L = 930
+FULL_CFGS["R"] = dict(FULL_CFGS["C"], sequence_length=10)
+
+
 def fake_mae_ckpt():
     vit = ref_loader.ref_module("models.vit_mae")
     mae = vit.MaskedAutoencoderViT(patch_size=16, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512,
@@ -151,6 +166,10 @@ def build_reference_model(cfg):
     m.vision_encoder.requires_grad_(False)
     m._init_model_type()
     return m.eval()
+
+
+class _Done(Exception):
+    pass
 
 
 def full_fixture(name):
@@ -194,6 +213,8 @@ def full_fixture(name):
                 torch.randn = fake_randn
                 out = m(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], mode="test")
                 fx["test"] = [None if o is None else o.detach().clone() for o in out]
+                if name == "R":      # the rollout fixture needs the sampler outputs only
+                    raise _Done
                 # the reference's OWN bf16 path (train.py --precision amp_bf16 -> autocast) on the same inputs / noise, five
                 # times (CPU bf16 GEMMs are not run-to-run deterministic): its scatter around the fp32 value is the bf16 floor
                 # of the action-MSE and sets the tolerance of the GPU check (tests/model_checks.py).  Run last, so the fp32
@@ -208,11 +229,29 @@ def full_fixture(name):
                                 action_label=label, mode="train")
                     runs.append(float(o16[0]))
                 fx["train_loss_ref_amp_bf16_runs"] = runs
+            if cfg["phase"] == "pretrain":
+                # TRAINING-mode forward: the reference rebuilds self.attention_mask from the rule (dreamvla_model.py:610-628;
+                # mask_l_obs_ratio = 0: nothing random in it); dropout off so that the result is reproducible
+                for mod in m.modules():
+                    if isinstance(mod, nn.Dropout):
+                        mod.p = 0.0
+                m.train()
+                m.device = torch.device("cpu")     # the regenerated mask is moved `.to(self.device)` (dreamvla_model.py:627)
+                before = m.attention_mask
+                out = m(b["image_primary"], b["image_wrist"], b["state"], b["text_token"], action=None,
+                        action_label=label, mode="train")
+                assert m.attention_mask is not before, "the training-mode forward did not regenerate the mask"
+                fx["training_mode"] = [None if o is None else o.detach().clone() for o in out]
+                m.eval()
+    except _Done:
+        pass
     finally:
         for k, v in real.items():
             setattr(torch, k, v)
     # keep the fixture small: store big dream-head outputs as a strided sample + checksum
-    for key in ("train",):
+    for key in ("train", "training_mode"):
+        if key not in fx:
+            continue
         outs = fx[key]
         for i, o in enumerate(outs):
             if o is not None and o.numel() > 20000:

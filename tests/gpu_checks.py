@@ -326,8 +326,22 @@ def check_self_attention(B, H, L, mask_kind="none", dropout_p=0.0, grad=True, se
         S = L // 93
         assert L == 93 * S
         mask = generate_attention_mask(S, 36, 57, 0, False, False, False, 0.0, 54, 3)
+    mt = None
+    if mask_kind == "pretrain":
+        # the shipped PRETRAIN mask (pretrain.sh:37-52: S = 14, obs head + 3 action tokens -> 36 + 21 tokens per step, L = 798,
+        # --atten_goal 4 --atten_goal_state --atten_only_obs --attn_robot_proprio_state): the kernels' tables come from the RULE
+        # evaluated on the device (csrc/masks.hip, what the pretrain phase runs every step), the oracle gets the mask tensor
+        # of the reference-pinned generator
+        from dreamvla_amd.dreamvla_model import generate_attention_mask
+        S = L // 57
+        assert L == 57 * S
+        rule = dict(K=S, num_A=36, num_B=21, atten_goal=4, atten_goal_state=True, atten_only_obs=True,
+                    attn_robot_proprio_state=True, num_obs_token=18, action_pred_steps=3)
+        mask = generate_attention_mask(mask_l_obs_ratio=0.0, **rule)
+        mt = ops.build_mask_tables_device(DEV, drop=None, **rule)
     qd = qkv.to(DEV, BF).requires_grad_(grad)
-    mt = ops.build_mask_tables(mask, device=DEV) if mask is not None else None
+    if mt is None and mask is not None:
+        mt = ops.build_mask_tables(mask, device=DEV)
     from dreamvla_amd.ops import _Seeds
     _Seeds.counter = 1000 + seed
     o = ops.self_attention(qd, H, mask_tables=mt, dropout_p=dropout_p, scale=scale)
@@ -657,6 +671,8 @@ def all_checks(quick=False):
         (check_self_attention, dict(B=2, H=16, L=930, mask_kind="dreamvla", dropout_p=0.1)),
         # ... at the benchmark's batch: B = 32 trunk (oracle on 8 sampled rows; all rows == their representative without
         # dropout), the decoders' B = 2 * 32 * 7 = 448 sequences of 9 + 196 / 9 + 256 tokens, the DiT head's 1792 x 6
+        (check_self_attention, dict(B=2, H=16, L=798, mask_kind="pretrain")),
+        (check_self_attention, dict(B=2, H=16, L=798, mask_kind="pretrain", dropout_p=0.1)),
         (check_self_attention, dict(B=32, H=16, L=651, mask_kind="dreamvla", dropout_p=0.1, rows=8)),
         (check_self_attention, dict(B=32, H=16, L=651, mask_kind="dreamvla", rows=6, period=5)),
         (check_self_attention, dict(B=448, H=16, L=205, rows=10, period=9)),

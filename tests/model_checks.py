@@ -251,6 +251,16 @@ def hip_gpt2_dropout_checks():
             {"name": "hip.gpt2 train mode (dropout 0.1) dx", "rel_l2": r_g, "tol": 1.5e-2, "ok": r_g <= 1.5e-2}]
 
 
+def zero_dropout(m):
+    """every dropout site of the HIP module off (the trunk keeps its probabilities as attributes, gpt2.py)"""
+    for mod in m.modules():
+        for a in ("attn_pdrop", "resid_pdrop", "embd_pdrop"):
+            if hasattr(mod, a):
+                setattr(mod, a, 0.0)
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+
+
 def hip_full_model_checks(name):
     fx = load(f"dreamvla_{name}.pt")
     m = build_hip_model(fx["cfg"]).to(BF).to("cuda")
@@ -264,6 +274,18 @@ def hip_full_model_checks(name):
             m.action_model._injected = (fx["dit_noise"].to("cuda", BF), fx["dit_timestep"].to("cuda"))
         out = m(*args, action_label=fx["action_label"].to("cuda", BF), mode="train")
         res += compare_outputs(out, fx["train"], TOL_MODEL, f"hip.{name}.train", fx=fx)
+        if "training_mode" in fx:
+            # pretrain phase, module in TRAINING mode: the reference regenerates the mask every forward
+            # (dreamvla_model.py:610-628); here the kernels' tables are computed on the device from the rule
+            # (DreamVLA._pretrain_mask_tables).  Dropout 0 on both sides (the fixture was generated that way).
+            zero_dropout(m)
+            m.train()
+            out = m(*args, action_label=fx["action_label"].to("cuda", BF), mode="train")
+            used_rule = getattr(m, "_step_mask_tables", None) is not None
+            m.eval()
+            res.append({"name": f"hip.{name}.training_mode: mask tables came from the device-side rule", "rel_l2": 0.0, "tol": 0.0,
+                        "ok": bool(used_rule)})
+            res += compare_outputs(out, fx["training_mode"], TOL_MODEL, f"hip.{name}.training_mode", fx=fx)
         if fx["cfg"]["use_dit_head"]:
             want, got = float(fx["train"][0]), float(out[0])
             # north_star: action-MSE parity within 1e-3 (relative once the loss exceeds 1) -- or, where the REAL reference's

@@ -22,13 +22,30 @@ class WindowOracle:
         return window, pick
 
 
-def gpu_rollout_checks(head="mlp", use_graph=True, steps=7, tol=2e-2):
-    """engine vs full-window forward on cuda, B = 3 episodes, S = 4, one episode reset mid-way."""
+# Tolerances.  Engine and full-window forward run the same kernels on differently shaped problems (one frame per encode
+# instead of S: other GEMM tile / split choices, i.e. another fp32 summation order before each bf16 rounding), so the two
+# agree to bf16 rounding noise, which the 10 sampler steps of the DiT head amplify exactly as they amplify it between
+# two bf16 runs of the reference.  The bound is therefore the REAL reference's own recorded bf16 deviation of the same
+# sampler run x 1.25 (tests/model_checks.py::REF_DEV_FACTOR) -- round 3 allowed a flat 2e-2 and did not compare the
+# DiT + hipGraph combination at all.
+def _fixture_tols(name):
+    from tests.model_checks import REF_DEV_FACTOR, load
+    rec = load(f"dreamvla_{name}.pt")["ref_test_bf16_deviation"]
+    return REF_DEV_FACTOR * rec[0]["rel_l2"], REF_DEV_FACTOR * rec[1]["rel_l2"]
+
+
+MLP_TOL = 1.25 * 6.78e-3      # fixture A: the reference's own `--precision bf16` deviation of the MLP head's arm action
+
+
+def gpu_rollout_checks(head="mlp", use_graph=True, steps=7):
+    """engine vs full-window forward of the HIP module on cuda (same start noise through both), B = 3 episodes, S = 4, one
+    episode reset mid-way: queue semantics + cache + graph replay.  Every step compares the ACTIONS (no finite-only branch)."""
     from dreamvla_amd.dreamvla_model import DreamVLA
     from dreamvla_amd.rollout import RolloutEngine
     from oracle import weights
     BF = torch.bfloat16
     S, B = 4, 3
+    tol = MLP_TOL if head == "mlp" else max(_fixture_tols("B"))
     cfg = dict(finetune_type="calvin", sequence_length=S, num_resampler_query=16, num_obs_token_per_image=9,
                action_pred_steps=3, transformer_layers=2, hidden_dim=1024, transformer_heads=16, phase="finetune",
                obs_pred=True, use_dit_head=(head == "dit"), attn_implementation="sdpa")
@@ -44,7 +61,6 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7, tol=2e-2):
     text[:, 21:] = 0
     oracles = [WindowOracle(S) for _ in range(B)]
     res = []
-    real_randn = torch.randn
     for t in range(steps):
         if t == 5:                                  # restart episode 1 only
             mask = torch.tensor([False, True, False])
@@ -53,30 +69,80 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7, tol=2e-2):
         fr = dict(ip=torch.randn(B, 3, 224, 224, generator=g).to(BF), iw=torch.randn(B, 3, 224, 224, generator=g).to(BF),
                   st=torch.cat([torch.rand(B, 6, generator=g), (torch.rand(B, 1, generator=g) > 0.5).float()], -1).to(BF))
         wins, picks = zip(*[o.push({k: v[b] for k, v in fr.items()}) for b, o in enumerate(oracles)])
-        noise = real_randn(B * S, 3, 7, generator=g).to("cuda")
-        if head == "dit" and not use_graph:
-            torch.randn = lambda *a, **k: noise.clone()
-        try:
-            action, arm, grip = eng.step(fr["ip"], fr["iw"], fr["st"], text)
-            stack = lambda key: torch.stack([torch.stack([f[key] for f in w]) for w in wins]).to("cuda")
-            with torch.no_grad():
-                out = m(stack("ip"), stack("iw"), stack("st"), text.unsqueeze(1).repeat(1, S, 1).to("cuda"), mode="test")
-        finally:
-            torch.randn = real_randn
+        noise = torch.randn(B * S, 3, 7, generator=g).to(BF).float().to("cuda")
+        action, arm, grip = eng.step(fr["ip"], fr["iw"], fr["st"], text, noise=noise)
+        stack = lambda key: torch.stack([torch.stack([f[key] for f in w]) for w in wins]).to("cuda")
+        with torch.no_grad():
+            parts = m.encode_frames(stack("ip"), stack("iw"), stack("st"), text.unsqueeze(1).repeat(1, S, 1).to("cuda"))
+            out = m.decode_tokens(parts, mode="test", test_noise=noise if head == "dit" else None)
         ra, rg = out[0], out[1]
         if head == "dit":
             ra, rg = ra.view(B, S, 3, 6), rg.view(B, S, 3, 1)
         want = torch.stack([ra[b, picks[b], 0].float() for b in range(B)])
         got = action[:, :6]
+        tag = f"rollout.{head}.graph{int(use_graph)}.t{t}"
         ok_sel = bool((eng.count - 1 == torch.tensor(picks)).all())
-        res.append({"name": f"rollout.{head}.graph{int(use_graph)}.t{t}.window_pick", "rel_l2": 0.0, "tol": 0.0, "ok": ok_sel})
+        res.append({"name": tag + ".window_pick", "rel_l2": 0.0, "tol": 0.0, "ok": ok_sel})
         finite = bool(torch.isfinite(action).all()) and bool(((action[:, 6].abs() - 1).abs() < 1e-6).all())
-        res.append({"name": f"rollout.{head}.graph{int(use_graph)}.t{t}.finite", "rel_l2": 0.0, "tol": 0.0, "ok": finite})
-        if head == "mlp" or not use_graph:          # with the DiT head under a graph the sampler noise is the graph's own
-            r = float((got - want).norm() / max(float(want.norm()), 1e-12))
-            res.append({"name": f"rollout.{head}.graph{int(use_graph)}.t{t}.action", "rel_l2": r, "tol": tol, "ok": r <= tol})
-            r2 = float((arm.float() - ra.float()).norm() / max(float(ra.float().norm()), 1e-12))
-            res.append({"name": f"rollout.{head}.graph{int(use_graph)}.t{t}.arm_all_positions", "rel_l2": r2, "tol": tol, "ok": r2 <= tol})
+        res.append({"name": tag + ".finite", "rel_l2": 0.0, "tol": 0.0, "ok": finite})
+        r = float((got - want).norm() / max(float(want.norm()), 1e-12))
+        res.append({"name": tag + ".action", "rel_l2": r, "tol": tol, "ok": r <= tol})
+        r2 = float((arm.float() - ra.float()).norm() / max(float(ra.float().norm()), 1e-12))
+        res.append({"name": tag + ".arm_all_positions", "rel_l2": r2, "tol": tol, "ok": r2 <= tol})
+        r3 = float((grip.float() - rg.float()).norm() / max(float(rg.float().norm()), 1e-12))
+        res.append({"name": tag + ".gripper_all_positions", "rel_l2": r3, "tol": tol, "ok": r3 <= tol})
+        if use_graph and t >= 2:                   # two eager warm-up decodes, then the capture: later steps are replays
+            res.append({"name": tag + ".graph_replayed", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
+    return res
+
+
+def gpu_rollout_vs_reference(name, use_graph=True):
+    """The engine against the REAL reference: fixture `name` (B, E, F: S = 2, 2 layers; C: S = 7, 24 layers; R: S = 10, 24
+    layers = the configuration bench.py's rollout leg times) holds fx["test"], the real reference's `mode="test"` outputs
+    on a full window with a recorded start noise (oracle/make_golden.py).  The window's S frames are pushed through the
+    engine one control step at a time (utils/eval_utils_calvin.py:103-134 queue semantics); after the S-th push the
+    engine's window IS the fixture's window, and its sampled actions -- DDIM-10 + CFG (or the flow-matching Euler loop)
+    from the recorded noise, decode replayed from the hipGraph -- are compared with the reference's at 1.25 x the
+    reference's own bf16 deviation of that sampler run.  Earlier steps (padded windows) are compared with the HIP
+    module's full-window forward on the same padded window and noise."""
+    from dreamvla_amd.rollout import RolloutEngine
+    from tests.model_checks import BF, build_hip_model, compare_outputs, golden_inputs, load
+    fx = load(f"dreamvla_{name}.pt")
+    cfg, S = fx["cfg"], fx["S"]
+    assert fx["B"] == 1
+    m = build_hip_model(cfg).to(BF).to("cuda")
+    m._init_model_type()
+    m.eval()
+    inp = {k: v.to("cuda") for k, v in golden_inputs(fx).items()}
+    ip, iw, st, tx = inp["image_primary"].to(BF), inp["image_wrist"].to(BF), inp["state"].to(BF), inp["text_token"]
+    eng = RolloutEngine(m, 1, use_graph=use_graph, warmup_decodes=1)     # step 1 eager, capture at step 2, replays afterwards
+    tn = fx["test_noise"].to("cuda")
+    tol_arm, tol_grip = _fixture_tols(name)
+    res = []
+    g = torch.Generator().manual_seed(11)
+    for k in range(S):
+        last = k == S - 1
+        noise = tn if last else torch.randn(tn.shape, generator=g).to(BF).float().to("cuda")
+        action, arm, grip = eng.step(ip[:, k], iw[:, k], st[:, k], tx[:, k], noise=noise)
+        tag = f"rollout.ref.{name}.graph{int(use_graph)}.k{k + 1}"
+        if last:
+            out = (arm.reshape(1, S, *arm.shape[2:]), grip.reshape(1, S, *grip.shape[2:])) + (None,) * 8
+            want = list(fx["test"][:2]) + [None] * 8
+            res += compare_outputs(out, want, 1e-3, tag + ".vs_real_reference", fx=fx, records=("ref_test_bf16_deviation",))
+            ref_pick = fx["test"][0].view(S, -1, 6)[S - 1, 0].float()
+            r = float((action[0, :6].cpu() - ref_pick).norm() / max(float(ref_pick.norm()), 1e-12))
+            res.append({"name": tag + ".picked_action_vs_real_reference", "rel_l2": r, "tol": 2.0 * tol_arm, "ok": r <= 2.0 * tol_arm})
+            gsign = (fx["test"][1].view(S, -1, 1)[S - 1, 0].float() > 0.5).float() * 2 - 1     # eval_utils_calvin.py:141-146
+            res.append({"name": tag + ".gripper_command", "rel_l2": 0.0, "tol": 0.0, "ok": bool(action[0, 6].cpu() == gsign[0])})
+        else:
+            idx = list(range(k + 1)) + [k] * (S - k - 1)                  # eval_utils_calvin.py:118-126: last frame repeated
+            with torch.no_grad():
+                parts = m.encode_frames(ip[:, idx], iw[:, idx], st[:, idx], tx[:, idx])
+                o = m.decode_tokens(parts, mode="test", test_noise=noise)
+            ra, rg = o[0].view(1, S, -1, 6), o[1].view(1, S, -1, 1)
+            for nm, a, b_, t in (("arm", arm, ra, tol_arm), ("gripper", grip, rg, tol_grip)):
+                r = float((a.float() - b_.float()).norm() / max(float(b_.float().norm()), 1e-12))
+                res.append({"name": f"{tag}.{nm}_vs_full_window_forward", "rel_l2": r, "tol": t, "ok": r <= t})
     if use_graph:
-        res.append({"name": f"rollout.{head}.graph_captured", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
+        res.append({"name": f"rollout.ref.{name}.graph_captured", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
     return res

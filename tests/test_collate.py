@@ -77,6 +77,77 @@ def test_host_side_layout_matches_the_reference_collator():
     assert torch.equal(d_s[0], want[:4])
 
 
+def test_token_cache_overflow_keeps_the_whole_batch():
+    """round-3 ADVICE: a clear in the middle of a batch must not lose the batch's already-cached strings"""
+    calls.clear()
+    tc = collate.TokenCache(_fake_tokenize, max_entries=3)
+    tc(["a", "b", "c"])
+    out = tc(["a", "d", "b"])                      # 3 cached + 1 new > 3: cleared, the whole batch re-tokenised
+    assert out.shape == (3, 77) and calls[-1] == ["a", "d", "b"]
+    assert torch.equal(out[0], _fake_tokenize(["a"])[0]) and torch.equal(out[2], _fake_tokenize(["b"])[0])
+
+
+def _libero_reference_collate(sample, window_size, act_step):
+    """restatement of the host half of DiskLiberoDataset.collator (data_utils.py:2719-2798) -- actions, states, robot_obs
+    chunking, label cuts, return layout; the image half is the CALVIN one (same image_fn / RandomShiftsAug calls)"""
+    action = torch.from_numpy(np.array([np.stack(s["actions"]) for s in sample]))
+    state = torch.from_numpy(np.array([np.stack(s["robot_obs"]) for s in sample]))
+    _ = [s["episode_id"] for s in sample]
+    sam = torch.stack([s["sam_features_obs"]["sam_feats_static"] for s in sample]) if "sam_features_obs" in sample[0] else None
+    tr = None
+    if "track_label" in sample[0]:
+        tr = {k: torch.stack([s["track_label"][k] for s in sample]) for k in ("tracks", "track_visibility", "tracks_gripper",
+                                                                               "track_visibility_gripper")}
+    robot = torch.zeros(1)
+    if act_step != 1:
+        acts = torch.zeros((action.shape[0], window_size, act_step, action.shape[-1]))
+        robot = torch.zeros((action.shape[0], window_size, act_step, state.shape[-1]))
+        for b in range(action.shape[0]):
+            for ix in range(window_size):
+                acts[b, ix] = action[b, ix:ix + act_step]
+                robot[b, ix] = state[b, ix:ix + act_step]
+        robot = torch.cat([robot[..., :6], robot[..., [-1]]], dim=-1)
+        action = acts
+        state = state[:, :-(act_step - 1)]
+        sam = None if sam is None else sam[:, :-(act_step - 1)]
+        tr = None if tr is None else {k: v[:, :-(act_step - 1)] for k, v in tr.items()}
+    return action, state, robot, sam, (tr if tr is not None else dict())
+
+
+@pytest.mark.parametrize("act_step", [1, 3])
+def test_libero_collator_layout(act_step):
+    """DiskLiberoDataset.collator (data_utils.py:2719-2798): no depth entries even when the samples carry depth, the track
+    dictionary whenever the samples have `track_label`, `episode_id` required, robot_obs chunking (2765-2772)"""
+    T = 6
+    W = T - (act_step - 1)
+    smp = _samples(3, T)
+    for i, s in enumerate(smp):
+        s["episode_id"] = 100 + i
+        s["robot_obs"] = [np.concatenate([r, r[:1]]) for r in s["robot_obs"]]      # 16 values: LIBERO's proprio layout is wider
+        s["track_label"] = {k: torch.randn(T, 196, 2) for k in ("tracks", "track_visibility", "tracks_gripper",
+                                                                 "track_visibility_gripper")}
+    col = collate.LiberoDeviceCollator(_fake_tokenize, window_size=W, act_step=act_step, device="cpu")
+    col._camera = lambda sample, cam, pad: torch.zeros(len(sample), T, 3, 8, 8)
+    out = col(smp)
+    assert len(out) == 13
+    img, txt, act, grip, state, robot, d_s, d_g, dino, dino_g, sam, sam_g, tr = out
+    assert d_s is None and d_g is None                       # LIBERO: no depth path although the samples hold depth_obs
+    r_act, r_state, r_robot, r_sam, r_tr = _libero_reference_collate(smp, W, act_step)
+    assert torch.equal(act, r_act) and torch.equal(state, r_state) and torch.equal(robot, r_robot) and torch.equal(sam, r_sam)
+    assert set(tr) == set(r_tr) and all(torch.equal(tr[k], r_tr[k]) for k in tr)
+    assert img.shape[1] == W and grip.shape[1] == W and txt.shape == (3, 77)
+    if act_step != 1:
+        assert robot.shape == (3, W, act_step, 7) and act.shape == (3, W, act_step, 7)
+    # the CALVIN flavour on the same samples: depth present, tracks withheld without load_track_labels
+    outc = collate.DeviceCollator(_fake_tokenize, window_size=W, act_step=act_step, device="cpu")
+    outc._camera = col._camera
+    oc = outc(smp)
+    assert oc[6] is not None and oc[12] == {}
+    del smp[1]["episode_id"]
+    with pytest.raises(KeyError):
+        col(smp)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("traj", [False, True])
 def test_device_frames_match_host_transform_and_shift(traj):

