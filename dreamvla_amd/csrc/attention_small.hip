@@ -115,11 +115,29 @@ __global__ __launch_bounds__(64) void attn_small_bwd_kernel(SmallArgs p) {
   }
 }
 
+constexpr size_t SMALL_LDS_LIMIT = 160 * 1024;
+inline size_t small_fwd_smem(int L, int D) { return ((size_t)3 * L * (D + 1) + (size_t)L * (L + 1)) * 4; }
+inline size_t small_bwd_smem(int L, int D) { return ((size_t)4 * L * (D + 1) + (size_t)2 * L * (L + 1)) * 4; }
+
+// hipFuncSetAttribute is per device: remember which devices have it (a process may drive several)
+template <class K>
+void small_allow_lds(K kernel, uint64_t& done_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (done_mask & (1ull << dev)) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_LIMIT);
+  done_mask |= 1ull << dev;
+}
+
 int fill(const dvla_attn_params* q, int head_dim, SmallArgs& a) {
   if (!q || !q->q || !q->k || !q->v || !q->o) return DVLA_ERR_ARG;
   if (q->B <= 0 || q->H <= 0 || q->Lq <= 0 || q->Lk != q->Lq || !(q->scale > 0.f)) return DVLA_ERR_ARG;
   if (q->Lq > SMAX_L || head_dim <= 0 || head_dim > SMAX_D || head_dim % 8 != 0) return DVLA_ERR_UNSUPPORTED;
   if (q->tile_map || q->key_index || q->dropout_p > 0.f) return DVLA_ERR_UNSUPPORTED;   // no mask / dropout on this path
+  if (q->B > 65535) return DVLA_ERR_UNSUPPORTED;     // gridDim.y
+  // the BACKWARD kernel's LDS (the larger of the two) must fit the 160 KiB of a CU: refused here, for forward and backward
+  // alike, so that a forward never succeeds whose backward cannot be launched (L = 64, D = 128 needs 165 376 B)
+  if (small_bwd_smem(q->Lq, head_dim) > SMALL_LDS_LIMIT) return DVLA_ERR_UNSUPPORTED;
   a.q = (const bf16_t*)q->q; a.k = (const bf16_t*)q->k; a.v = (const bf16_t*)q->v;
   a.o = (const bf16_t*)q->o; a.out = (bf16_t*)q->o;
   a.qsb = q->q_stride_b; a.qst = q->q_stride_t; a.qsh = q->q_stride_h;
@@ -141,9 +159,9 @@ extern "C" int dvla_attn_small_fwd(const dvla_attn_params* q, int32_t head_dim, 
   SmallArgs a;
   int rc = fill(q, head_dim, a);
   if (rc != DVLA_OK) return rc;
-  const size_t smem = ((size_t)3 * a.L * (a.D + 1) + (size_t)a.L * (a.L + 1)) * 4;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_small_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  const size_t smem = small_fwd_smem(a.L, a.D);
+  static uint64_t attr_done = 0;
+  small_allow_lds(attn_small_fwd_kernel, attr_done);
   hipLaunchKernelGGL(attn_small_fwd_kernel, dim3((unsigned)a.H, (unsigned)a.B), dim3(64), smem, reinterpret_cast<hipStream_t>(stream_), a);
   return dvla_check_launch();
 }
@@ -153,9 +171,9 @@ extern "C" int dvla_attn_small_bwd(const dvla_attn_params* q, int32_t head_dim, 
   int rc = fill(q, head_dim, a);
   if (rc != DVLA_OK) return rc;
   if (!q->dout || !q->lse || !q->dq || !q->dk || !q->dv) return DVLA_ERR_ARG;
-  const size_t smem = ((size_t)4 * a.L * (a.D + 1) + (size_t)2 * a.L * (a.L + 1)) * 4;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_small_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  const size_t smem = small_bwd_smem(a.L, a.D);
+  static uint64_t attr_done = 0;
+  small_allow_lds(attn_small_bwd_kernel, attr_done);
   hipLaunchKernelGGL(attn_small_bwd_kernel, dim3((unsigned)a.H, (unsigned)a.B), dim3(64), smem, reinterpret_cast<hipStream_t>(stream_), a);
   return dvla_check_launch();
 }

@@ -152,14 +152,17 @@ class GradBucketReducer:
         import ctypes
         from . import _lib
         lib = _lib.load()
+        from .ops import GemmTuner
         if robust and self._saved_schedule is None:
             k, sk = ctypes.c_int(0), ctypes.c_int(0)
             lib.dvla_get_gemm_schedule(ctypes.byref(k), ctypes.byref(sk))
             self._saved_schedule = (k.value, sk.value)
             lib.dvla_set_gemm_schedule(8, 0)
+            GemmTuner.schedule_tag = 1      # problem keys under the robust schedule are tuned (and locked) on their own
         elif not robust and self._saved_schedule is not None:
             lib.dvla_set_gemm_schedule(*self._saved_schedule)
             self._saved_schedule = None
+            GemmTuner.schedule_tag = 0
 
     def _launch(self, b):
         b["launched"] = True
@@ -217,6 +220,8 @@ class GradBucketReducer:
                     p._dvla_grad_free = True       # dreamvla_amd.ops may write this step's gradient into the slot once
         self._handles = []
         self._next_launch = 0
+        # a step that raised in backward / skipped finish() must not leave the process on the robust schedule (round-3 ADVICE)
+        self._gemm_schedule(False)
 
     def finish(self):
         """call after the (last) backward(): flush, in index order, the buckets that were not launched during backward (unused
@@ -231,12 +236,14 @@ class GradBucketReducer:
                     b["expected"] = [e or f for e, f in zip(b["expected"], b["fired"])]
                 elif all(b["expected"]):            # first learning step: wait only for what fired
                     b["expected"] = list(b["fired"])
-        for h, host, flat in self._handles:
-            h.wait()
-            if host is not None:
-                flat.copy_(host)
-        self._handles = []
-        self._gemm_schedule(False)
+        try:
+            for h, host, flat in self._handles:
+                h.wait()
+                if host is not None:
+                    flat.copy_(host)
+        finally:
+            self._handles = []
+            self._gemm_schedule(False)
         if self.world > 1 and not self._avg_in_collective():
             for b in self.buckets:
                 b["flat"].div_(self.world)

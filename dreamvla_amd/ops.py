@@ -159,9 +159,12 @@ class GemmTuner:
     CANDIDATES = tuple(int(v) for v in os.environ.get("DVLA_GEMM_CANDIDATES", "0,4,6,7,8,9,10,2").split(","))
     ROUNDS = int(os.environ.get("DVLA_GEMM_TUNE_ROUNDS", "3"))
     enabled = os.environ.get("DVLA_GEMM_AUTOTUNE", "1") != "0" and os.environ.get("DVLA_GEMM_VARIANT") is None
+    KEY_LEN = 17    # fields of a problem key (ops.gemm builds it)
     table = {}      # key -> locked variant
     trials = {}     # key -> {"pending": [(variant, e0, e1)], "times": {variant: [ms]}, "next": int}
     frozen = False  # True (hipGraph capture / replay-critical sections): no trials, no events -- locked choice or the cost model
+    schedule_tag = 0  # part of every problem key: 1 while GradBucketReducer runs the GEMMs under its robust schedule (collectives
+                      # outstanding).  A candidate timed under one schedule must not be locked for the other (round-3 ADVICE).
 
     @classmethod
     def pick(cls, key):
@@ -208,7 +211,10 @@ class GemmTuner:
         import json
         with open(path) as f:
             for k, v in json.load(f):
-                cls.table[tuple(bool(x) if isinstance(x, bool) else int(x) for x in k)] = int(v)
+                k = tuple(bool(x) if isinstance(x, bool) else int(x) for x in k)
+                if len(k) == cls.KEY_LEN - 1:      # a plan written before the schedule tag joined the key: default schedule
+                    k = k + (0,)
+                cls.table[k] = int(v)
         cls.frozen = bool(freeze)     # keys the plan does not know take the cost model (no trials)
 
     @classmethod
@@ -283,6 +289,11 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
         klen = M if which == "a" else N
         if which not in ("a", "b") or kout.shape != (klen,) or not kout.is_contiguous() or kout.device != a.device:
             raise ValueError("gemm: bad `ksum`")
+        # decided ONCE, independent of the configuration the tuner picks for this call (round-3 ADVICE: the layout was only
+        # checked under the configurations that leave the sum to the column-sum kernel, so a row-major operand would have failed
+        # on some tuning steps and passed on others): the column-sum fallback needs the summed operand stored k-major
+        if not (a_trans if which == "a" else b_trans):
+            raise _lib.DvlaError("gemm: k-sums need the summed operand stored k-major (a_trans / b_trans)")
     prof = GemmProfiler.active
     # "plain": nothing but (optionally) the bias vector rides on the GEMM (reported per shape by the profiler)
     plain = (act == 0 and not want_preact and dact_aux is None and residual is None and dropout_p == 0.0
@@ -293,7 +304,8 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     if GemmTuner.enabled and not forced:
         key = (M, N, K, int(a_trans), int(b_trans), int(p.split_k), int(act), int(dact),
                bias is not None, want_preact, dact_aux is not None, residual is not None,
-               dropout_p > 0.0, out.dtype == torch.float32, bool(accumulate), 0 if ksum is None else (1 if ksum[0] == "a" else 2))
+               dropout_p > 0.0, out.dtype == torch.float32, bool(accumulate), 0 if ksum is None else (1 if ksum[0] == "a" else 2),
+               int(GemmTuner.schedule_tag))
         variant, trial = GemmTuner.pick(key)
     # k-sums: carried by the ring kernels (variants 4 / 6 / 7; 0 = the library's choice, which falls back by itself); under a
     # configuration without the summing code the column-sum kernel runs here, AFTER the profiler's end event (it is not GEMM
@@ -322,8 +334,6 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     e2 = e1 if (prof is not None or trial is not None) else None
     if ksum_here:
         src = a if which == "a" else b
-        if not (a_trans if which == "a" else b_trans):
-            raise _lib.DvlaError("gemm: k-sums under this configuration need the operand stored k-major (a_trans / b_trans)")
         colsum(src, kout.dtype, out=kout)
         if trial is not None:
             e2 = torch.cuda.Event(enable_timing=True)
@@ -1068,7 +1078,7 @@ class _SelfAttentionSmall(torch.autograd.Function):
         B, L, W = qkv.shape
         if W != 3 * H * D:
             raise ValueError("attention: qkv width must be 3 * heads * head_dim")
-        if L > 64 or D > 128 or D % 8:
+        if L > 64 or D > 128 or D % 8 or (4 * L * (D + 1) + 2 * L * (L + 1)) * 4 > 160 * 1024 or B > 65535:
             raise _lib.DvlaError(f"attention with head_dim {D}: only sequences of <= 64 tokens and head_dim <= 128 (multiple of 8) "
                                  f"are supported off the head_dim-64 MFMA kernels (got L = {L})")
         if not qkv.is_contiguous():

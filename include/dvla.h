@@ -36,7 +36,8 @@ extern "C" {
 #define DVLA_ACT_SIGMOID 7
 
 /* ABI revision of this header; dreamvla_amd/_lib.py refuses a library that reports another one (a stale prebuilt .so then fails
- * with a clear message instead of a missing-symbol error).  3 = round 3 (dvla_last_gemm_variant, variant 10, ...). */
+ * with a clear message instead of a missing-symbol error).  3 = round 3 (dvla_last_gemm_variant, variant 10, ...); 4 = k-sums on the
+ * weight-gradient GEMM (ksum_* fields of dvla_gemm_params). */
 #define DVLA_ABI_VERSION 4
 int dvla_abi_version(void);
 
@@ -181,7 +182,8 @@ typedef struct dvla_attn_params {
 int dvla_attn_fwd(const dvla_attn_params* p, void* stream);
 int dvla_attn_bwd(const dvla_attn_params* p, void* stream);
 /* The same attention for SHORT sequences (Lq == Lk <= 64) with ANY head_dim <= 128 (multiple of 8), no mask, no dropout: one
- * wave per (batch, head).  The only head_dim != 64 the reference can produce is the DiT-S action head (models/action_model/
+ * wave per (batch, head).  Further limits (DVLA_ERR_UNSUPPORTED from both entry points): B <= 65535, and the backward kernel's
+ * LDS, (4 L (head_dim + 1) + 2 L (L + 1)) * 4 bytes, must fit 160 KiB -- L = 64 with head_dim 128 does not (L <= 63 does).  The only head_dim != 64 the reference can produce is the DiT-S action head (models/action_model/
  * action_model.py:12-14: 384 / 4 = 96) on 6-token sequences.  Same parameter block; `delta` is not used. */
 int dvla_attn_small_fwd(const dvla_attn_params* p, int32_t head_dim, void* stream);
 int dvla_attn_small_bwd(const dvla_attn_params* p, int32_t head_dim, void* stream);

@@ -16,6 +16,7 @@ Tolerances (written here, used everywhere):
 rel-L2 = ||a - b||_2 / max(||b||_2, tiny).
 """
 import math
+import os
 
 import torch
 
@@ -218,6 +219,153 @@ def check_gemm_model_scale(name):
                 out.append({"name": tag + f": forced configuration ran (dvla_last_gemm_variant = {ran})", "rel_l2": 0.0, "tol": 0.0,
                             "ok": ran == v})
             del r, got, pre
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Every (shape, layout, epilogue) problem of the TIMED training step under the configuration the tuner locked for it
+# (round-3 VERDICT weak #3: MODEL_GEMMS above is a hand-picked list of 10 of the 121 problem keys).  The keys come from the
+# plan file bench.py --save-plan wrote on the GPU (profiles/r0N_gemm_plan.json: the kernel mix the bench line was measured
+# with).  Per key, at full size:
+#   (1) the whole output against the oracle's formulas (oracle/torch_ref.py act / drop_keep_mask) evaluated in fp32 ON THE
+#       DEVICE (an fp32 ATen matmul of the same bf16 operand values; the outputs are up to 1 GB, a host round trip per key
+#       would take minutes) -- rel-L2 + the element-wise bound of `metrics`;
+#   (2) a block of sampled rows x sampled columns (first / last rows and columns, the rows and columns either side of
+#       every kind of tile boundary: 31/32, 127/128, 255/256, seeded random others) against the CPU oracle proper;
+#   (3) dvla_last_gemm_variant(): the locked configuration ran (or its documented fallback inside the library: the
+#       register-staged kernel for shapes a configuration does not take, the plain schedule when stream-K does not engage).
+# ---------------------------------------------------------------------------------------------------
+ACT_NAMES = {0: "none", 1: "gelu_erf", 2: "gelu_tanh", 3: "relu", 4: "silu", 5: "quick_gelu", 6: "tanh", 7: "sigmoid"}
+
+
+def load_gemm_plan():
+    """-> (file name, [(key tuple, variant)]) of the newest committed plan"""
+    import glob
+    import json
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    files = sorted(glob.glob(os.path.join(root, "r[0-9][0-9]_gemm_plan.json")))
+    if not files:
+        return None, []
+    with open(files[-1]) as f:
+        plan = json.load(f)
+    return os.path.basename(files[-1]), [(tuple(k), int(v)) for k, v in plan]
+
+
+def _sample_index(n, count, seed):
+    pts = {0, 1, n - 1, n - 2}
+    for edge in (32, 128, 256):
+        for mult in (1, 2, (n // edge) - 1, n // edge):
+            for d in (-1, 0):
+                pts.add(mult * edge + d)
+    g = torch.Generator().manual_seed(seed)
+    pts |= set(torch.randint(0, n, (count,), generator=g).tolist())
+    pts = sorted(i for i in pts if 0 <= i < n)
+    if len(pts) > count:
+        keep = set(torch.randperm(len(pts), generator=g)[:count].tolist())
+        pts = [v for i, v in enumerate(pts) if i in keep or v in (0, n - 1)]
+    return torch.tensor(pts, dtype=torch.int64)
+
+
+def _dev_metrics(name, got, ref, tol, round_ref=True, k_ulp=None):
+    """`metrics` evaluated on the device (no host copy of the output)"""
+    g = got.detach().float()
+    ref_c = ref.to(BF).float() if round_ref else ref
+    num = float((g - ref_c).norm())
+    den = max(float(ref_c.norm()), 1e-12)
+    d = (g - ref_c).abs()
+    max_abs, absmax = float(d.max()), float(ref_c.abs().max())
+    finite = bool(torch.isfinite(g).all())
+    if round_ref:
+        k = elem_ulps(tol) if k_ulp is None else k_ulp
+        elem_tol = k * 2.0 ** -8 * absmax + 1e-30
+    else:
+        k = None
+        elem_tol = (2e-4 if tol <= 1e-4 else 20 * tol) * absmax + 1e-6
+    r = num / den
+    return {"name": name, "rel_l2": r, "max_abs": max_abs, "ref_absmax": absmax, "max_abs_tol": elem_tol, "k_ulp": k,
+            "shape": list(g.shape), "finite": finite, "tol": tol, "ok": bool(finite and r <= tol and max_abs <= elem_tol)}
+
+
+def check_gemm_plan_entry(key, variant):
+    from dreamvla_amd import _lib, ops
+    (M, N, K, a_trans, b_trans, split_k, act_i, dact_i, has_bias, want_preact, has_aux, has_res, has_drop, out_f32, accumulate,
+     ksum_i) = key[:16]
+    act, dact = ACT_NAMES[int(act_i)], (ACT_NAMES[int(dact_i)] if has_aux else None)
+    p_drop = 0.1 if has_drop else 0.0
+    g = torch.Generator(device=DEV).manual_seed(20260926 + (M * 31 + N * 17 + K) % 100003)
+    A = torch.randn((M, K), generator=g, device=DEV).to(BF)
+    Bm = (torch.randn((N, K), generator=g, device=DEV) / math.sqrt(K) + (0.01 if ksum_i else 0.0)).to(BF)
+    bias = torch.randn((N,), generator=g, device=DEV).to(BF) if has_bias else None
+    res = torch.randn((M, N), generator=g, device=DEV).to(BF) if has_res else None
+    aux = torch.randn((M, N), generator=g, device=DEV).to(BF) if has_aux else None
+    c0 = torch.randn((M, N), generator=g, device=DEV) if accumulate else None
+    sd = (77, 4242)
+    rows, cols = _sample_index(M, 96, 1), _sample_index(N, 128, 2)
+
+    def oracle(a32, b32, bias32, res32, aux32, ridx, cidx, c_init):
+        """the epilogue of include/dvla.h in the oracle's formulas; a32 (m, K), b32 (n, K) fp32 on any device"""
+        ref = a32 @ b32.t()
+        if bias32 is not None:
+            ref = ref + bias32
+        pre = ref.clone() if want_preact else None
+        if want_preact:
+            ref = R.bf16_round(ref) if ref.device.type == "cpu" else ref.to(BF).float()
+        ref = R.act(ref, act)
+        if p_drop > 0:
+            keep = R.drop_keep_mask(sd, ridx[:, None], cidx[None, :], p_drop)
+            ref = torch.where(keep, ref / (1.0 - p_drop), torch.zeros_like(ref))
+        if dact or res32 is not None:
+            ref = ref.to(BF).float()
+        if dact:
+            x = aux32.clone().requires_grad_(True)
+            R.act(x, dact).sum().backward()
+            ref = ref * x.grad
+        if res32 is not None:
+            ref = ref + res32
+        if c_init is not None:
+            ref = ref + c_init
+        return ref, pre
+
+    a_dev = A.t().contiguous() if a_trans else A
+    b_dev = Bm.t().contiguous() if b_trans else Bm
+    kout = None
+    if ksum_i:
+        kout = torch.full((M if ksum_i == 1 else N,), float("nan"), dtype=torch.float32, device=DEV)
+    out_buf = c0.clone() if accumulate else None
+    out = []
+    tag = (f"plan gemm {M}x{N}x{K} at{int(a_trans)} bt{int(b_trans)} sk{split_k} act{act_i} dact{dact_i} b{int(has_bias)} "
+           f"pre{int(want_preact)} res{int(has_res)} drop{int(has_drop)} f32{int(out_f32)} acc{int(accumulate)} ksum{ksum_i} v{variant}")
+    lib = _lib.load()
+    r = ops.gemm(a_dev, b_dev, a_trans=bool(a_trans), b_trans=bool(b_trans), bias=bias, act=int(act_i), want_preact=bool(want_preact),
+                 dact_aux=aux, dact=int(dact_i) if has_aux else 0, dropout_p=p_drop, seed=sd, residual=res,
+                 out_dtype=torch.float32 if out_f32 else BF, out=out_buf, accumulate=bool(accumulate), split_k=int(split_k),
+                 variant=int(variant) if variant else None, ksum=(("a" if ksum_i == 1 else "b"), kout) if ksum_i else None)
+    ran = int(lib.dvla_last_gemm_variant())
+    got, pre = r if want_preact else (r, None)
+    tol = TOL_F32 if out_f32 else TOL_FWD
+    # (1) whole output, oracle formulas in fp32 on the device
+    f = lambda t: None if t is None else t.float()
+    ref, pre_ref = oracle(A.float(), Bm.float(), f(bias), f(res), f(aux), torch.arange(M, device=DEV), torch.arange(N, device=DEV), c0)
+    out.append(_dev_metrics(tag + " [whole output, device fp32]", got, ref, tol, round_ref=not out_f32))
+    if want_preact:
+        out.append(_dev_metrics(tag + " preact [whole output, device fp32]", pre, pre_ref, TOL_FWD))
+    del ref, pre_ref
+    # (2) sampled rows x columns against the CPU oracle
+    rd, cd = rows.to(DEV), cols.to(DEV)
+    blk = lambda t: None if t is None else t[rd][:, cd].float().cpu()
+    ref_b, pre_b = oracle(A[rd].float().cpu(), Bm[cd].float().cpu(), None if bias is None else bias[cd].float().cpu(), blk(res),
+                          blk(aux), rows, cols, None if c0 is None else c0[rd][:, cd].cpu())
+    out.append(metrics(tag + f" [{len(rows)} x {len(cols)} sampled block, CPU oracle]", got[rd][:, cd], ref_b, tol, round_ref=not out_f32))
+    if want_preact:
+        out.append(metrics(tag + " preact [sampled block, CPU oracle]", pre[rd][:, cd], pre_b, TOL_FWD))
+    if ksum_i:
+        src = A if ksum_i == 1 else Bm
+        kref = src.float().cpu().double().sum(1).float()
+        out.append(metrics(tag + " k-sums [CPU oracle]", kout, kref, 1e-5, round_ref=False))
+    # (3) what ran
+    allowed = {int(variant), 2} | ({8} if variant in (9, 10) else set())
+    out.append({"name": tag + f": locked configuration ran (dvla_last_gemm_variant = {ran})", "rel_l2": 0.0, "tol": 0.0,
+                "ok": variant == 0 or ran in allowed, "ran": ran})
     return out
 
 

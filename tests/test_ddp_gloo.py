@@ -62,10 +62,13 @@ def _worker(rank, world, port, q, direct):
         loss = ((m(xs) - ys) ** 2).mean()
         loss.backward()
         early[it] = [b["launched"] for b in red.buckets]             # launched during backward, before finish()
+        from dreamvla_amd.ops import GemmTuner
         if any(early[it]):       # collectives outstanding: the GEMMs run under the schedule that needs no co-residency
             assert _schedule() == (8, 0), _schedule()
+            assert GemmTuner.schedule_tag == 1      # ... and the tuner keys its trials / locked choices on that (round-3 ADVICE)
         red.finish()
         assert _schedule() == sched0, (_schedule(), sched0)          # ... and back once every handle has been waited for
+        assert GemmTuner.schedule_tag == 0
         assert red.grads_are_views()
         out[it] = {n: red.grad_of(p).clone() for n, p in m.named_parameters()}
         if direct:      # parameters without a gradient keep p.grad = None; the others were adopted into their bucket slot
@@ -81,6 +84,15 @@ def _worker(rank, world, port, q, direct):
         assert not early[0][i] and early[1][i] and early[2][i], (early, i)
     for i in ub:                                    # step 3: the used set grew -> held until finish(); step 4: re-learned
         assert not early[3][i] and early[4][i], (early, i)
+    # round-3 ADVICE: an iteration that never reaches finish() (backward / the step raised) must not leave the process on the
+    # robust schedule: the next zero_grad() restores it
+    red.zero_grad()
+    ((m(xs) - ys) ** 2).mean().backward()
+    assert any(b["launched"] for b in red.buckets) and _schedule() == (8, 0)
+    for h, _, _ in red._handles:      # (drain what was launched so that the ranks stay in step)
+        h.wait()
+    red.zero_grad()
+    assert _schedule() == sched0 and GemmTuner.schedule_tag == 0
     # gradient accumulation (utils/train_utils.py:588-607): two half-batches under no_sync() + outside == one full pass
     m.use_extra = True          # (the set learned in steps 3-4: every expected gradient arrives, so buckets can go out early)
     red.zero_grad()

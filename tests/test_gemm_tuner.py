@@ -64,14 +64,18 @@ def test_plan_round_trip(tmp_path):
     """save_plan / load_plan carry the locked choices to another process (profiler passes of the tuned step): keys survive JSON
     (tuples of ints and bools), unknown keys take the cost model (variant 0) once the plan is frozen, no trials are started"""
     GemmTuner.reset()
-    key = (20832, 4096, 1024, 0, 1, 1, 2, 0, True, True, False, False, False, False, False)
+    key = (20832, 4096, 1024, 0, 1, 1, 2, 0, True, True, False, False, False, False, False, 0, 0)
+    assert len(key) == GemmTuner.KEY_LEN
+    old_key = (1024, 4096, 20832, 1, 0, 4, 0, 0, False, False, False, False, False, True, False, 2)   # a round-3 plan entry
     GemmTuner.table[key] = 10
+    GemmTuner.table[old_key] = 4
     path = str(tmp_path / "plan.json")
     GemmTuner.save_plan(path)
     GemmTuner.reset()
     try:
         GemmTuner.load_plan(path)
         assert GemmTuner.pick(key) == (10, None)
+        assert GemmTuner.pick(old_key + (0,)) == (4, None)        # pre-schedule-tag keys load as default-schedule keys
         assert GemmTuner.pick((1, 2, 3)) == (0, None) and GemmTuner.trials == {}
     finally:
         GemmTuner.frozen = False
