@@ -249,12 +249,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
       }
-      if (p.has_drop) {
+      if (p.has_drop) {        // one hash per (row, tile), one 24-bit multiply-add per element (common.h)
+        const uint32_t tk = drop_tilekey(rowkey, (uint32_t)kt);
+        const uint32_t dx = drop_rot(tk, (uint32_t)g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)(k0 + acc_row(r, g)));
-          sv[r] = (hsh >= p.drop_thr) ? sv[r] * p.inv_keep : 0.f;
-        }
+        for (int r = 0; r < 16; ++r) sv[r] = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? sv[r] * p.inv_keep : 0.f;
       }
       const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
 #pragma unroll
@@ -487,12 +486,11 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
       }
       }
-      if (p.has_drop) {
+      if (p.has_drop) {        // one hash per (row, tile), one 24-bit multiply-add per element (common.h)
+        const uint32_t tk = drop_tilekey(rowkey, (uint32_t)kt);
+        const uint32_t dx = drop_rot(tk, (uint32_t)g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)(k0 + acc_row(r, g)));
-          sv[r] = (hsh >= p.drop_thr) ? sv[r] * p.inv_keep : 0.f;
-        }
+        for (int r = 0; r < 16; ++r) sv[r] = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? sv[r] * p.inv_keep : 0.f;
       }
       const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
 #pragma unroll
@@ -625,13 +623,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ds[r] = vis_bit(vg, r) ? ds[r] : 0.f;
       }
+      uint32_t tk = 0u, dx = 0u;   // one hash per (row, tile), one 24-bit multiply-add per element (common.h)
+      if (p.has_drop) { tk = drop_tilekey(rowkey, (uint32_t)kt); dx = drop_rot(tk, (uint32_t)g); }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float dp = dpacc[r];
-        if (p.has_drop) {
-          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)(k0 + acc_row(r, g)));
-          dp = (hsh >= p.drop_thr) ? dp * p.inv_keep : 0.f;
-        }
+        if (p.has_drop) dp = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? dp * p.inv_keep : 0.f;
         ds[r] = ds[r] * (dp - dlt) * p.scale;
       }
       const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
@@ -753,9 +750,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
       for (int r = 0; r < 16; ++r) {
         float dp = dpacc[r];
         float pdrop = pr[r];
-        if (p.has_drop) {
+        if (p.has_drop) {      // (fallback kernel: the tile key is hashed per element here; the ring kernel keeps a table)
           const uint32_t rk = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + q0 + acc_row(r, g)));
-          const bool keep = drop_hash_rk(rk, (uint32_t)key) >= p.drop_thr;
+          const uint32_t tk = drop_tilekey(rk, (uint32_t)ktw);
+          const bool keep = drop_elem(drop_rot(tk, (uint32_t)((l31 >> 2) & 1)), tk, DVLA_DROP_C((l31 & 3) + 4 * (l31 >> 3))) >= p.drop_thr;
           dp = keep ? dp * p.inv_keep : 0.f;
           pdrop = keep ? pdrop * p.inv_keep : 0.f;
         }
@@ -998,13 +996,12 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
         for (int r = 0; r < 16; ++r) ds[r] = vis_bit(vg, r) ? ds[r] : 0.f;
       }
+      uint32_t tk = 0u, dx = 0u;   // one hash per (row, tile), one 24-bit multiply-add per element (common.h)
+      if (p.has_drop) { tk = drop_tilekey(rowkey, (uint32_t)kt); dx = drop_rot(tk, (uint32_t)g); }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float dp = dpacc[r];
-        if (p.has_drop) {
-          const uint32_t hsh = drop_hash_rk(rowkey, (uint32_t)(k0 + acc_row(r, g)));
-          dp = (hsh >= p.drop_thr) ? dp * p.inv_keep : 0.f;
-        }
+        if (p.has_drop) dp = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? dp * p.inv_keep : 0.f;
         ds[r] = ds[r] * (dp - dlt) * p.scale;
       }
       const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
@@ -1022,9 +1019,11 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 }
 
 // dynamic LDS of the dK/dV ring kernel: ring | tile flags [nqt] | visibility words [128 keys][nqt] | lse2 [32 nqt] | delta [32 nqt]
-// | dropout row keys [32 nqt] (one hash per query row and workgroup instead of one per score element)
-__host__ __device__ inline size_t fa_dkv_smem_bytes(int nqt, bool has_bits) {
-  return (size_t)FA_RING + fa_pad16(nqt) + (has_bits ? (size_t)128 * nqt * 4 : 0) + (size_t)3 * 32 * nqt * 4;
+// | dropout tile keys [4 key tiles of the workgroup][32 nqt] (common.h: hash32(rowkey(query) + key tile * golden), hashed once per
+// workgroup; an element then costs a rotate + a 24-bit multiply-add instead of a hash)
+__host__ __device__ inline size_t fa_dkv_smem_bytes(int nqt, bool has_bits, bool has_drop) {
+  return (size_t)FA_RING + fa_pad16(nqt) + (has_bits ? (size_t)128 * nqt * 4 : 0) + (size_t)2 * 32 * nqt * 4 +
+         (has_drop ? (size_t)4 * 32 * nqt * 4 : 0);
 }
 
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs p) {
@@ -1049,7 +1048,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
   uint32_t* bits = reinterpret_cast<uint32_t*>(smem + FA_RING + fa_pad16(p.nqt));
   float* lse2s = reinterpret_cast<float*>(smem + FA_RING + fa_pad16(p.nqt) + (has_bits ? (size_t)128 * p.nqt * 4 : 0));
   float* dlts = lse2s + 32 * p.nqt;
-  uint32_t* rks = reinterpret_cast<uint32_t*>(dlts + 32 * p.nqt);
+  uint32_t* tks = reinterpret_cast<uint32_t*>(dlts + 32 * p.nqt);      // [4][32 nqt], only with dropout
 
   // requested first, waited for after the first Q / dO tiles are on their way (see the forward kernel)
   bf16x8 kf[4], vf[4];
@@ -1075,8 +1074,16 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
   for (int i = t; i < 32 * p.nqt; i += AT_THREADS) {
     lse2s[i] = i < p.Lq ? p.lse[bh_row0 + i] * LOG2E : INFINITY;   // q >= Lq: exp2(s - inf) = 0
     dlts[i] = i < p.Lq ? p.delta[bh_row0 + i] : 0.f;
-    if (p.has_drop) rks[i] = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + i));
+    if (p.has_drop) {
+      const uint32_t rk = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + i));
+#pragma unroll
+      for (int w = 0; w < 4; ++w) tks[w * 32 * p.nqt + i] = drop_tilekey(rk, (uint32_t)(kt0 + w));
+    }
   }
+  // this lane's key j = l31 of its tile: multiplier and operand rotation of the element generator (common.h)
+  const uint32_t drop_cj = DVLA_DROP_C((l31 & 3) + 4 * (l31 >> 3));
+  const uint32_t drop_half = (uint32_t)((l31 >> 2) & 1);
+  const uint32_t* tkw = tks + wave * 32 * p.nqt;
   f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
   __syncthreads();
 
@@ -1152,8 +1159,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         uint32_t rk[4] = {0u, 0u, 0u, 0u};
-        if (p.has_drop) {      // row keys of queries q0 + 8 rq + 4 g .. + 3 (= acc_row(4 rq + e, g)), hashed once per workgroup
-          const uint4 a = *reinterpret_cast<const uint4*>(rks + q0 + 8 * rq + 4 * g);
+        if (p.has_drop) {      // tile keys of queries q0 + 8 rq + 4 g .. + 3 (= acc_row(4 rq + e, g)) for this wave's key tile
+          const uint4 a = *reinterpret_cast<const uint4*>(tkw + q0 + 8 * rq + 4 * g);
           rk[0] = a.x; rk[1] = a.y; rk[2] = a.z; rk[3] = a.w;
         }
 #pragma unroll
@@ -1162,7 +1169,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
           float dp = dpacc[r];
           float pdrop = pr[r];
           if (p.has_drop) {
-            const bool keep = drop_hash_rk(rk[e], (uint32_t)key) >= p.drop_thr;
+            const bool keep = drop_elem(drop_rot(rk[e], drop_half), rk[e], drop_cj) >= p.drop_thr;
             dp = keep ? dp * p.inv_keep : 0.f;
             pdrop = keep ? pdrop * p.inv_keep : 0.f;
           }
@@ -1190,6 +1197,359 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
   }
 }
 
+
+// ====================================================================================================
+// backward for SHORT dense sequences, one pass per (batch, head)  (round 4)
+//
+//   The dream-head decoders run B = 448 x 16 heads of L = 205 / 265 tokens (dreamvla_model.py:806-904): 7-9 key tiles per
+//   sequence.  Under the two ring kernels every 128-token workgroup pays its prologue (fragment loads, tables, ring fill) and its
+//   store tail for 7 tile iterations of work, K / V / Q / dO are each read twice from HBM (2.0 GB at B = 448 where 1.5 GB is
+//   needed) and the matrix pipe is 10-15 % busy (profiles/r03_attn_perf.jsonl: 829 us for L = 205).  Here a PERSISTENT workgroup
+//   of 8 waves takes whole (batch, head) items:
+//     * Q, dO (region A) and K, V (region B) of the item arrive by LDS-DMA ONCE, as 32-row tiles in the swizzled image of the
+//       ring kernels (one image serves row fragments and hardware-transposed fragments);
+//     * phase X (the dQ kernel's tile loop): wave j owns query tile j -- Q / dO fragments from region A, delta = rowsum(dO * O)
+//       on its way (written with log2-domain lse to an LDS table), K / V tiles streamed from region B, dQ^T in registers;
+//     * phase Y (the dK/dV kernel's tile loop): wave j owns key tile j -- K / V fragments from region B, Q / dO tiles streamed
+//       from region A, dK^T / dV^T in registers;
+//     * no barrier inside a phase (everything a wave reads is resident and read-only): the two waves of a SIMD overlap each
+//       other's MFMA and softmax VALU freely;
+//     * region B is re-filled with the NEXT item's K / V as soon as every wave has taken its K / V fragments (phase Y streams
+//       only region A); region A tile by tile behind phase Y's walk (one barrier per query tile in that phase keeps the
+//       waves in step): the next item's loads run under this item's second phase.
+//   Same arithmetic, same tile order and the same two rounding points as the ring kernels (oracle/torch_ref.py::attention_bf16).
+//   LDS: 4 operands x nt tiles x 4 KiB + 2 x 32 nt floats = 16 640 nt bytes: 116 KiB at L = 205 (nt = 7), 150 KiB at L = 265.
+//   Sequences of more than 8 tiles give wave j the tiles j and j + 8.
+// ====================================================================================================
+constexpr int SB_WAVES = 8, SB_THREADS = 64 * SB_WAVES, SB_MAX_TILES = 9;
+__host__ __device__ inline size_t sb_smem_bytes(int nt) { return (size_t)nt * (4 * FA_TILE + 2 * 32 * 4); }
+
+__global__ __launch_bounds__(SB_THREADS) void attn_bwd_short_kernel(AttnKArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int L = p.Lq;
+  const int nt = p.nqt;                       // Lq == Lk: query tiles == key tiles
+  const int rounds = (nt + SB_WAVES - 1) / SB_WAVES;
+  const float scale_log2 = p.scale * LOG2E;
+
+  char* const regA = smem;                                   // Q tiles [nt] | dO tiles [nt]
+  char* const regB = smem + (size_t)2 * nt * FA_TILE;        // K tiles [nt] | V tiles [nt]
+  float* const lse2s = reinterpret_cast<float*>(smem + (size_t)4 * nt * FA_TILE);
+  float* const dlts = lse2s + 32 * nt;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t offA = 0u, offB = (uint32_t)(2 * nt * FA_TILE);
+
+  // LDS-DMA: wave w copies rows 8 (w & 3) .. + 7 of the tiles t = (w >> 2), (w >> 2) + 2, ...: lane -> (row, LDS slot lane % 8)
+  const int rl = 8 * (wave & 3) + (lane >> 3);
+  const int oct = (lane & 7) ^ fa_sw(rl);
+  auto issue_op = [&](const bf16_t* base, uint32_t stride_bytes, uint32_t region) {
+    for (int tt = wave >> 2; tt < nt; tt += 2) {
+      int row = tt * 32 + rl;
+      row = row < L ? row : L - 1;
+      const uint32_t dst = smem_base + region + (uint32_t)(tt * FA_TILE + (wave & 3) * 1024);
+      fa_glds16(base, (uint32_t)row * stride_bytes + (uint32_t)(oct * 16), __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
+  const uint32_t qst2 = (uint32_t)p.qst * 2u, kst2 = (uint32_t)p.kst * 2u, vst2 = (uint32_t)p.vst * 2u, dst2 = (uint32_t)p.dst * 2u;
+  auto issue_A = [&](int item) {
+    const int b = item / p.H, h = item - b * p.H;
+    issue_op(p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh, qst2, offA);
+    issue_op(p.dout + (int64_t)b * p.dsb + (int64_t)h * p.dsh, dst2, offA + (uint32_t)(nt * FA_TILE));
+  };
+  // one tile of region A (Q and dO) for `item`: issued by the four waves whose tile parity it is
+  auto issue_A_tile = [&](int item, int tt) {
+    const int b = item / p.H, h = item - b * p.H;
+    int row = tt * 32 + rl;
+    row = row < L ? row : L - 1;
+    const uint32_t dst = smem_base + offA + (uint32_t)(tt * FA_TILE + (wave & 3) * 1024);
+    fa_glds16(p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh, (uint32_t)row * qst2 + (uint32_t)(oct * 16), __builtin_amdgcn_readfirstlane(dst));
+    fa_glds16(p.dout + (int64_t)b * p.dsb + (int64_t)h * p.dsh, (uint32_t)row * dst2 + (uint32_t)(oct * 16),
+              __builtin_amdgcn_readfirstlane(dst + (uint32_t)(nt * FA_TILE)));
+  };
+  auto issue_B = [&](int item) {
+    const int b = item / p.H, h = item - b * p.H;
+    issue_op(p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh, kst2, offB);
+    issue_op(p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh, vst2, offB + (uint32_t)(nt * FA_TILE));
+  };
+
+  const int n_items = p.B * p.H;
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  issue_A(item);
+  issue_B(item);
+
+  // rows of O (for delta) and lse of this wave's first query tile: requested one item AHEAD, at the start of the previous item's
+  // phase Y -- at the top of the item loop the compiler waits for the previous stores before it may reuse their registers
+  // (vmcnt(0): the DMA included), so a request placed there would start its round trip only after the DMA has landed
+  uint4 ofr[4];
+  float lse_in = 0.f;
+  auto prefetch_o = [&](int it_) {
+    const int b_ = it_ / p.H, h_ = it_ - b_ * p.H;
+    const bf16_t* ob_ = p.o + (int64_t)b_ * p.osb + (int64_t)h_ * p.osh;
+    const int q = wave * 32 + l31;
+    const bool ok = wave < nt && q < L;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ofr[s] = load16(ob_ + (int64_t)q * p.ost + 16 * s + 8 * g, ok);
+    lse_in = ok ? p.lse[(b_ * p.H + h_) * L + q] : 0.f;
+  };
+  prefetch_o(item);
+
+  for (; item < n_items; item += gridDim.x) {
+    const int b = item / p.H, h = item - b * p.H;
+    const int next = item + (int)gridDim.x;
+    const int row0 = (b * p.H + h) * L;
+    const bf16_t* ob = p.o + (int64_t)b * p.osb + (int64_t)h * p.osh;
+
+    fa_wait_vmcnt<0>();            // this wave's share of regions A and B has landed (and its O / lse rows)
+    // (tell the compiler so on EVERY path: a wave without a tile never uses them, and registers with a load the compiler
+    // believes pending cost a vmcnt(0) -- which would also drain the DMA just issued -- where the next prefetch overwrites them)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { fa_settle(ofr[s].x); fa_settle(ofr[s].y); fa_settle(ofr[s].z); fa_settle(ofr[s].w); }
+    fa_settle(lse_in);
+    __syncthreads();               // ... and everybody else's
+
+    // ---------------- phase X: dQ of query tile j, delta and lse (log2 domain) of its rows into the LDS table ----------------
+    for (int r = 0; r < rounds; ++r) {
+      const int j = wave + SB_WAVES * r;
+      if (j >= nt) break;
+      const int q = j * 32 + l31;
+      const bool q_ok = q < L;
+      if (r > 0) {                 // a second tile of this wave (sequences of more than 8 tiles): its O / lse rows now
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ofr[s] = load16(ob + (int64_t)q * p.ost + 16 * s + 8 * g, q_ok);
+        lse_in = q_ok ? p.lse[row0 + q] : 0.f;
+      }
+      const char* qs = regA + (size_t)j * FA_TILE;
+      const char* dos = regA + (size_t)(nt + j) * FA_TILE;
+      bf16x8 qf[4], dof[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { qf[s] = fa_frag_rm(qs, l31, s, g); dof[s] = fa_frag_rm(dos, l31, s, g); }
+      float acc = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const uint4 dv = *reinterpret_cast<const uint4*>(&dof[s]);
+        const uint32_t ow[4] = {ofr[s].x, ofr[s].y, ofr[s].z, ofr[s].w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc += bf2f((bf16_t)(dw[i] & 0xffff)) * bf2f((bf16_t)(ow[i] & 0xffff));
+          acc += bf2f((bf16_t)(dw[i] >> 16)) * bf2f((bf16_t)(ow[i] >> 16));
+        }
+      }
+      acc += __shfl_xor(acc, 32, 64);
+      const float lse2 = q_ok ? lse_in * LOG2E : INFINITY;       // q >= L: exp2(s - inf) = 0
+      const float dlt = q_ok ? acc : 0.f;
+      if (g == 0) { lse2s[j * 32 + l31] = lse2; dlts[j * 32 + l31] = dlt; }
+      f32x16 dqacc[2] = {zero16(), zero16()};
+      for (int kt = 0; kt < nt; ++kt) {
+        const char* ks = regB + (size_t)kt * FA_TILE;
+        const char* vs = regB + (size_t)(nt + kt) * FA_TILE;
+        f32x16 sacc = zero16(), dpacc = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(vs, l31, s, g), dof[s], dpacc, 0, 0, 0);
+        }
+        const int k0 = kt * 32;
+        float ds[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) ds[rr] = fast_exp2(fmaf(sacc[rr], scale_log2, -lse2));
+        if (k0 + 32 > L) {           // the ragged last key tile (wave-uniform)
+          const uint32_t vg = low_mask(L - k0) >> (4 * g);
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) ds[rr] = vis_bit(vg, rr) ? ds[rr] : 0.f;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) ds[rr] = ds[rr] * (dpacc[rr] - dlt) * p.scale;
+        const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(ks, db, 0, lane), f0, dqacc[db], 0, 0, 0);
+          dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(ks, db, 1, lane), f1, dqacc[db], 0, 0, 0);
+        }
+      }
+      if (q_ok) store_token(p.dq + (int64_t)b * p.dqsb + (int64_t)q * p.dqst + (int64_t)h * p.dqsh, dqacc, 1.0f, g, (p.st16 & 2) != 0);
+    }
+    __syncthreads();               // the lse / delta table is complete
+
+    // ---------------- phase Y: dK, dV of key tile j ----------------
+    for (int r = 0; r < rounds; ++r) {
+      const int j = wave + SB_WAVES * r;
+      const bool active = j < nt;
+      const int key = j * 32 + l31;
+      const bool key_ok = active && key < L;
+      bf16x8 kf[4], vf[4];
+      if (active) {
+        const char* ks = regB + (size_t)j * FA_TILE;
+        const char* vs = regB + (size_t)(nt + j) * FA_TILE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { kf[s] = fa_frag_rm(ks, l31, s, g); vf[s] = fa_frag_rm(vs, l31, s, g); }
+      }
+      if (r == rounds - 1) {
+        __syncthreads();           // every wave holds the K / V fragments of its last tile: region B is free
+        // (the prefetch first: the compiler guards the registers it overwrites against the dQ stores that last read them with
+        // a vmcnt wait, which must not sit behind the DMA issue -- it would drain it)
+        if (next < n_items) { prefetch_o(next); issue_B(next); }
+      }
+      // In the LAST round every wave (with or without a tile) walks the query tiles in step: after the barrier that ends
+      // tile qt nobody reads it again, and the next item's Q / dO tile qt is requested into its place -- region A is re-filled
+      // under this phase instead of after it (the load used to be exposed at the top of every item: ~5 k of ~50 k cycles).
+      const bool last_round = r == rounds - 1;
+      if (!active && !last_round) continue;
+      f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
+      for (int qt = 0; qt < nt; ++qt) {
+        const char* qs = regA + (size_t)qt * FA_TILE;
+        const char* dos = regA + (size_t)(nt + qt) * FA_TILE;
+        if (qt > 0 && last_round) {
+          __syncthreads();         // every wave is done with tile qt - 1
+          if (next < n_items && (wave >> 2) == ((qt - 1) & 1)) issue_A_tile(next, qt - 1);
+        }
+        if (!active) continue;
+        f32x16 sacc = zero16(), dpacc = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(qs, l31, s, g), kf[s], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(dos, l31, s, g), vf[s], dpacc, 0, 0, 0);
+        }
+        const int q0 = qt * 32;
+        float pr[16], ds[16];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const float4 a = *reinterpret_cast<const float4*>(lse2s + q0 + 8 * rq + 4 * g);
+          const float4 c = *reinterpret_cast<const float4*>(dlts + q0 + 8 * rq + 4 * g);
+          const float l4[4] = {a.x, a.y, a.z, a.w}, d4[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int rr = 4 * rq + e;
+            float pv = fast_exp2(fmaf(sacc[rr], scale_log2, -l4[e]));
+            pv = key_ok ? pv : 0.f;
+            pr[rr] = pv;
+            ds[rr] = pv * (dpacc[rr] - d4[e]) * p.scale;
+          }
+        }
+        const bf16x8 pf0 = pack_frag(pr), pf1 = pack_frag(pr + 8);
+        const bf16x8 sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(dos, db, 0, lane), pf0, dvacc[db], 0, 0, 0);
+          dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(dos, db, 1, lane), pf1, dvacc[db], 0, 0, 0);
+          dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(qs, db, 0, lane), sf0, dkacc[db], 0, 0, 0);
+          dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(qs, db, 1, lane), sf1, dkacc[db], 0, 0, 0);
+        }
+      }
+      if (key_ok) {
+        store_token(p.dk + (int64_t)b * p.dksb + (int64_t)key * p.dkst + (int64_t)h * p.dksh, dkacc, 1.0f, g, (p.st16 & 4) != 0);
+        store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key * p.dvst + (int64_t)h * p.dvsh, dvacc, 1.0f, g, (p.st16 & 8) != 0);
+      }
+    }
+    __syncthreads();               // every wave is done with the last query tile and with the table
+    if (next < n_items && (wave >> 2) == ((nt - 1) & 1)) issue_A_tile(next, nt - 1);
+  }
+}
+
+
+// ====================================================================================================
+// forward for SHORT dense sequences (same shapes as attn_bwd_short_kernel: the ViT's L = 197, the decoders' 205 / 265): a persistent
+// workgroup of 8 waves takes whole (batch, head) items -- K and V arrive ONCE by LDS-DMA (the ring kernel reads them once per
+// 128-query block: twice at L = 205, three times at 265), wave j owns query tile j, no barrier inside the tile loop.  K / V are
+// single-buffered (8 KiB per tile: 56-72 KiB) so that TWO workgroups share a CU and fill each other's load phases.
+// Same arithmetic and tile order as attn_fwd_ring_kernel (integer running maximum in the log2 domain).
+// ====================================================================================================
+__host__ __device__ inline size_t sf_smem_bytes(int nt) { return (size_t)nt * 2 * FA_TILE; }
+
+__global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_short_kernel(AttnKArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int L = p.Lq;
+  const int nt = p.nqt;
+  const int rounds = (nt + SB_WAVES - 1) / SB_WAVES;
+  const float scale_log2 = p.scale * LOG2E;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int rl = 8 * (wave & 3) + (lane >> 3);
+  const int oct = (lane & 7) ^ fa_sw(rl);
+  const uint32_t kst2 = (uint32_t)p.kst * 2u, vst2 = (uint32_t)p.vst * 2u;
+  auto issue_op = [&](const bf16_t* base, uint32_t stride_bytes, uint32_t region) {
+    for (int tt = wave >> 2; tt < nt; tt += 2) {
+      int row = tt * 32 + rl;
+      row = row < L ? row : L - 1;
+      const uint32_t dst = smem_base + region + (uint32_t)(tt * FA_TILE + (wave & 3) * 1024);
+      fa_glds16(base, (uint32_t)row * stride_bytes + (uint32_t)(oct * 16), __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
+  const int n_items = p.B * p.H;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / p.H, h = item - b * p.H;
+    const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
+    issue_op(p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh, kst2, 0u);
+    issue_op(p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh, vst2, (uint32_t)(nt * FA_TILE));
+    for (int r = 0; r < rounds; ++r) {
+      const int j = wave + SB_WAVES * r;
+      const bool active = j < nt;
+      const int q = j * 32 + l31;
+      const bool q_ok = active && q < L;
+      bf16x8 qf[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const uint4 u = load16(qb + (int64_t)q * p.qst + 16 * s + 8 * g, q_ok);
+        qf[s] = *reinterpret_cast<const bf16x8*>(&u);
+      }
+      if (r == 0) {
+        fa_wait_vmcnt<0>();        // this wave's share of K / V (and its Q rows)
+        __syncthreads();
+      }
+      if (!active) continue;
+      float m_run = -INFINITY, l_run = 0.f;
+      f32x16 oacc[2] = {zero16(), zero16()};
+      for (int kt = 0; kt < nt; ++kt) {
+        const char* ks = smem + (size_t)kt * FA_TILE;
+        const char* vs = smem + (size_t)(nt + kt) * FA_TILE;
+        f32x16 sacc = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
+        const int k0 = kt * 32;
+        float sv[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) sv[rr] = sacc[rr];
+        if (k0 + 32 > L) {
+          const uint32_t vg = low_mask(L - k0) >> (4 * g);
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) sv[rr] = vis_bit(vg, rr) ? sv[rr] : -INFINITY;
+        }
+        float mt = sv[0];
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) mt = fmaxf(mt, sv[rr]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, ceilf(mt * scale_log2));     // integer running maximum: see attn_fwd_ring_kernel
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m_run - m_safe);
+        float rs = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) { sv[rr] = fast_exp2(fmaf(sv[rr], scale_log2, -m_safe)); rs += sv[rr]; }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) { oacc[0][rr] *= alpha; oacc[1][rr] *= alpha; }
+        }
+        const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(vs, db, 0, lane), pf0, oacc[db], 0, 0, 0);
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(vs, db, 1, lane), pf1, oacc[db], 0, 0, 0);
+        }
+      }
+      if (q_ok) {
+        const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
+        store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g, (p.st16 & 1) != 0);
+        if (p.lse && g == 0) p.lse[(b * p.H + h) * L + q] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
+      }
+    }
+    __syncthreads();               // every wave is done with K / V before the next item's DMA lands
+  }
+}
+
 }  // namespace
 
 // The ring kernels address K / V / Q / dO rows as a 32-bit byte offset from the (batch, head) base: every row they can touch
@@ -1204,6 +1564,18 @@ static bool attn_force_staged() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("DVLA_ATTN_STAGED"); v = (e && e[0] == '1') ? 1 : 0; }
   return v == 1;
+}
+
+// DVLA_ATTN_SHORT=0 keeps short dense sequences on the two ring kernels (A/B measurements; read per launch)
+static bool attn_short_enabled() { const char* e = getenv("DVLA_ATTN_SHORT"); return !(e && e[0] == '0'); }
+static bool attn_short_fwd_enabled() { const char* e = getenv("DVLA_ATTN_SHORT_FWD"); return !(e && e[0] == '0'); }
+static int attn_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return cus;
 }
 
 // DVLA_ATTN_DBG=<bits>: ablation builds of the forward ring kernel (timing only, results garbage by design) -- compiled only
@@ -1247,6 +1619,23 @@ extern "C" int dvla_attn_fwd(const dvla_attn_params* q, void* stream_) {
   const dim3 ring_grid = fwd_ring_grid(a);
   const size_t smem = fa_smem_bytes(a.nkt, a.Lk, a.key_index != nullptr, a.tile_map != nullptr && a.bits_q != nullptr);
   const bool span_kv = attn_span32(a.Lk, a.kst, a.key_index != nullptr) && attn_span32(a.Lk, a.vst, a.key_index != nullptr);
+  if (attn_short_fwd_enabled() && !a.tile_map && !a.key_index && !a.has_drop && a.Lq == a.Lk && a.nqt > 2 && a.nqt <= SB_MAX_TILES &&
+      span_kv && !attn_force_staged()) {
+    // short dense sequences (ViT L = 197, decoders 205 / 265): whole (batch, head) items per persistent workgroup, K / V read once
+    const size_t sm = sf_smem_bytes(a.nqt);
+    static uint64_t attr_done = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!(attr_done & (1ull << dev))) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_short_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr_done |= 1ull << dev;
+    }
+    const int64_t items = (int64_t)a.B * a.H;
+    int64_t wgs = (int64_t)attn_num_cus() * 2;
+    if (wgs > items) wgs = items;
+    hipLaunchKernelGGL(attn_fwd_short_kernel, dim3((unsigned)wgs), dim3(SB_THREADS), sm, stream, a);
+    return dvla_check_launch();
+  }
   if (smem <= 64 * 1024 && span_kv && !attn_force_staged())
 #ifndef DVLA_ATTN_ABLATION
     hipLaunchKernelGGL(attn_fwd_ring_kernel<0>, ring_grid, block, smem, stream, a);
@@ -1286,8 +1675,30 @@ extern "C" int dvla_attn_bwd(const dvla_attn_params* q, void* stream_) {
     return DVLA_ERR_UNSUPPORTED;
   const int64_t nrows = (int64_t)a.B * a.H * a.Lq;
   dim3 block(AT_THREADS);
+  const bool span_all = attn_span32(a.Lk, a.kst, false) && attn_span32(a.Lk, a.vst, false) && attn_span32(a.Lq, a.qst, false) &&
+                        attn_span32(a.Lq, a.dst, false);
+  if (attn_short_enabled() && !a.tile_map && !a.key_index && !a.has_drop && a.Lq == a.Lk && a.nqt <= SB_MAX_TILES && span_all &&
+      !attn_force_staged()) {
+    // short dense sequences (the dream-head decoders, L = 205 / 265): one pass per (batch, head), operands read once
+    const size_t smem = sb_smem_bytes(a.nqt);
+    static uint64_t attr_done = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!(attr_done & (1ull << dev))) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_short_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done |= 1ull << dev;
+    }
+    int per_cu = (int)((size_t)(160 * 1024) / smem);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2048 / SB_THREADS) per_cu = 2048 / SB_THREADS;
+    const int64_t items = (int64_t)a.B * a.H;
+    int64_t wgs = (int64_t)attn_num_cus() * per_cu;
+    if (wgs > items) wgs = items;
+    hipLaunchKernelGGL(attn_bwd_short_kernel, dim3((unsigned)wgs), dim3(SB_THREADS), smem, stream, a);
+    return dvla_check_launch();
+  }
   const size_t smem_dq = fa_smem_bytes(a.nkt, a.Lk, a.key_index != nullptr, a.tile_map != nullptr && a.bits_q != nullptr);
-  const size_t smem_dkv = fa_dkv_smem_bytes(a.nqt, a.tile_map != nullptr && a.bits_k != nullptr);
+  const size_t smem_dkv = fa_dkv_smem_bytes(a.nqt, a.tile_map != nullptr && a.bits_k != nullptr, a.has_drop != 0);
   const dim3 grid_dq((unsigned)((a.nqt + 3) / 4), (unsigned)a.H, (unsigned)a.B);
   const dim3 grid_dkv((unsigned)((a.nkt + 3) / 4), (unsigned)a.H, (unsigned)a.B);
   const bool span_kv = attn_span32(a.Lk, a.kst, a.key_index != nullptr) && attn_span32(a.Lk, a.vst, a.key_index != nullptr);

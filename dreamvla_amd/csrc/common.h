@@ -195,6 +195,26 @@ __device__ __forceinline__ uint32_t drop_rowkey(uint32_t seed_lo, uint32_t seed_
 __device__ __forceinline__ uint32_t drop_hash_rk(uint32_t rowkey, uint32_t idx_lo) {
   return hash32(rowkey + idx_lo * 0x9E3779B9u);
 }
+// Attention-probability dropout (round 4).  One hash per score ELEMENT (two 32-bit multiplies + three xor-shifts, ~10 VALU
+// issues) made the dropout section 160 of the ~450 instructions of a 32 x 32 score tile in each of the three trunk kernels
+// -- more than the softmax itself.  Now: one strong hash per (score row, 32-key tile),
+//     tk = hash32(rowkey(row) + tile * 0x9E3779B9),
+// and per element j = key % 32 of that tile ONE 24-bit multiply-add (v_mad_u32_u24, full rate):
+//     v = (x[23:0] * DROP_C[(j & 3) + 4 (j >> 3)])[31:0] + tk,   x = ((j >> 2) & 1) ? rotr(tk, 12) : tk,   keep <=> v >= thr.
+// ((j >> 2) & 1 is the lane half that owns key j in the transposed score layout, (j & 3) + 4 (j >> 3) its accumulator register:
+// in the forward / dQ kernels the 16 constants are immediates and x is formed once per tile.)  Keep rate and pairwise / triple
+// statistics: tests/test_attention_oracle.py; oracle/torch_ref.py::attn_drop_keep_mask restates it bit for bit.
+__device__ __forceinline__ uint32_t drop_tilekey(uint32_t rowkey, uint32_t tile) { return hash32(rowkey + tile * 0x9E3779B9u); }
+#define DVLA_DROP_C(r)                                                                                                          \
+  ((r) == 0 ? 0xb60881u : (r) == 1 ? 0x554da5u : (r) == 2 ? 0x6dada9u : (r) == 3 ? 0x9e0fffu : (r) == 4 ? 0xd1517fu :            \
+   (r) == 5 ? 0x966d65u : (r) == 6 ? 0x764223u : (r) == 7 ? 0xb59e1du : (r) == 8 ? 0x80cd71u : (r) == 9 ? 0x769d3bu :            \
+   (r) == 10 ? 0xba1a8fu : (r) == 11 ? 0xf85869u : (r) == 12 ? 0xf94c5bu : (r) == 13 ? 0x905af7u : (r) == 14 ? 0xec5577u : 0xaa3cd1u)
+__device__ __forceinline__ uint32_t drop_rot(uint32_t tk, uint32_t half) {      // half = (j >> 2) & 1
+  return __builtin_amdgcn_alignbit(tk, tk, 12u * half);
+}
+__device__ __forceinline__ uint32_t drop_elem(uint32_t x, uint32_t tk, uint32_t c) {
+  return (x & 0xffffffu) * c + tk;        // the compiler forms v_mad_u32_u24 (24-bit operands: c < 2^24)
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

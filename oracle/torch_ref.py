@@ -66,6 +66,25 @@ def drop_keep_mask(seed, idx_hi, idx_lo, p):
     return h >= thr
 
 
+_DROP_C = (0xb60881, 0x554da5, 0x6dada9, 0x9e0fff, 0xd1517f, 0x966d65, 0x764223, 0xb59e1d,
+           0x80cd71, 0x769d3b, 0xba1a8f, 0xf85869, 0xf94c5b, 0x905af7, 0xec5577, 0xaa3cd1)
+
+
+def attn_drop_keep_mask(seed, idx_hi, idx_lo, p):
+    """the attention kernels' dropout generator (csrc/common.h, round 4): one hash per (score row, 32-key tile), one 24-bit
+    multiply-add per element.  idx_hi = score row id, idx_lo = (compacted) key index; int64 tensors (broadcastable)."""
+    seed_lo, seed_hi = int(seed[0]) & _M32, int(seed[1]) & _M32
+    rowkey = (_hash32((idx_hi & _M32) ^ seed_hi) + seed_lo) & _M32
+    tile, j = idx_lo >> 5, idx_lo & 31
+    tk = _hash32((rowkey + ((tile & _M32) * 0x9E3779B9 & _M32)) & _M32)
+    half = (j >> 2) & 1
+    x = torch.where(half == 1, ((tk >> 12) | (tk << 20)) & _M32, tk)
+    c = torch.tensor(_DROP_C, dtype=torch.int64, device=idx_lo.device)[(j & 3) + 4 * (j >> 3)]
+    v = ((x & 0xFFFFFF) * c + tk) & _M32
+    thr = min(int(p * 4294967296.0), 4294967295)
+    return v >= thr
+
+
 def dropout_elementwise(x2, p, seed):
     """(rows, cols) tensor: idx_hi = row, idx_lo = col."""
     rows, cols = x2.shape
@@ -112,7 +131,7 @@ def attention(q, k, v, scale=None, mask=None, drop=None, drop_cols=None, batch_i
         pd, seed = drop
         rows = _drop_rows(B, H, Lq, batch_index)
         cols = (torch.arange(Lk, dtype=torch.int64) if drop_cols is None else drop_cols.to(torch.int64)).view(1, 1, 1, Lk)
-        keep = drop_keep_mask(seed, rows, cols, pd)
+        keep = attn_drop_keep_mask(seed, rows, cols, pd)
         p = torch.where(keep, p / (1.0 - pd), torch.zeros_like(p))
     return torch.matmul(p, v)
 
@@ -158,7 +177,7 @@ def attention_bf16(q, k, v, scale=None, mask=None, drop=None, drop_cols=None, do
         pd, seed = drop
         rows = _drop_rows(B, H, Lq, batch_index)
         cols = (torch.arange(Lk, dtype=torch.int64) if drop_cols is None else drop_cols.to(torch.int64)).view(1, 1, 1, Lk)
-        keep = drop_keep_mask(seed, rows, cols, pd)
+        keep = attn_drop_keep_mask(seed, rows, cols, pd)
         inv_keep = 1.0 / (1.0 - pd)
     pdrop = p if keep is None else torch.where(keep, p * inv_keep, torch.zeros_like(p))
     some = l > 0                    # a row that sees no key: o = 0, lse = +inf (the kernel's convention; the reference never builds one)

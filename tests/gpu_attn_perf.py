@@ -40,6 +40,22 @@ def main():
         tb = timeit(g, iters=10)
         r = {"B": B, "H": H, "L": L, "mask": mk, "visible": round(vis, 3), "fwd_us": tf * 1e6, "bwd_us": tb * 1e6,
              "fwd_TF_visible": fl / tf / 1e12, "bwd_TF_visible": 2.5 * fl / tb / 1e12}
+        el = B * H * L * 64 * 2                                   # bytes of one (B, L, H, 64) bf16 operand
+        r["fwd_TBps_algorithmic"] = 4 * el / tf / 1e12            # q, k, v read + o written
+        r["bwd_TBps_algorithmic"] = 8 * el / tb / 1e12            # q, k, v, o, do read + dq, dk, dv written
+        if mk == "dense" and L <= 288:
+            # same-process A/B against the ring kernels (round 3's path for these shapes): the switches are read per launch
+            os.environ["DVLA_ATTN_SHORT_FWD"] = "0"
+            os.environ["DVLA_ATTN_SHORT"] = "0"
+            r["fwd_us_ring_kernels"] = timeit(f, iters=10) * 1e6
+            r["bwd_us_ring_kernels"] = timeit(g, iters=10) * 1e6
+            del os.environ["DVLA_ATTN_SHORT_FWD"], os.environ["DVLA_ATTN_SHORT"]
+        if mk == "trunk":
+            fd = lambda: ops.attn_fwd_raw(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], scale=0.125, mask_tables=mt, dropout_p=0.1, seed=(3, 4))
+            gd = lambda: ops.attn_bwd_raw(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], o, lse, do, d5[:, :, 0], d5[:, :, 1], d5[:, :, 2],
+                                          scale=0.125, mask_tables=mt, dropout_p=0.1, seed=(3, 4))
+            r["fwd_us_dropout"] = timeit(fd, iters=10) * 1e6
+            r["bwd_us_dropout"] = timeit(gd, iters=10) * 1e6
         res.append(r)
         print(json.dumps(r), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -70,3 +70,32 @@ def test_fully_masked_rows_and_ragged_keys():
     o, lse, dq, dk, dv = R.attention_bf16(q, k, v, mask=mask, dout=do)
     assert torch.isfinite(dq).all() and torch.isfinite(dk).all() and torch.isfinite(dv).all()
     assert float(dq[0, 0, 2].abs().max()) == 0.0
+
+
+def test_attention_dropout_generator_statistics():
+    """oracle/torch_ref.py::attn_drop_keep_mask (= csrc/common.h drop_tilekey / drop_rot / drop_elem, round 4: one hash per
+    (score row, 32-key tile) and one 24-bit multiply-add per element instead of one hash per element): the keep rate is 1 - p per
+    column and per row, and the 32 elements that share a tile key are pairwise uncorrelated (the multipliers are fixed odd 24-bit
+    constants, half of the elements use the key rotated by 12 bits)."""
+    import torch
+    from oracle import torch_ref as R
+    n_rows, n_cols = 20000, 384
+    rows = torch.arange(n_rows, dtype=torch.int64)[:, None]
+    cols = torch.arange(n_cols, dtype=torch.int64)[None, :]
+    for p in (0.1, 0.5):
+        keep = R.attn_drop_keep_mask((77, 4242), rows, cols, p)
+        d = (~keep).double()
+        assert abs(float(d.mean()) - p) < 2e-3
+        assert float((d.mean(0) - p).abs().max()) < 5.0 * (p * (1 - p) / n_rows) ** 0.5          # every column (= element slot)
+        assert abs(float(d.mean(1).std()) - (p * (1 - p) / n_cols) ** 0.5) < 1e-3               # rows scatter binomially
+        t = (d - d.mean(0, keepdim=True)).view(n_rows, n_cols // 32, 32)
+        cm = torch.einsum("ntj,ntk->jk", t, t) / (n_rows * (n_cols // 32)) / (p * (1 - p))
+        off = cm - torch.diag(torch.diag(cm))
+        assert float(off.abs().max()) < 5.0 / (n_rows * (n_cols // 32)) ** 0.5, float(off.abs().max())
+        # triples inside one accumulator quad (consecutive multipliers of the same key)
+        a, b = d[:, 0::32] * d[:, 1::32], d[:, 2::32]
+        assert abs(float((a * b).sum() / a.sum()) - p) < (0.03 if p < 0.5 else 0.01)
+    # a different seed / row block gives a different mask
+    k1 = R.attn_drop_keep_mask((77, 4242), rows[:64], cols, 0.1)
+    k2 = R.attn_drop_keep_mask((78, 4242), rows[:64], cols, 0.1)
+    assert float((k1 != k2).double().mean()) > 0.1
