@@ -1218,6 +1218,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
 //       only region A); region A tile by tile behind phase Y's walk (one barrier per query tile in that phase keeps the
 //       waves in step): the next item's loads run under this item's second phase.
 //   Same arithmetic, same tile order and the same two rounding points as the ring kernels (oracle/torch_ref.py::attention_bf16).
+//   (The same idea for the MASKED trunk -- K / V of the 378 compacted keys resident, the 21 query tiles handed out heaviest-first
+//   from a ticket counter, no barrier inside an item -- was built, passed every parity case and was NOT faster than the ring kernels:
+//   forward 81.2 vs 77.1 us, backward 284 vs 271 (profiles/r04_attn_resident_experiment.jsonl); it is not in the tree.  With two
+//   items per CU and 6 visible key tiles per query tile these kernels sit at the per-score instruction cost, not at barriers.)
 //   LDS: 4 operands x nt tiles x 4 KiB + 2 x 32 nt floats = 16 640 nt bytes: 116 KiB at L = 205 (nt = 7), 150 KiB at L = 265.
 //   Sequences of more than 8 tiles give wave j the tiles j and j + 8.
 // ====================================================================================================
@@ -1550,6 +1554,7 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   }
 }
 
+
 }  // namespace
 
 // The ring kernels address K / V / Q / dO rows as a 32-bit byte offset from the (batch, head) base: every row they can touch
@@ -1716,8 +1721,20 @@ extern "C" int dvla_attn_bwd(const dvla_attn_params* q, void* stream_) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid_dq, block, 0, stream, a);
   rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;
-  if (smem_dkv <= 64 * 1024 && span_q && !attn_force_staged())
+  // (two workgroups of this kernel share a CU -- 186 VGPRs -- so a workgroup may take 80 KiB of its 160: the dropout tile keys
+  // of a 930-token window are 15 KiB on top of 56)
+  if (smem_dkv <= 80 * 1024 && span_q && !attn_force_staged()) {
+    if (smem_dkv > 64 * 1024) {
+      static uint64_t attr_done = 0;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+      if (!(attr_done & (1ull << dev))) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done |= 1ull << dev;
+      }
+    }
     hipLaunchKernelGGL(attn_bwd_dkv_ring_kernel, grid_dkv, block, smem_dkv, stream, a);
+  }
   else
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid_dkv, block, 0, stream, a);
   return dvla_check_launch();
