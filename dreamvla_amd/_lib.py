@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVLA_LIB") or os.path.join(_HERE, "libdvla_hip.so")
 
 DT_BF16, DT_F32 = 0, 1
-ABI_VERSION = 4          # DVLA_ABI_VERSION of include/dvla.h
+ABI_VERSION = 5          # DVLA_ABI_VERSION of include/dvla.h
 ACT = {"none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "gelu_new": 2, "relu": 3, "silu": 4,
        "quick_gelu": 5, "tanh": 6, "sigmoid": 7}
 
@@ -101,6 +101,7 @@ SYMBOLS = {
     "dvla_dropout": (C.c_int, [_P, _P, _I64, _I64, _F, _U32, _U32, _P]),
     "dvla_act_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _F, _U32, _U32, _P]),
     "dvla_act_fwd": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "dvla_ddim_cfg_step": (C.c_int, [_P, _I64, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
     "dvla_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_cast_bf16_to_f32": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),

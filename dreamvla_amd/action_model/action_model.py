@@ -58,6 +58,46 @@ class ActionModel(nn.Module):
                                                diffusion_steps=self.diffusion_steps, sigma_small=True, learn_sigma=False)
         return self.ddim_diffusion
 
+    @torch.no_grad()
+    def sample_ddim_cfg(self, cond, noise, cfg_scale):
+        """The evaluation sampler of models/dreamvla_model.py:935-987 -- `ddim_sample_loop(net.forward_with_cfg, ..., eta=0)` over
+        [cond ; uncondition] -- with the work that does not depend on the sampler step taken out of the loop and the per-step
+        tensor algebra in one kernel.  Same arithmetic, same rounding points:
+          * the condition embedding z_embedder([cond ; uncondition]) is computed once (the reference recomputes it in each of
+            the 10 steps from the same input);
+          * every row of a step has the same timestep, and the 10 timesteps are known: t_embedder runs once on the 10 of them;
+          * both halves of the sampler state are the same tensor (forward_with_cfg feeds [half ; half] and returns
+            [eps ; eps], action_model/models.py:253-268): the state is kept once, x_embedder runs on bs rows;
+          * guidance + DDIM update: ops.ddim_cfg_step (one launch instead of ~20 elementwise ATen launches on (bs, 3, 7)).
+        cond: (bs, T, token) conditions; noise: (bs, T, C) start noise.  Returns the samples (bs, T, C), float32."""
+        import numpy as np
+        from .. import ops
+        net, dd = self.net, self.ddim_diffusion
+        bs, T = noise.shape[0], noise.shape[1]
+        wdt = torch.bfloat16
+        unc = net.z_embedder.uncondition.to(cond.dtype).unsqueeze(0).expand(bs, T, -1)
+        z_emb = net.z_embedder(torch.cat([cond, unc], 0).to(wdt), False)               # (2 bs, T, H)
+        steps = list(range(dd.num_timesteps))[::-1]
+        cache = self.__dict__.setdefault("_fast_tables", {})
+        key = (str(cond.device), dd.num_timesteps)
+        if key not in cache:        # built outside any stream capture (the engine's eager warm-up calls come first)
+            cache[key] = torch.tensor([dd.timestep_map[i] for i in steps], device=cond.device, dtype=torch.long)
+        t_emb = net.t_embedder(cache[key])                                               # (steps, H): one call
+        pos = net.positional_embedding.to(wdt)
+        f32 = np.float32
+        x = noise.float().contiguous()
+        for j, i in enumerate(steps):
+            xe = net.x_embedder(x.to(wdt))                                               # (bs, T, H)
+            tok = torch.cat((z_emb + t_emb[j], torch.cat((xe, xe), 0)), dim=1) + pos     # (2 bs, 2 T, H)
+            for blk in net.blocks:
+                tok = blk(tok)
+            out = net.final_layer(tok)[:, T:, :]                                         # (2 bs, T, C)
+            # the coefficients as `_extract_into_tensor` gathers them: float64 tables read as float32, sqrt taken in float32
+            acp_prev = f32(dd.alphas_cumprod_prev[i])
+            x = ops.ddim_cfg_step(out, x, cfg_scale, f32(dd.sqrt_recip_alphas_cumprod[i]), f32(dd.sqrt_recipm1_alphas_cumprod[i]),
+                                  np.sqrt(acp_prev), np.sqrt(f32(1.0) - acp_prev))
+        return x
+
 
 class ActionModelFM(nn.Module):
     """Flow-matching variant (`--use_fm`; /root/reference/models/action_model/action_model.py:86-170): same DiT, 10 "diffusion

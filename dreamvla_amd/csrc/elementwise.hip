@@ -222,6 +222,36 @@ extern "C" int dvla_act_bwd(const void* dy, const void* preact, void* dz, int64_
   return dvla_check_launch();
 }
 
+// classifier-free guidance + one eta = 0 DDIM update (dvla.h): every intermediate is rounded where the tensor expression it
+// replaces rounds it (bf16 for the guidance arithmetic on the model's bf16 output, fp32 -- without contraction -- for the update)
+__global__ void ddim_cfg_step_kernel(const bf16_t* __restrict__ mo, int64_t sample_stride, const float* __restrict__ x,
+                                     float* __restrict__ xn, int64_t bs, int64_t per, float cfg, float a, float b, float sp, float sq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs * per) return;
+  const int64_t s = i / per, j = i - s * per;
+  const float cond = bf2f(mo[s * sample_stride + j]), unc = bf2f(mo[(s + bs) * sample_stride + j]);
+  const float d = bf2f(f2bf(__fsub_rn(cond, unc)));
+  const float sd = bf2f(f2bf(__fmul_rn(cfg, d)));
+  const float e = bf2f(f2bf(__fadd_rn(unc, sd)));
+  const float ax = __fmul_rn(a, x[i]);
+  const float px = __fsub_rn(ax, __fmul_rn(b, e));
+  const float e2 = __fdiv_rn(__fsub_rn(ax, px), b);
+  xn[i] = __fadd_rn(__fmul_rn(px, sp), __fmul_rn(sq, e2));
+}
+
+extern "C" int dvla_ddim_cfg_step(const void* model_out, int64_t sample_stride, const float* x, float* x_next, int64_t bs,
+                                  int64_t per_sample, float cfg_scale, float a, float b, float sqrt_acp_prev, float sqrt_1m_acp_prev,
+                                  void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!model_out || !x || !x_next || bs < 0 || per_sample <= 0 || sample_stride < per_sample || !(b != 0.f)) return DVLA_ERR_ARG;
+  if (bs == 0) return DVLA_OK;
+  const int64_t n = bs * per_sample;
+  hipLaunchKernelGGL(ddim_cfg_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(model_out), sample_stride, x, x_next, bs, per_sample, cfg_scale, a, b,
+                     sqrt_acp_prev, sqrt_1m_acp_prev);
+  return dvla_check_launch();
+}
+
 extern "C" int dvla_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!x || !y || n < 0) return DVLA_ERR_ARG;

@@ -4,6 +4,7 @@
 
 #include <mutex>
 #include "gemm_phase.h"
+#include "gemm_skinny.h"
 
 namespace dvla_gemm {
 #define DVLA_EXTERN_REG(CF, AT, BT, DBG) extern template void launch_one<CF, AT, BT, DBG>(const GemmKArgs&, int, hipStream_t);
@@ -332,8 +333,10 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     // for 128^2 / 256x128 BK64 / 256^2 / phase (it was 5.7 / 5.9 / 18.7 with the LDS-patch epilogue of round 1), the slope per
     // stage 0.58 / 0.49 / 0.85 / 0.775.  The online tuner (dreamvla_amd.ops.GemmTuner) refines this per problem key in-model.
     // The register-staged kernel is the fallback for shapes the DMA kernels do not take (ragged N, unaligned operands, tiny).
-    int choice = 0;   // 0 = register-staged S (always valid), 1 = ring L, 3 = ring S, 4 = ring M64, 5 = phase
-    if (variant == 0) {
+    int choice = 0;   // 0 = register-staged S (always valid), 1 = ring L, 3 = ring S, 4 = ring M64, 5 = phase, 11 = skinny
+    if ((variant == 0 || variant == 11) && skinny_ok(a, combo, split_k)) {
+      choice = 11;      // few rows (evaluation-time shapes): one 32 x 32 tile per workgroup, K split over its four waves
+    } else if (variant == 0) {
       const double ns = (double)(a.k_per_split < a.K ? a.k_per_split : a.K) / 32.0;
       const int slots = num_cus();
       double best = 1e30;
@@ -374,6 +377,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       case 5: launch_phase(a, combo, split_k, stream); break;
       case 6: launch_phase(a, combo, split_k, stream, 1); break;   // falls back to the plain schedule when stream-K does not apply
       case 7: launch_phase(a, combo, split_k, stream, 2); break;
+      case 11: launch_skinny(a, stream); break;
       case 81: case 83: case 84: case 85: case 86: case 89:   // ablations (plain bf16 epilogue only): 81 no MFMA, 83 no MFMA + no reads, 84 no DMA, 85 no epilogue, 86 raw stores only
         set_tiles<PCfg::BM, PCfg::BN, PCfg::GH>(a);
         if (epi_class(a) != EPI_P0) return DVLA_ERR_UNSUPPORTED;
@@ -386,7 +390,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
         break;
       default: launch_cfg<CfgS>(a, combo, split_k, stream); break;
     }
-    g_last_variant = choice == 1 ? 4 : choice == 3 ? 6 : choice == 4 ? 7 : choice == 5 ? 8
+    g_last_variant = choice == 11 ? 11 : choice == 1 ? 4 : choice == 3 ? 6 : choice == 4 ? 7 : choice == 5 ? 8
                    : (choice == 6 || choice == 7) ? (a.sk_tiles > 0 ? (choice == 6 ? 9 : 10) : 8) : choice >= 80 ? choice : 2;
   }
   int rc = dvla_check_launch();

@@ -408,7 +408,14 @@ class DreamVLA(nn.Module):
         ev.synchronize()
         return bool(flag.item())
 
-    def encode_frames(self, image_primary, image_wrist, state, text_token):
+    def encode_text(self, text_token):
+        """(B, S, 77) int64 -> the text token of every frame (B, S, 1, H): frozen CLIP text tower + projector (643-653)"""
+        B, S = text_token.shape[:2]
+        with torch.no_grad():
+            text_feature = self.clip_model.encode_text(text_token.flatten(0, 1))
+        return self.text_projector(text_feature.to(torch.bfloat16)).view(B, S, -1, self.hidden_dim)
+
+    def encode_frames(self, image_primary, image_wrist, state, text_token, text_embedding=None):
         """Conditioning tokens of every frame, as the list [text (B,S,1,H), state (B,S,1,H), primary image (B,S,nq,H),
         wrist image (B,S,nq,H), cls primary (B,S,1,H), cls wrist (B,S,1,H)]  (dreamvla_model.py:643-737).  Each frame
         is encoded independently of every other frame and of its position in the window (the window position embedding
@@ -418,7 +425,9 @@ class DreamVLA(nn.Module):
         H = self.hidden_dim
         wdt = torch.bfloat16     # compute dtype: fp32 parameters are masters, the kernels run on bf16 shadows (ops.shadow)
 
-        share_pending = self._text_share_begin(text_token)     # verdict read below, after the vision path is enqueued
+        # `text_embedding` (B, S, 1, H), if given, is used instead of running the text tower on `text_token` (the rollout engine
+        # keeps it across control steps while the instruction does not change)
+        share_pending = None if text_embedding is not None else self._text_share_begin(text_token)   # verdict read below
 
         # state: arm Linear(6,H) | gripper one-hot(2) -> Linear(2,H) -> cat -> Linear(2H,H)   (656-664)
         st = state.flatten(0, 1).to(wdt)
@@ -459,7 +468,9 @@ class DreamVLA(nn.Module):
         # The training loop feeds the SAME instruction to every frame of a window (`text_tokens.unsqueeze(1).repeat(1,
         # window_size, 1)`, utils/train_utils.py:124): when all S rows of every sample are equal the 12-layer tower runs on B
         # sequences instead of B*S and the result is broadcast.  Decided per forward, exactly (self._text_share_begin/_end).
-        if self._text_share_end(share_pending):
+        if text_embedding is not None:
+            pass
+        elif self._text_share_end(share_pending):
             with torch.no_grad():
                 text_feature = self.clip_model.encode_text(text_token[:, 0].contiguous())
             text_embedding = self.text_projector(text_feature.to(wdt)).view(B, 1, -1, H).expand(B, S, -1, H)
@@ -613,11 +624,16 @@ class DreamVLA(nn.Module):
                 z = torch.cat([cond, uncondition], 0)
                 if self.action_model.ddim_diffusion is None:
                     self.action_model.create_ddim(ddim_step=10)
-                samples = self.action_model.ddim_diffusion.ddim_sample_loop(
-                    self.action_model.net.forward_with_cfg, noise.shape, noise, clip_denoised=False,
-                    model_kwargs=dict(z=z, cfg_scale=cfg_scale), progress=False, device=cond.device, eta=0.0,
-                    start_noise=None if test_noise is None else noise)
-                samples, _ = samples.chunk(2, dim=0)
+                if getattr(self, "fast_sampler", True) and hasattr(self.action_model, "sample_ddim_cfg"):
+                    # the same sampler with the step-invariant work hoisted and the per-step algebra in one kernel
+                    # (ActionModel.sample_ddim_cfg; `model.fast_sampler = False` runs the operation-by-operation loop below)
+                    samples = self.action_model.sample_ddim_cfg(cond, noise[:bs].float(), cfg_scale)
+                else:
+                    samples = self.action_model.ddim_diffusion.ddim_sample_loop(
+                        self.action_model.net.forward_with_cfg, noise.shape, noise, clip_denoised=False,
+                        model_kwargs=dict(z=z, cfg_scale=cfg_scale), progress=False, device=cond.device, eta=0.0,
+                        start_noise=None if test_noise is None else noise)
+                    samples, _ = samples.chunk(2, dim=0)
                 arm_pred_action, gripper_pred_action = samples.unsqueeze(0)[..., :6], samples.unsqueeze(0)[..., 6:]
 
         return (arm_pred_action, gripper_pred_action, image_pred, arm_pred_state, gripper_pred_state, loss_arm_action,

@@ -444,6 +444,23 @@ def act_fwd_raw(x, act):
     return y
 
 
+def ddim_cfg_step(model_out, x, cfg_scale, a, b, sqrt_acp_prev, sqrt_1m_acp_prev):
+    """classifier-free guidance + one eta = 0 DDIM update in one launch (dvla_ddim_cfg_step).  model_out: bf16 (2 bs, T, C) -- a
+    view whose samples are contiguous (e.g. `full[:, T:, :]` of a contiguous (2 bs, 2 T, C) tensor); x: fp32 (bs, T, C)."""
+    lib = _lib.load()
+    _req(model_out, "ddim_cfg_step.model_out")
+    bs, per = x.shape[0], x[0].numel()
+    if model_out.shape[0] != 2 * bs or model_out[0].numel() != per or model_out.dtype != BF16 or x.dtype != torch.float32:
+        raise ValueError("ddim_cfg_step: model_out (2 bs, ...) bf16 and x (bs, ...) fp32 of matching sample size")
+    if not model_out[0].is_contiguous() or (bs > 0 and model_out.stride(0) < per) or not x.is_contiguous():
+        raise ValueError("ddim_cfg_step: samples must be contiguous")
+    out = torch.empty_like(x)
+    check(lib.dvla_ddim_cfg_step(model_out.data_ptr(), int(model_out.stride(0)), x.data_ptr(), out.data_ptr(), bs, per,
+                                 float(cfg_scale), float(a), float(b), float(sqrt_acp_prev), float(sqrt_1m_acp_prev), _stream()),
+          "dvla_ddim_cfg_step")
+    return out
+
+
 def add_raw(a, b, period=0):
     lib = _lib.load()
     a = a.contiguous(); b = b.contiguous()

@@ -8,6 +8,7 @@ frames through the ViT and the resampler although only one of them is new -- and
 frame.  This engine keeps that contract (same queue / padding / selection semantics, same DreamVLA weights, batched
 over independent episodes) and removes the redundant work:
 
+  * the instruction's text token is computed once per instruction (`text_embedding`), not once per frame and step;
   * per-frame token cache: `DreamVLA.encode_frames` output (text | state | 2 x 16 resampled image tokens | 2 cls tokens
     = 36 x H per frame) of every frame seen so far lives in a (B, S, 36, H) ring in HBM; a control step encodes ONLY
     the newest frame (1/S of the ViT + resampler + CLIP work), shifts the ring and decodes;
@@ -74,6 +75,8 @@ class RolloutEngine:
         self.count = torch.zeros(self.B, dtype=torch.long)          # host: frames seen per episode (capped at S)
         self.use_graph = bool(use_graph)
         self.warmup_decodes = int(warmup_decodes)
+        self._text_ref = self._text_tok = self._text_emb = None
+        self.text_encodes = 0                                             # how often the text tower actually ran
         self.needs_noise = bool(getattr(m, "use_dit_head", False))       # the MLP action head samples nothing
         self._no_noise = torch.zeros(1, device=self.device)
         self._decode_g = _Graphed(self._decode_eager, warmup_decodes) if self.use_graph else None
@@ -87,18 +90,35 @@ class RolloutEngine:
         else:
             self.count[torch.as_tensor(mask, dtype=torch.bool).cpu()] = 0
 
-    def _encode_eager(self, image_primary, image_wrist, state, text_token):
+    def _encode_eager(self, image_primary, image_wrist, state, text_emb):
         m = self.model
-        parts = m.encode_frames(image_primary.unsqueeze(1), image_wrist.unsqueeze(1), state.unsqueeze(1),
-                                text_token.unsqueeze(1))
+        parts = m.encode_frames(image_primary.unsqueeze(1), image_wrist.unsqueeze(1), state.unsqueeze(1), None,
+                                text_embedding=text_emb.view(text_emb.shape[0], 1, 1, -1))
         return (torch.cat(parts, dim=2)[:, 0],)
 
     @torch.no_grad()
+    def text_embedding(self, text_token):
+        """(B, 77) int64 -> (B, H) text tokens.  The instruction of an episode does not change between control steps, and the
+        frozen CLIP tower (12 layers, ~110 launches) gives the same embedding for the same tokens: it is kept and re-used while
+        the tokens are the same tensor at the same version, or compare equal (the reference re-encodes the text of all
+        `history_len` frames every step, utils/eval_utils_calvin.py:127-134)."""
+        ref = self._text_ref
+        if ref is not None and ref[0] is text_token and ref[1] == text_token._version:
+            return self._text_emb
+        tok = text_token.to(self.device)
+        if self._text_tok is None or tok.shape != self._text_tok.shape or not bool(torch.equal(tok, self._text_tok)):
+            self._text_tok = tok.clone()
+            self._text_emb = self.model.encode_text(tok.unsqueeze(1))[:, 0, 0].contiguous()
+            self.text_encodes += 1
+        self._text_ref = (text_token, text_token._version)
+        return self._text_emb
+
+    @torch.no_grad()
     def encode_newest(self, image_primary, image_wrist, state, text_token):
-        """(B,3,224,224) x 2, (B,7|8), (B,77) int64 -> (B, 36, H) tokens of the newest frame (CLIP text tower, state
-        encoders, ViT on both views, resampler, projectors: ~330 launches, one hipGraph when use_graph)"""
+        """(B,3,224,224) x 2, (B,7|8), (B,77) int64 -> (B, 36, H) tokens of the newest frame (state encoders, ViT on both
+        views, resampler, projectors: one hipGraph when use_graph; the text token comes from `text_embedding`)"""
         f = self._encode_g if self.use_graph else self._encode_eager
-        return f(image_primary.contiguous(), image_wrist.contiguous(), state.contiguous(), text_token.contiguous())[0]
+        return f(image_primary.contiguous(), image_wrist.contiguous(), state.contiguous(), self.text_embedding(text_token))[0]
 
     def _push(self, new_tok):
         """queue semantics of ModelWrapper.step: append; while an episode has seen k < S frames its window is
@@ -153,6 +173,9 @@ class RolloutEngine:
         new_tok = self.encode_newest(image_primary.to(self.device, dt), image_wrist.to(self.device, dt),
                                      state.to(self.device, dt), text_token.to(self.device))
         self._push(new_tok)
+        # the wrapper conditions EVERY frame of the window on the current instruction (eval_utils_calvin.py:127-134 repeat the
+        # text over the window), so the text token (slot 0 of a frame's 36) is not history: all S frames carry today's embedding
+        self.tokens[:, :, 0] = self._text_emb.to(self.tokens.dtype).unsqueeze(1)
         if not self.needs_noise:
             noise = self._no_noise
         elif noise is None:

@@ -37,8 +37,8 @@ extern "C" {
 
 /* ABI revision of this header; dreamvla_amd/_lib.py refuses a library that reports another one (a stale prebuilt .so then fails
  * with a clear message instead of a missing-symbol error).  3 = round 3 (dvla_last_gemm_variant, variant 10, ...); 4 = k-sums on the
- * weight-gradient GEMM (ksum_* fields of dvla_gemm_params). */
-#define DVLA_ABI_VERSION 4
+ * weight-gradient GEMM (ksum_* fields of dvla_gemm_params); 5 = dvla_ddim_cfg_step, GEMM configuration 11. */
+#define DVLA_ABI_VERSION 5
 int dvla_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -81,6 +81,8 @@ typedef struct dvla_gemm_params {
 int64_t dvla_gemm_ksum_partial_rows(int32_t split_k);
 int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
 /* tuning hook: 0 = automatic kernel choice by the built-in cost model (default; env DVLA_GEMM_VARIANT overrides at load);
+ * 11 = the few-rows kernel (M <= 128, both operands k-contiguous, K % 16 == 0: one 32 x 32 tile of C per workgroup, K split over
+ * its four waves, fragments straight from global memory -- the evaluation-time shapes; what 0 picks for such problems);
  * 2 = register-staged 128x128 kernel; 4 / 6 / 7 = LDS-DMA ring kernels 256x256 / 128x128 / 256x128 (K-tile 64); 8 = phase
  * kernel (256x256, K-tile 64, two wave groups in ping-pong); 9 = the phase kernel under the stream-K hybrid schedule (whole
  * rounds one tile per CU; the last, partial rounds as equal K-iteration ranges per group of 16 CUs, the two halves of a
@@ -207,6 +209,15 @@ int dvla_act_bwd(const void* dy, const void* preact, void* dz, int64_t rows, int
                  float dropout_p, uint32_t seed_lo, uint32_t seed_hi, void* stream);
 /* y = act(x) */
 int dvla_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream);
+/* One step of the action sampler's algebra, evaluation path (models/dreamvla_model.py:935-987): classifier-free guidance
+ * (action_model/models.py:253-268: eps = uncond + s (cond - uncond), evaluated in the model dtype like the tensor expression
+ * it replaces: three bf16 roundings) followed by the eta = 0 DDIM update (gaussian_diffusion.py:522-569):
+ *     pred_x0 = a x - b eps;   eps' = (a x - pred_x0) / b;   x_next = pred_x0 sqrt_acp_prev + sqrt_1m_acp_prev eps'
+ * in fp32, operation by operation (no contraction) -- ~20 elementwise ATen launches on (bs, 3, 7) tensors become one.
+ * model_out: bf16, sample i of the guided half at model_out + i * sample_stride, of the unguided half at
+ * model_out + (bs + i) * sample_stride, per_sample contiguous values each; x, x_next: fp32 (bs, per_sample) contiguous. */
+int dvla_ddim_cfg_step(const void* model_out, int64_t sample_stride, const float* x, float* x_next, int64_t bs, int64_t per_sample,
+                       float cfg_scale, float a, float b, float sqrt_acp_prev, float sqrt_1m_acp_prev, void* stream);
 /* dst(bf16) = src(fp32) / dst(fp32) = src(bf16) */
 int dvla_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dvla_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

@@ -123,6 +123,18 @@ def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", re
     return out
 
 
+def check_gemm_skinny(forced=True, **kw):
+    """the few-rows kernel (csrc/gemm_skinny.h: M <= 128, k-contiguous operands -- the shapes of a single-episode control step):
+    the same oracle as every other configuration, plus the assertion that it is what ran (forced = variant 11; not forced = the
+    library's own choice for such a problem must be this kernel)"""
+    from dreamvla_amd import _lib
+    out = check_gemm(variant=11 if forced else None, **kw)
+    ran = int(_lib.load().dvla_last_gemm_variant())
+    out.append({"name": f"gemm skinny M{kw['M']} N{kw['N']} K{kw['K']}: few-rows kernel ran (dvla_last_gemm_variant = {ran})", "rel_l2": 0.0,
+                "tol": 0.0, "ok": ran == 11})
+    return out
+
+
 def check_gemm_ksum(M, N, K, which, split_k=1, variant=None, a_trans=True, b_trans=True, out_f32=False, ksum_f32=False, seed=0):
     """dvla_gemm_bf16 with ksum_operand: the k-sums of operand `which` ("a": sum_k A(i, k), "b": sum_k B(j, k)) next to the
     product -- the bias gradient of a weight-gradient GEMM (utils/train_utils.py:599-608: autograd's dz.sum(0)).  Oracle: fp32
@@ -713,6 +725,19 @@ def all_checks(quick=False):
         (check_gemm, dict(M=100, N=1024, K=6, bias=True)),
         (check_gemm, dict(M=100, N=64, K=7, b_trans=True, bias=True)),
         (check_gemm, dict(M=257, N=129, K=33)),
+        # the DiT head's GEMMs at one episode (2 x 10 x 6 = 120 rows, models/action_model/models.py:128-160), the timestep MLP,
+        # the output layer (N = 7), the CLIP tower at 77 rows, one-row problems, ragged N / M, fp32 output, pre-activation store
+        (check_gemm_skinny, dict(M=120, N=2304, K=768, bias=True)),
+        (check_gemm_skinny, dict(M=120, N=768, K=768, bias=True, residual=True, forced=False)),
+        (check_gemm_skinny, dict(M=120, N=3072, K=768, bias=True, act="gelu_tanh", forced=False)),
+        (check_gemm_skinny, dict(M=120, N=768, K=3072, bias=True, residual=True, forced=False)),
+        (check_gemm_skinny, dict(M=20, N=768, K=256, bias=True, act="silu", forced=False)),
+        (check_gemm_skinny, dict(M=120, N=7, K=768, bias=True, forced=False)),
+        (check_gemm_skinny, dict(M=77, N=2048, K=512, bias=True, act="quick_gelu")),
+        (check_gemm_skinny, dict(M=1, N=1024, K=512, bias=True, forced=False)),
+        (check_gemm_skinny, dict(M=128, N=1000, K=80, act="relu", out_f32=True)),
+        (check_gemm_skinny, dict(M=100, N=40, K=48, bias=True, act="gelu_erf", want_preact=True)),
+        (check_gemm_skinny, dict(M=33, N=96, K=4096, bias=True, dropout_p=0.1, residual=True)),
         (check_gemm, dict(M=128, N=128, K=2048, a_trans=True, b_trans=True, split_k=4)),
         (check_gemm, dict(M=200, N=72, K=1000, a_trans=True, b_trans=True, split_k=3)),
         (check_gemm, dict(M=256, N=128, K=64, dropout_p=0.1, residual=True)),

@@ -15,10 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(Bs=(1, 64), naive=True, eager_engine=True, steps=20):
-    """-> {"config": ..., "rows": [...]}; bench.py's `rollout` leg calls it with naive=False, eager_engine=False (graph only)"""
+def build_model():
+    """the evaluation model of BASELINE configs[4]: S = 10 (scripts/CALVIN_ABC_D/DreamVLA/eval.sh), head set C weights, DiT head"""
     from dreamvla_amd.dreamvla_model import DreamVLA
-    from dreamvla_amd.rollout import RolloutEngine
     S, BF, dev = 10, torch.bfloat16, "cuda"
     cfg = dict(finetune_type="calvin", sequence_length=S, num_resampler_query=16, num_obs_token_per_image=9,
                action_pred_steps=3, transformer_layers=24, hidden_dim=1024, transformer_heads=16, phase="finetune",
@@ -27,6 +26,14 @@ def run(Bs=(1, 64), naive=True, eager_engine=True, steps=20):
     m = DreamVLA(clip_device="cpu", vit_checkpoint_path=None, **cfg).bfloat16().to(dev)
     m._init_model_type()
     m.eval()
+    return m, S
+
+
+def run(Bs=(1, 64), naive=True, eager_engine=True, steps=20):
+    """-> {"config": ..., "rows": [...]}; bench.py's `rollout` leg calls it with naive=False, eager_engine=False (graph only)"""
+    from dreamvla_amd.rollout import RolloutEngine
+    BF, dev = torch.bfloat16, "cuda"
+    m, S = build_model()
     out = {"config": "eval step, S=10, DiT head DDIM-10 + CFG, head set C weights, bf16, 1x MI355X", "rows": []}
     for B in Bs:
         g = torch.Generator().manual_seed(B)

@@ -315,6 +315,22 @@ def hip_full_model_checks(name):
             # sampled actions (10 sampler steps feed the denoiser its own output): tolerance from the REAL reference's own bf16
             # runs of the same loop on the same start noise (oracle/make_golden.py `amp`: ref_test_bf16_deviation)
             res += compare_outputs(out, fx["test"], TOL_MODEL, f"hip.{name}.test", fx=fx, records=("ref_test_bf16_deviation",))
+            if hasattr(m.action_model, "sample_ddim_cfg"):
+                # the operation-by-operation sampler loop (forward_with_cfg inside ddim_sample_loop, as the reference writes it)
+                # against the same golden samples, and against the default path above (step-invariant work hoisted, guidance +
+                # DDIM update in one kernel: ActionModel.sample_ddim_cfg) -- same arithmetic, same rounding points
+                m.fast_sampler = False
+                torch.randn = fake_randn
+                try:
+                    out_slow = m(*args, mode="test")
+                finally:
+                    torch.randn = real
+                    m.fast_sampler = True
+                res += compare_outputs(out_slow, fx["test"], TOL_MODEL, f"hip.{name}.test(op-by-op sampler)", fx=fx,
+                                       records=("ref_test_bf16_deviation",))
+                for nm, a, b_ in (("arm", out[0], out_slow[0]), ("gripper", out[1], out_slow[1])):
+                    r = rel_l2(a, b_)
+                    res.append({"name": f"hip.{name}.test fast sampler vs op-by-op loop: {nm}", "rel_l2": r, "tol": 2e-3, "ok": r <= 2e-3})
     return res
 
 

@@ -66,6 +66,11 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7):
             mask = torch.tensor([False, True, False])
             eng.reset(mask)
             oracles[1] = WindowOracle(S)
+        if t == 3:                                  # a new instruction for episode 2 (a NEW tensor: the engine must notice and
+            text = text.clone()                     # re-encode; every frame of the window is conditioned on it, as in the wrapper)
+            text[2, 1:20] = torch.randint(1, 49000, (19,), generator=g)
+        if t == 4:
+            text = text.clone()                     # same tokens in a new tensor object: compared, not re-encoded
         fr = dict(ip=torch.randn(B, 3, 224, 224, generator=g).to(BF), iw=torch.randn(B, 3, 224, 224, generator=g).to(BF),
                   st=torch.cat([torch.rand(B, 6, generator=g), (torch.rand(B, 1, generator=g) > 0.5).float()], -1).to(BF))
         wins, picks = zip(*[o.push({k: v[b] for k, v in fr.items()}) for b, o in enumerate(oracles)])
@@ -93,6 +98,8 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7):
         res.append({"name": tag + ".gripper_all_positions", "rel_l2": r3, "tol": tol, "ok": r3 <= tol})
         if use_graph and t >= 2:                   # two eager warm-up decodes, then the capture: later steps are replays
             res.append({"name": tag + ".graph_replayed", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
+    res.append({"name": f"rollout.{head}.graph{int(use_graph)}: text tower ran once per instruction ({eng.text_encodes} of {steps} steps)",
+                "rel_l2": float(eng.text_encodes), "tol": 2.0, "ok": eng.text_encodes == 2})
     return res
 
 
