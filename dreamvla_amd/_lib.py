@@ -37,6 +37,7 @@ class GemmParams(C.Structure):
         ("accumulate", C.c_int32),
         ("split_k", C.c_int32), ("workspace", C.c_void_p),
         ("ksum", C.c_void_p), ("ksum_dtype", C.c_int32), ("ksum_operand", C.c_int32), ("ksum_workspace", C.c_void_p),
+        ("a_layernorm", C.c_int32), ("a_ln_eps", C.c_float),
     ]
 
 

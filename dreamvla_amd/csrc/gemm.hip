@@ -210,6 +210,10 @@ inline int streamk_tiles(int64_t tiles, int cus, bool full = false) {
 void launch_phase(GemmKArgs& a, int combo, int split_k, hipStream_t stream, int stream_k = 0) {
   set_tiles<PCfg::BM, PCfg::BN, PCfg::GH>(a);
   a.sk_tiles = 0;
+  if (a.K % PCfg::BKS != 0) {       // partial last K-tile (phase_tail): its own instantiation, plain schedule
+    launch_phase_one<true, true, EPI_F32, 128>(a, split_k, stream);
+    return;
+  }
   if (stream_k && split_k == 1) {
     const int groups = num_cus();
     const int r = streamk_tiles((int64_t)a.tiles_m * a.tiles_n, groups, stream_k == 2);
@@ -234,8 +238,17 @@ bool ring_ok(const GemmKArgs& a, int combo) {
 }
 
 // the phase kernel addresses its operands as base + 32-bit byte offset: both must span less than 4 GiB
+// a contraction length that is not a multiple of the K-tile: the TT layout's fp32 class only (gemm_phase.h DBG & 128: the weight
+// gradients over 20 832 tokens), whole k16-steps, at least two K-tiles
+bool phase_tail(const GemmKArgs& a, int combo) {
+  return a.K % PCfg::BKS != 0 && combo == 3 && epi_class(a) == EPI_F32 && a.K % 16 == 0 && a.K >= 2 * PCfg::BKS;
+}
 bool phase_ok(const GemmKArgs& a, int combo) {
-  if (!ring_ok<PCfg>(a, combo)) return false;
+  if (phase_tail(a, combo)) {
+    GemmKArgs b = a;
+    b.K = a.K - a.K % PCfg::BKS;       // every other requirement as for a whole number of K-tiles
+    if (!ring_ok<PCfg>(b, combo)) return false;
+  } else if (!ring_ok<PCfg>(a, combo)) return false;
   const int64_t a_rows = (combo & 2) ? a.K : a.M, b_rows = (combo & 1) ? a.K : a.N;
   return a_rows * a.lda * 2 < (1ll << 32) && b_rows * a.ldb * 2 < (1ll << 32);
 }
@@ -288,6 +301,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   GemmKArgs a;
   a.sk_tiles = 0; a.sk_slabs = nullptr; a.sk_flags = nullptr;
   a.ksum_ws = q->ksum_workspace; a.ksum_op = 0;   // set below, once the configuration is known to carry the summing code
+  a.a_ln = q->a_layernorm != 0; a.a_ln_eps = q->a_ln_eps;
   a.A = reinterpret_cast<const bf16_t*>(q->A); a.lda = q->lda;
   a.B = reinterpret_cast<const bf16_t*>(q->B); a.ldb = q->ldb;
   a.C = q->C; a.ldc = q->ldc; a.c_f32 = (q->c_dtype == DVLA_DT_F32);
@@ -334,7 +348,8 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     // stage 0.58 / 0.49 / 0.85 / 0.775.  The online tuner (dreamvla_amd.ops.GemmTuner) refines this per problem key in-model.
     // The register-staged kernel is the fallback for shapes the DMA kernels do not take (ragged N, unaligned operands, tiny).
     int choice = 0;   // 0 = register-staged S (always valid), 1 = ring L, 3 = ring S, 4 = ring M64, 5 = phase, 11 = skinny
-    if ((variant == 0 || variant == 11) && skinny_ok(a, combo, split_k)) {
+    if (a.a_ln && !(skinny_ok(a, combo, split_k) && skinny_ln_ok(a))) return DVLA_ERR_UNSUPPORTED;   // only the few-rows kernel normalises
+    if ((variant == 0 || variant == 11 || a.a_ln) && skinny_ok(a, combo, split_k)) {
       choice = 11;      // few rows (evaluation-time shapes): one 32 x 32 tile per workgroup, K split over its four waves
     } else if (variant == 0) {
       const double ns = (double)(a.k_per_split < a.K ? a.k_per_split : a.K) / 32.0;

@@ -89,6 +89,8 @@ struct GemmKArgs {
   int sk_tiles; float* sk_slabs; unsigned* sk_flags;
   // k-sums of an operand (dvla.h ksum_*): fp32 partials [split][KSUM_PARTS][len], len = M (op 1) or N (op 2); EPI_F32 kernels only
   float* ksum_ws; int ksum_op;
+  // rows of A layer-normalised on the fly (dvla.h a_layernorm): few-rows kernel only
+  int a_ln; float a_ln_eps;
 };
 constexpr int KSUM_PARTS = 8;   // (up to 4 waves that share the operand rows, each taking every 4th k16-step) x (2 half-waves)
 
@@ -742,7 +744,7 @@ __device__ __forceinline__ RingItem ring_item(const GemmKArgs& p, int id) {
   it.m0 = (int64_t)tm * RC::BM; it.n0 = (int64_t)tn * RC::BN; it.split = split;
   it.k_begin = (int64_t)split * p.k_per_split;
   const int64_t k_end = (it.k_begin + p.k_per_split < p.K) ? (it.k_begin + p.k_per_split) : p.K;
-  it.ns = (int)((k_end - it.k_begin) / RC::BKS);   // K range % BKS == 0 (ring_ok)
+  it.ns = (int)((k_end - it.k_begin + RC::BKS - 1) / RC::BKS);   // K range % BKS == 0 (ring_ok) except the phase kernel's partial last tile
   return it;
 }
 

@@ -31,6 +31,12 @@
 //
 // Requirements (dispatcher falls back otherwise): as ring_ok with BKS = 64: 16-B-vectorisable operands / outputs,
 // K-range % 64 == 0, N % 64 == 0, M >= 256, N >= 256, r-contiguous operands with rows % 256 == 0.
+// DBG & 128 (round 4, the TT layout's fp32 class = the weight gradients): K % 64 may be 16 / 32 / 48 -- the trunk's weight
+// gradients contract over 20 832 = 651 x 32 tokens and ran on the BK-32 ring kernel at 775-850 TFLOP/s where this kernel runs the
+// same problem class at 1 200-1 300 (profiles/r03_gemm_breakdown.json).  The last K-tile of the last K slice is then partial:
+// its DMA pieces that would read k rows past the operand are pointed at the tile's first row instead (same count of pieces:
+// the counted waits do not change), and the A fragments of its dead k16-steps are zeroed after the fragment reads have
+// retired, so whatever the B fragments of those steps hold is multiplied by zero.
 #pragma once
 #include "gemm_impl.h"
 
@@ -58,6 +64,8 @@ template <bool A_T, bool B_T, int EPI, int DBG = 0>
 __global__ __launch_bounds__(PCfg::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_phase_kernel(GemmKArgs p) {
   constexpr int BM = PCfg::BM, BN = PCfg::BN, BKS = PCfg::BKS, CPW = PCfg::CPW;
+  constexpr bool TAIL = (DBG & 128) != 0;
+  static_assert(!TAIL || (A_T && B_T), "partial K-tiles: k-major operands only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -97,6 +105,13 @@ void gemm_phase_kernel(GemmKArgs p) {
     while (sk_n > 0 && (sk_t0 + sk_n - 1) * SG + sk_gi >= nitems) --sk_n;   // the last super-tile may be ragged
   }
   struct Seg { int m0, n0, k_begin, ns, split, kind; };   // kind: 0 whole item, 1 head (owner), 2 tail
+  // valid k16-steps of a segment's last K-tile (4 = whole); only a build with TAIL can see less
+  auto tail_steps = [&](const Seg& sg) -> int {
+    if constexpr (!TAIL) return 4;
+    const int64_t k_last = (int64_t)sg.k_begin + (int64_t)(sg.ns - 1) * BKS;
+    const int64_t left = p.K - k_last;
+    return left >= BKS ? 4 : (int)(left / 16);
+  };
   auto seg_of = [&](int it, Seg& sg) -> bool {
     int id;
     sg.kind = 0;
@@ -132,13 +147,14 @@ void gemm_phase_kernel(GemmKArgs p) {
   uint32_t srcB[CPW];
   int itA = 0, ktA = 0, nkA = 0, nA = 0; bool liveA = false;   // nA = slot (mod 3) of the next A image to issue
   int itB = 0, ktB = 0, nkB = 0, nB = 0; bool liveB = false;
+  int tvA = 4, tvB = 4;                                         // tail_steps of the segments the cursors are in
   const uint32_t stepA = (uint32_t)(2 * (A_T ? (int64_t)BKS * p.lda : (int64_t)BKS));
   const uint32_t stepB = (uint32_t)(2 * (B_T ? (int64_t)BKS * p.ldb : (int64_t)BKS));
   auto openA = [&](int it) {
     Seg w;
     liveA = seg_of(it, w);
     if (!liveA) return;
-    nkA = w.ns; ktA = 0;
+    nkA = w.ns; ktA = 0; tvA = tail_steps(w);
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
       srcA[i] = (uint32_t)(reinterpret_cast<const char*>(dma_src<A_T, BM, BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, wave * CPW + i, lane)) -
@@ -148,7 +164,7 @@ void gemm_phase_kernel(GemmKArgs p) {
     Seg w;
     liveB = seg_of(it, w);
     if (!liveB) return;
-    nkB = w.ns; ktB = 0;
+    nkB = w.ns; ktB = 0; tvB = tail_steps(w);
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
       srcB[i] = (uint32_t)(reinterpret_cast<const char*>(dma_src<B_T, BN, BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, wave * CPW + i, lane)) -
@@ -158,15 +174,25 @@ void gemm_phase_kernel(GemmKArgs p) {
   // the pieces can be issued BETWEEN the MFMAs of a multiply segment: an LDS-DMA issue (M0 write + VMEM issue) costs
   // 100-185 cycles inside a fragment-read segment but hides in the shadow of a 32-cycle MFMA (the first version issued
   // them in the LOAD segments: those then took ~900 cycles against the partner's 512-cycle MFMA segment and paced the loop).
+  // partial last K-tile (TAIL): piece c = 4 wave + i of a k-major image holds k rows 2 c and 2 c + 1 of the tile (lanes 0-31 /
+  // 32-63, dma_src); a row at or past 16 tail_steps lies outside the operand: read the tile's row 0 in its place
+  auto tail_back = [&](int i, int tv, int64_t ld) -> uint32_t {
+    const int k_local = 2 * (wave * CPW + i) + (lane >> 5);
+    return k_local >= 16 * tv ? (uint32_t)(2 * (int64_t)k_local * ld) : 0u;
+  };
   auto pieceA = [&](int i) {
     const uint32_t dst = smem_base + (uint32_t)(nA * PCfg::A_BYTES + wave * (CPW * 1024) + i * 1024);
-    glds16s(p.A, srcA[i], __builtin_amdgcn_readfirstlane(dst));
+    uint32_t off = srcA[i];
+    if constexpr (TAIL) { if (tvA < 4 && ktA == nkA - 1) off -= tail_back(i, tvA, p.lda); }
+    glds16s(p.A, off, __builtin_amdgcn_readfirstlane(dst));
     srcA[i] += stepA;
   };
   auto doneA = [&]() { nA = nA == PCfg::NA - 1 ? 0 : nA + 1; if (++ktA == nkA) openA(++itA); };
   auto pieceB = [&](int i) {
     const uint32_t dst = smem_base + (uint32_t)(PCfg::B_BASE + (nB & 1) * PCfg::B_BYTES + wave * (CPW * 1024) + i * 1024);
-    glds16s(p.B, srcB[i], __builtin_amdgcn_readfirstlane(dst));
+    uint32_t off = srcB[i];
+    if constexpr (TAIL) { if (tvB < 4 && ktB == nkB - 1) off -= tail_back(i, tvB, p.ldb); }
+    glds16s(p.B, off, __builtin_amdgcn_readfirstlane(dst));
     srcB[i] += stepB;
   };
   auto doneB = [&]() { ++nB; if (++ktB == nkB) openB(++itB); };
@@ -230,6 +256,7 @@ void gemm_phase_kernel(GemmKArgs p) {
     w.m0 = __builtin_amdgcn_readfirstlane(w.m0); w.n0 = __builtin_amdgcn_readfirstlane(w.n0);
     w.split = __builtin_amdgcn_readfirstlane(w.split); w.kind = __builtin_amdgcn_readfirstlane(w.kind);
     const int seg_ns = w.ns;
+    const int seg_tv = __builtin_amdgcn_readfirstlane(tail_steps(w));
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -277,6 +304,14 @@ void gemm_phase_kernel(GemmKArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       wait_lds();
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (TAIL) {      // the dead k16-steps of a partial last K-tile contribute nothing (fragment reads have retired)
+        if (kt == seg_ns - 1 && seg_tv < 4) {
+#pragma unroll
+          for (int ks = 1; ks < 4; ++ks)
+            if (ks >= seg_tv) { fa[0][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; fa[1][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       stamp(u, 1);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
       stamp(u, 2);
@@ -316,6 +351,14 @@ void gemm_phase_kernel(GemmKArgs p) {
       if (grp == 1) { if (ia && ib) wait_vmcnt<5>(); else wait_vmcnt<0>(); }
       wait_lds();
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (TAIL) {
+        if (kt == seg_ns - 1 && seg_tv < 4) {
+#pragma unroll
+          for (int ks = 1; ks < 4; ++ks)
+            if (ks >= seg_tv) { fa[0][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; fa[1][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       stamp(u, 5);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
       stamp(u, 6);

@@ -16,7 +16,11 @@ from . import ops
 class Linear(nn.Linear):
     """nn.Linear whose forward is the fused HIP GEMM (+bias, optional activation / residual / dropout)."""
 
-    def forward(self, x, act="none", residual=None, dropout_p=0.0):
+    def forward(self, x, act="none", residual=None, dropout_p=0.0, ln_eps=None):
+        """ln_eps: x is layer-normalised (no affine parameters) inside the GEMM -- Linear(LayerNorm(x)) in one launch
+        (ops.linear_ln: evaluation-time shapes only, see ops.ln_fusable)"""
+        if ln_eps is not None:
+            return ops.linear_ln(x, self.weight, self.bias, eps=ln_eps, act=act, residual=residual)
         return ops.linear(x, self.weight, self.bias, act=act, residual=residual, dropout_p=dropout_p)
 
 
@@ -55,7 +59,9 @@ class Mlp(nn.Module):
         self.fc2 = Linear(hidden_features, out_features, bias=bias)
         self.act_name = act
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, ln_eps=None):
+        if ln_eps is not None:          # fc1(LayerNorm(x)) in one launch (evaluation-time shapes)
+            return self.fc2(self.fc1(x, act=self.act_name, ln_eps=ln_eps), residual=residual)
         return ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, act=self.act_name,
                        residual=residual)
 
@@ -74,8 +80,8 @@ class Attention(nn.Module):
         self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = Linear(dim, dim)
 
-    def forward(self, x, residual=None):
-        qkv = self.qkv(x)
+    def forward(self, x, residual=None, ln_eps=None):
+        qkv = self.qkv(x, ln_eps=ln_eps)
         o = ops.self_attention(qkv, self.num_heads, scale=self.scale, head_dim=self.head_dim)
         return self.proj(o, residual=residual)
 

@@ -228,9 +228,11 @@ class GemmTuner:
 
 def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=False, dact_aux=None, dact=0,
          dropout_p=0.0, seed=(0, 0), residual=None, res_rows=0, out_dtype=BF16, out=None, accumulate=False, split_k=1,
-         variant=None, ksum=None):
+         variant=None, ksum=None, a_ln_eps=None):
     """C[M,N] = epilogue(A . B^T); see include/dvla.h.  `variant` forces a kernel configuration (tests / sweeps)
     instead of asking the tuner.  a: (M,K) or (K,M) if a_trans; b: (N,K) or (K,N) if b_trans.
+    a_ln_eps: the rows of A are layer-normalised (no affine, this epsilon) on their way into the product -- Linear(LayerNorm(x))
+    from x in one launch; few-rows kernel only (M <= 512, k-contiguous operands, 512 <= K <= 1536), inference.
     ksum = ("a" | "b", out): also out[i] = sum over k of that operand's row i (the bias gradient of a weight-gradient GEMM,
     summed from the fragments the kernel multiplies anyway); out: 1-D, M (a) or N (b) long, bf16 or fp32.
     Returns C (and the pre-activation tensor if want_preact)."""
@@ -289,16 +291,22 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
         klen = M if which == "a" else N
         if which not in ("a", "b") or kout.shape != (klen,) or not kout.is_contiguous() or kout.device != a.device:
             raise ValueError("gemm: bad `ksum`")
-        # decided ONCE, independent of the configuration the tuner picks for this call (round-3 ADVICE: the layout was only
-        # checked under the configurations that leave the sum to the column-sum kernel, so a row-major operand would have failed
-        # on some tuning steps and passed on others): the column-sum fallback needs the summed operand stored k-major
-        if not (a_trans if which == "a" else b_trans):
-            raise _lib.DvlaError("gemm: k-sums need the summed operand stored k-major (a_trans / b_trans)")
+        # decided ONCE, independent of what the tuner would pick for this call (round-3 ADVICE: the layout used to be checked only
+        # under the configurations that leave the sum to the column-sum kernel, so a row-major operand failed on some tuning steps
+        # and passed on others).  The column-sum fallback needs the summed operand stored k-major; an operand in any other
+        # layout can only be summed by the ring kernels' fused code: such a call names one of them itself (variant 4 / 6 / 7)
+        # and is never handed to the tuner.
+        if not (a_trans if which == "a" else b_trans) and (variant is None or int(variant) not in (4, 6, 7)):
+            raise _lib.DvlaError("gemm: k-sums of an operand that is not stored k-major (a_trans / b_trans) need a ring "
+                                 "configuration forced (variant 4, 6 or 7)")
     prof = GemmProfiler.active
     # "plain": nothing but (optionally) the bias vector rides on the GEMM (reported per shape by the profiler)
     plain = (act == 0 and not want_preact and dact_aux is None and residual is None and dropout_p == 0.0
              and not (bias is not None and accumulate))
     trial, key = None, None
+    if a_ln_eps is not None:
+        p.a_layernorm, p.a_ln_eps = 1, float(a_ln_eps)
+        variant = 11                    # only the few-rows kernel normalises: never handed to the tuner
     forced = variant is not None
     variant = int(variant) if forced else 0
     if GemmTuner.enabled and not forced:
@@ -870,6 +878,25 @@ class _Linear(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None, None
+
+
+def linear_ln(x, w, b=None, *, eps, act="none", residual=None):
+    """Linear(LayerNorm(x)) in ONE launch for the evaluation-time shapes: the LayerNorm (no affine parameters: the DiT blocks',
+    models/action_model/models.py:129-141) is applied to the rows of x inside the few-rows GEMM (dvla.h a_layernorm).  Inference
+    only (no autograd graph is recorded); callers check `torch.is_grad_enabled()` and the shape limits (ln_fusable)."""
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        raise RuntimeError("linear_ln is an inference path (call it under torch.no_grad())")
+    x, w = to_compute(x), shadow(w)
+    K = w.shape[1]
+    x2 = _rows2d(x, K)
+    res2 = _rows2d(to_compute(residual), w.shape[0]) if residual is not None else None
+    y = gemm(x2, w, bias=b, act=ACT[act] if isinstance(act, str) else int(act), residual=res2, a_ln_eps=eps)
+    return y.view(*x.shape[:-1], w.shape[0])
+
+
+def ln_fusable(x, K):
+    """may Linear(LayerNorm(x)) over rows of K features run as one few-rows GEMM launch?  (inference, <= 512 rows, 512 <= K <= 1536)"""
+    return (not torch.is_grad_enabled()) and x.is_cuda and x.numel() // K <= 512 and 512 <= K <= 1536 and K % 16 == 0
 
 
 def linear(x, w, b=None, *, act="none", conv1d=False, residual=None, dropout_p=0.0, res_rows=0):

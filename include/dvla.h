@@ -77,12 +77,18 @@ typedef struct dvla_gemm_params {
    * shadow); a configuration without that code runs the column-sum kernel on the operand instead, which needs the operand
    * stored k-major (a_trans / b_trans = 1: the weight-gradient layout); otherwise DVLA_ERR_UNSUPPORTED. */
   void* ksum; int32_t ksum_dtype; int32_t ksum_operand; float* ksum_workspace;
+  /* (ABI 5) a_layernorm != 0: the rows of A are layer-normalised on their way into the product -- A'(m, :) = (A(m, :) - mean_m) *
+   * rsqrt(var_m + a_ln_eps), no affine parameters, rounded to bf16 like the output of dvla_layernorm_fwd -- i.e. the GEMM computes
+   * Linear(LayerNorm(x)) from x.  The DiT blocks' parameter-free LayerNorms in front of qkv / fc1 / the output layer
+   * (models/action_model/models.py:129-141,158-160) at evaluation: 250 launches of a control step less.  Few-rows kernel only
+   * (configuration 11: M <= 512, k-contiguous operands, 512 <= K <= 1536); DVLA_ERR_UNSUPPORTED otherwise. */
+  int32_t a_layernorm; float a_ln_eps;
 } dvla_gemm_params;
 int64_t dvla_gemm_ksum_partial_rows(int32_t split_k);
 int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
 /* tuning hook: 0 = automatic kernel choice by the built-in cost model (default; env DVLA_GEMM_VARIANT overrides at load);
- * 11 = the few-rows kernel (M <= 128, both operands k-contiguous, K % 16 == 0: one 32 x 32 tile of C per workgroup, K split over
- * its four waves, fragments straight from global memory -- the evaluation-time shapes; what 0 picks for such problems);
+ * 11 = the few-rows kernel (M <= 512, both operands k-contiguous, K % 16 == 0: one 32 x 32 tile of C per workgroup, K split over
+ * its four or eight waves, fragments straight from global memory -- the evaluation-time shapes; what 0 picks for such problems);
  * 2 = register-staged 128x128 kernel; 4 / 6 / 7 = LDS-DMA ring kernels 256x256 / 128x128 / 256x128 (K-tile 64); 8 = phase
  * kernel (256x256, K-tile 64, two wave groups in ping-pong); 9 = the phase kernel under the stream-K hybrid schedule (whole
  * rounds one tile per CU; the last, partial rounds as equal K-iteration ranges per group of 16 CUs, the two halves of a

@@ -124,7 +124,7 @@ def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", re
 
 
 def check_gemm_skinny(forced=True, **kw):
-    """the few-rows kernel (csrc/gemm_skinny.h: M <= 128, k-contiguous operands -- the shapes of a single-episode control step):
+    """the few-rows kernel (csrc/gemm_skinny.h: M <= 512, k-contiguous operands -- the shapes of a single-episode control step):
     the same oracle as every other configuration, plus the assertion that it is what ran (forced = variant 11; not forced = the
     library's own choice for such a problem must be this kernel)"""
     from dreamvla_amd import _lib
@@ -133,6 +133,44 @@ def check_gemm_skinny(forced=True, **kw):
     out.append({"name": f"gemm skinny M{kw['M']} N{kw['N']} K{kw['K']}: few-rows kernel ran (dvla_last_gemm_variant = {ran})", "rel_l2": 0.0,
                 "tol": 0.0, "ok": ran == 11})
     return out
+
+
+def check_gemm_tail(**kw):
+    """the phase kernel with a PARTIAL last K-tile (gemm_phase.h DBG & 128: K % 64 = 16 / 32 / 48, k-major operands, fp32 class):
+    forced configuration 8 + the assertion that it ran -- before round 4 such a problem fell back to the BK-32 ring kernel"""
+    from dreamvla_amd import _lib
+    out = check_gemm(variant=8, a_trans=True, b_trans=True, **kw)
+    ran = int(_lib.load().dvla_last_gemm_variant())
+    out.append({"name": f"gemm K-tail M{kw['M']} N{kw['N']} K{kw['K']} sk{kw.get('split_k', 1)}: phase kernel ran (dvla_last_gemm_variant = {ran})",
+                "rel_l2": 0.0, "tol": 0.0, "ok": ran == 8})
+    return out
+
+
+def check_gemm_ln(M, N, K, bias=True, act="none", residual=False, eps=1e-6, seed=0):
+    """dvla_gemm_bf16 with a_layernorm: Linear(LayerNorm(x)) from x in one launch (the DiT blocks' parameter-free LayerNorms at
+    evaluation).  Oracle: F.layer_norm without affine -> rounded to bf16 (what dvla_layernorm_fwd writes) -> the GEMM epilogue."""
+    from dreamvla_amd import _lib, ops
+    from dreamvla_amd._lib import ACT
+    g = torch.Generator().manual_seed(4321 + seed)
+    A = rnd((M, K), g) * (1.0 + torch.arange(M).float().view(M, 1) % 5) + 0.5        # rows of different scale and a common offset
+    A = R.bf16_round(A)
+    B = rnd((N, K), g, 1.0 / math.sqrt(K))
+    bias_t = rnd((N,), g) if bias else None
+    res_t = rnd((M, N), g) if residual else None
+    dev = lambda t: None if t is None else t.to(DEV, BF)
+    got = ops.gemm(dev(A), dev(B), bias=dev(bias_t), act=ACT[act], residual=dev(res_t), a_ln_eps=eps)
+    ran = int(_lib.load().dvla_last_gemm_variant())
+    n = R.bf16_round(R.layer_norm(A, None, None, eps))
+    ref = n @ B.t()
+    if bias:
+        ref = ref + bias_t
+    ref = R.act(ref, act)
+    if residual:
+        ref = R.bf16_round(ref) + res_t
+    tag = f"gemm+layernorm M{M} N{N} K{K} bias{int(bias)} {act} res{int(residual)}"
+    # the normalised operand is rounded to bf16 in both; a value that sits on a rounding boundary may flip (stats summed in another order)
+    return [metrics(tag, got, ref, 2e-3, k_ulp=4.0),
+            {"name": tag + f": few-rows kernel ran ({ran})", "rel_l2": 0.0, "tol": 0.0, "ok": ran == 11}]
 
 
 def check_gemm_ksum(M, N, K, which, split_k=1, variant=None, a_trans=True, b_trans=True, out_f32=False, ksum_f32=False, seed=0):
@@ -170,7 +208,8 @@ MODEL_GEMMS = {
     "trunk c_attn fwd": dict(M=20832, N=3072, K=1024, b_trans=True, bias=True, variants=(8, 10)),
     "trunk c_proj fwd": dict(M=20832, N=1024, K=1024, b_trans=True, bias=True, residual=True, dropout_p=0.1, variants=(0, 7, 10)),
     "vit fc1": dict(M=88256, N=3072, K=768, bias=True, act="gelu_erf", variants=(8, 10)),
-    "trunk dW fc1": dict(M=1024, N=4096, K=20832, a_trans=True, b_trans=True, split_k=4, variants=(0, 4)),
+    "trunk dW fc1": dict(M=1024, N=4096, K=20832, a_trans=True, b_trans=True, split_k=4, variants=(0, 4, 8)),   # 8: partial last K-tile
+    "trunk dW c_attn": dict(M=1024, N=3072, K=20832, a_trans=True, b_trans=True, split_k=5, variants=(8,)),
     "decoder dW fc2": dict(M=4096, N=1024, K=91840, a_trans=True, b_trans=True, split_k=4, variants=(8,)),
     "decoder fc2 dX": dict(M=91840, N=1024, K=4096, b_trans=True, variants=(9, 10)),
 }
@@ -738,6 +777,19 @@ def all_checks(quick=False):
         (check_gemm_skinny, dict(M=128, N=1000, K=80, act="relu", out_f32=True)),
         (check_gemm_skinny, dict(M=100, N=40, K=48, bias=True, act="gelu_erf", want_preact=True)),
         (check_gemm_skinny, dict(M=33, N=96, K=4096, bias=True, dropout_p=0.1, residual=True)),
+        (check_gemm_tail, dict(M=256, N=256, K=160, out_f32=True)),                                # 2.5 K-tiles
+        (check_gemm_tail, dict(M=512, N=256, K=208, out_f32=True)),                                # tail of one k16-step
+        (check_gemm_tail, dict(M=256, N=768, K=1264, out_f32=True)),                               # tail of three, 19.75 K-tiles
+        (check_gemm_tail, dict(M=1024, N=512, K=2080, split_k=3)),                                 # split-K: only the last slice is ragged
+        (check_gemm_tail, dict(M=768, N=1024, K=4128, split_k=4, out_f32=True)),
+        (check_gemm_ln, dict(M=120, N=2304, K=768)),                                                # DiT qkv(norm1(x))
+        (check_gemm_ln, dict(M=120, N=3072, K=768, act="gelu_tanh")),                               # fc1(norm2(x))
+        (check_gemm_ln, dict(M=120, N=7, K=768)),                                                   # output layer
+        (check_gemm_ln, dict(M=33, N=96, K=1536, residual=True, eps=1e-5)),
+        (check_gemm_ln, dict(M=512, N=64, K=512, bias=False)),
+        (check_gemm_skinny, dict(M=394, N=2304, K=768, bias=True, forced=False)),                 # the ViT on the newest frame's two views
+        (check_gemm_skinny, dict(M=394, N=768, K=3072, bias=True, residual=True, forced=False)),
+        (check_gemm_skinny, dict(M=512, N=320, K=496, act="gelu_erf", bias=True)),                # four-wave variant (K < 512), ragged K share
         (check_gemm, dict(M=128, N=128, K=2048, a_trans=True, b_trans=True, split_k=4)),
         (check_gemm, dict(M=200, N=72, K=1000, a_trans=True, b_trans=True, split_k=3)),
         (check_gemm, dict(M=256, N=128, K=64, dropout_p=0.1, residual=True)),

@@ -328,9 +328,12 @@ def hip_full_model_checks(name):
                     m.fast_sampler = True
                 res += compare_outputs(out_slow, fx["test"], TOL_MODEL, f"hip.{name}.test(op-by-op sampler)", fx=fx,
                                        records=("ref_test_bf16_deviation",))
-                for nm, a, b_ in (("arm", out[0], out_slow[0]), ("gripper", out[1], out_slow[1])):
-                    r = rel_l2(a, b_)
-                    res.append({"name": f"hip.{name}.test fast sampler vs op-by-op loop: {nm}", "rel_l2": r, "tol": 2e-3, "ok": r <= 2e-3})
+                # the two paths differ in GEMM row counts (the tuner's choices, i.e. fp32 summation orders, differ): bf16 rounding
+                # noise that ten sampler steps amplify exactly as between two bf16 runs of the reference -- same bound
+                rec = fx["ref_test_bf16_deviation"]
+                for i, (nm, a, b_) in enumerate((("arm", out[0], out_slow[0]), ("gripper", out[1], out_slow[1]))):
+                    r, t = rel_l2(a, b_), REF_DEV_FACTOR * rec[i]["rel_l2"]
+                    res.append({"name": f"hip.{name}.test fast sampler vs op-by-op loop: {nm}", "rel_l2": r, "tol": t, "ok": r <= t})
     return res
 
 
