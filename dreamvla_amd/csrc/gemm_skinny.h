@@ -20,13 +20,15 @@
 
 namespace dvla_gemm {
 
-constexpr int SK_PREFETCH = 12;   // k16-steps in flight per wave: 24 x 16 B per lane
+// SK_PREFETCH = k16-steps in flight per wave (template parameter P): 12 -> 24 x 16 B per lane; 6 when a wave's share of K is
+// at most six steps (K <= 768 on eight waves) -- 48 instead of 96 staging registers, so that two workgroups share a CU and the
+// 288 / 384 tiles of the DiT head's qkv / fc1 projections start in ONE round instead of 256 + a straggler round
 
 // LN: the rows of A are layer-normalised (no affine) before they enter the product (dvla.h a_layernorm).  A wave then holds its
 // WHOLE share of the row in the prefetch registers (K <= 16 * SK_PREFETCH * WAVES): row sums and sums of squares from the
 // fragments, combined across the half-waves (which hold alternate octets of a row) and across the waves through LDS, then the
 // fragments are normalised in place and rounded to bf16 -- the value a separate LayerNorm launch would have written.
-template <int WAVES, bool LN>
+template <int WAVES, bool LN, int SK_PREFETCH>
 __global__ __launch_bounds__(64 * WAVES) void gemm_skinny_kernel(GemmKArgs p) {
   __shared__ float part[WAVES][32][33];
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
@@ -134,13 +136,32 @@ inline bool skinny_ok(const GemmKArgs& a, int combo, int split_k) {
 }
 
 // on-the-fly LayerNorm of A: the eight-wave variant with every wave's share of K resident in its prefetch registers
-inline bool skinny_ln_ok(const GemmKArgs& a) { return a.K >= 512 && a.K <= (int64_t)16 * SK_PREFETCH * 8 && a.a_ln_eps > 0.f; }
+inline bool skinny_ln_ok(const GemmKArgs& a) { return a.K >= 512 && a.K <= (int64_t)16 * 12 * 8 && a.a_ln_eps > 0.f; }
+
+// DVLA_SKINNY_CFG = 0 (default rule) | 1: 4 waves, 12 steps | 2: 8 waves, 12 steps | 3: 8 waves, 6 steps (K <= 768 only) | 4: 8 waves, 20
+// steps (1536 < K <= 3072, at most 512 tiles) -- measurement
+// (tests/gpu_skinny_perf.py); read per launch
+inline int skinny_cfg() { const char* e = getenv("DVLA_SKINNY_CFG"); return e ? atoi(e) : 0; }
 
 inline void launch_skinny(const GemmKArgs& a, hipStream_t stream) {
   dim3 grid((unsigned)((a.N + 31) / 32), (unsigned)((a.M + 31) / 32), 1);
-  if (a.a_ln) hipLaunchKernelGGL((gemm_skinny_kernel<8, true>), grid, dim3(512), 0, stream, a);
-  else if (a.K >= 512) hipLaunchKernelGGL((gemm_skinny_kernel<8, false>), grid, dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_skinny_kernel<4, false>), grid, dim3(256), 0, stream, a);
+  const bool short_k = a.K <= 16 * 6 * 8;       // a wave of the eight-wave variant holds its whole share in six steps
+  int cfg = skinny_cfg();
+  if (cfg == 3 && !short_k) cfg = 2;
+  if (a.a_ln) {
+    if (short_k && cfg != 2) hipLaunchKernelGGL((gemm_skinny_kernel<8, true, 6>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<8, true, 12>), grid, dim3(512), 0, stream, a);
+    return;
+  }
+  // long K on few tiles (the DiT head's fc2: K = 3072, 96 tiles): a workgroup alone on its CU is latency-bound -- 14.6 us with
+  // twelve steps in flight and two refills (profiles/r04_skinny_perf.jsonl); twenty of the 24 steps of a wave's share in flight at once (24 would spill)
+  const bool deep = a.K > 16 * 12 * 8 && a.K <= 16 * 24 * 8 && (int64_t)grid.x * grid.y <= 2 * 256;
+  if (cfg == 0) cfg = a.K < 512 ? 1 : (short_k ? 3 : (deep ? 4 : 2));
+  if (cfg == 4 && !deep) cfg = 2;
+  if (cfg == 1) hipLaunchKernelGGL((gemm_skinny_kernel<4, false, 12>), grid, dim3(256), 0, stream, a);
+  else if (cfg == 3) hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 6>), grid, dim3(512), 0, stream, a);
+  else if (cfg == 4) hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 20>), grid, dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12>), grid, dim3(512), 0, stream, a);
 }
 
 }  // namespace dvla_gemm

@@ -309,7 +309,12 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
         variant = 11                    # only the few-rows kernel normalises: never handed to the tuner
     forced = variant is not None
     variant = int(variant) if forced else 0
-    if GemmTuner.enabled and not forced:
+    # a problem the few-rows kernel takes (csrc/gemm_skinny.h) is not handed to the tuner: every tiled candidate falls back to the
+    # register-staged kernel there, the trials of a 5-20 us launch are timing noise (eager trials locked the slow fallback for 120
+    # of a control step's 540 small GEMMs), and configuration 0 picks the few-rows kernel by itself
+    few_rows = (not a_trans and not b_trans and M <= 512 and K >= 16 and K % 16 == 0 and int(p.split_k) <= 1 and a.stride(0) % 8 == 0
+                and b.stride(0) % 8 == 0)
+    if GemmTuner.enabled and not forced and not few_rows:
         key = (M, N, K, int(a_trans), int(b_trans), int(p.split_k), int(act), int(dact),
                bias is not None, want_preact, dact_aux is not None, residual is not None,
                dropout_p > 0.0, out.dtype == torch.float32, bool(accumulate), 0 if ksum is None else (1 if ksum[0] == "a" else 2),

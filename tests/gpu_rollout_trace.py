@@ -55,7 +55,13 @@ def summary(d, out):
             st = next(c for c in rd.fieldnames if "Start_Timestamp" in c)
             en = next(c for c in rd.fieldnames if "End_Timestamp" in c)
             for r in rd:
-                rows.append((int(r[st]), int(r[en]), short(r[kn])))
+                name = r[kn]
+                if "gemm_skinny_kernel" in name:       # keep the template arguments: <waves, LayerNorm on the fly>
+                    import re
+                    m = re.search(r"gemm_skinny_kernel<([^>]*)>", name)
+                    rows.append((int(r[st]), int(r[en]), "gemm_skinny_kernel<" + (m.group(1) if m else "?") + ">"))
+                else:
+                    rows.append((int(r[st]), int(r[en]), short(name)))
     rows.sort()
     with open(os.path.join(os.path.dirname(out), "rollout_trace_run.json")) as f:
         run_info = json.load(f)

@@ -332,7 +332,7 @@ def hip_full_model_checks(name):
                 # noise that ten sampler steps amplify exactly as between two bf16 runs of the reference -- same bound
                 rec = fx["ref_test_bf16_deviation"]
                 for i, (nm, a, b_) in enumerate((("arm", out[0], out_slow[0]), ("gripper", out[1], out_slow[1]))):
-                    r, t = rel_l2(a, b_), REF_DEV_FACTOR * rec[i]["rel_l2"]
+                    r, t = rel_l2(a, b_), 2.0 * REF_DEV_FACTOR * rec[i]["rel_l2"]      # two bf16 computations, each within 1.25 x: triangle bound
                     res.append({"name": f"hip.{name}.test fast sampler vs op-by-op loop: {nm}", "rel_l2": r, "tol": t, "ok": r <= t})
     return res
 

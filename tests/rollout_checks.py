@@ -35,6 +35,12 @@ def _fixture_tols(name):
 
 
 MLP_TOL = 1.25 * 6.78e-3      # fixture A: the reference's own `--precision bf16` deviation of the MLP head's arm action
+# Engine against the HIP module's full-window forward = two DIFFERENT bf16 computations of the same function (one frame per encode
+# runs the few-rows GEMM kernel, S frames the tiled ones; the tuner's choices differ between the row counts): each sits within
+# 1.25 x the reference's own bf16 deviation of the fp32 result (that is what the comparisons with the REAL reference's fixtures
+# below assert), so the two are within 2.5 x of each other -- the triangle bound, not a measured allowance.  Until the few-rows
+# kernel existed both sides ran the same kernels and agreed bit for bit.
+PAIR = 2.0
 
 
 def gpu_rollout_checks(head="mlp", use_graph=True, steps=7):
@@ -45,7 +51,7 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7):
     from oracle import weights
     BF = torch.bfloat16
     S, B = 4, 3
-    tol = MLP_TOL if head == "mlp" else max(_fixture_tols("B"))
+    tol = PAIR * (MLP_TOL if head == "mlp" else max(_fixture_tols("B")))
     cfg = dict(finetune_type="calvin", sequence_length=S, num_resampler_query=16, num_obs_token_per_image=9,
                action_pred_steps=3, transformer_layers=2, hidden_dim=1024, transformer_heads=16, phase="finetune",
                obs_pred=True, use_dit_head=(head == "dit"), attn_implementation="sdpa")
@@ -136,9 +142,12 @@ def gpu_rollout_vs_reference(name, use_graph=True):
             out = (arm.reshape(1, S, *arm.shape[2:]), grip.reshape(1, S, *grip.shape[2:])) + (None,) * 8
             want = list(fx["test"][:2]) + [None] * 8
             res += compare_outputs(out, want, 1e-3, tag + ".vs_real_reference", fx=fx, records=("ref_test_bf16_deviation",))
+            # the action the wrapper would execute (6 values): no element further from the real reference's than twice the
+            # reference's own worst bf16 element deviation on this output (a rel-L2 over 6 numbers is a 6-sample estimate)
             ref_pick = fx["test"][0].view(S, -1, 6)[S - 1, 0].float()
-            r = float((action[0, :6].cpu() - ref_pick).norm() / max(float(ref_pick.norm()), 1e-12))
-            res.append({"name": tag + ".picked_action_vs_real_reference", "rel_l2": r, "tol": 2.0 * tol_arm, "ok": r <= 2.0 * tol_arm})
+            worst = float((action[0, :6].cpu() - ref_pick).abs().max())
+            bound = 2.0 * fx["ref_test_bf16_deviation"][0]["max_abs"]
+            res.append({"name": tag + ".picked_action_vs_real_reference (max abs)", "rel_l2": worst, "tol": bound, "ok": worst <= bound})
             gsign = (fx["test"][1].view(S, -1, 1)[S - 1, 0].float() > 0.5).float() * 2 - 1     # eval_utils_calvin.py:141-146
             res.append({"name": tag + ".gripper_command", "rel_l2": 0.0, "tol": 0.0, "ok": bool(action[0, 6].cpu() == gsign[0])})
         else:
@@ -147,9 +156,18 @@ def gpu_rollout_vs_reference(name, use_graph=True):
                 parts = m.encode_frames(ip[:, idx], iw[:, idx], st[:, idx], tx[:, idx])
                 o = m.decode_tokens(parts, mode="test", test_noise=noise)
             ra, rg = o[0].view(1, S, -1, 6), o[1].view(1, S, -1, 1)
-            for nm, a, b_, t in (("arm", arm, ra, tol_arm), ("gripper", grip, rg, tol_grip)):
-                r = float((a.float() - b_.float()).norm() / max(float(b_.float().norm()), 1e-12))
-                res.append({"name": f"{tag}.{nm}_vs_full_window_forward", "rel_l2": r, "tol": t, "ok": r <= t})
+            rec = fx["ref_test_bf16_deviation"]
+            for i, (nm, a, b_, t) in enumerate((("arm", arm, ra, PAIR * tol_arm), ("gripper", grip, rg, PAIR * tol_grip))):
+                d = (a.float() - b_.float())
+                r = float(d.norm() / max(float(b_.float().norm()), 1e-12))
+                # element-wise: PAIR x the bound compare_outputs puts on one bf16 computation against the fp32 golden values; an
+                # output of a few values (the gripper channel of a 2-frame window: 6 numbers) is judged by that alone -- its
+                # rel-L2 is a 6-sample estimate
+                t_abs = PAIR * max(1.5 * rec[i]["max_abs"], 3.0 * 2.0 ** -8 * rec[i]["absmax"])
+                worst = float(d.abs().max())
+                ok = worst <= t_abs and (a.numel() < 256 or r <= t)
+                res.append({"name": f"{tag}.{nm}_vs_full_window_forward", "rel_l2": r, "tol": t, "max_abs": worst, "max_abs_tol": t_abs,
+                            "ok": bool(ok)})
     if use_graph:
         res.append({"name": f"rollout.ref.{name}.graph_captured", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
     return res
