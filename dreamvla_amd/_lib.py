@@ -101,6 +101,7 @@ SYMBOLS = {
     "dvla_colsum_partial_rows": (_I64, []),
     "dvla_dropout": (C.c_int, [_P, _P, _I64, _I64, _F, _U32, _U32, _P]),
     "dvla_act_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _F, _U32, _U32, _P]),
+    "dvla_act_bwd_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _F, _U32, _U32, _P, _I32, _P, _P]),
     "dvla_act_fwd": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "dvla_ddim_cfg_step": (C.c_int, [_P, _I64, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
     "dvla_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),

@@ -97,6 +97,64 @@ __global__ void act_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __re
   }
 }
 
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = bf2f((bf16_t)(u.x & 0xffff)); f[1] = bf2f((bf16_t)(u.x >> 16));
+  f[2] = bf2f((bf16_t)(u.y & 0xffff)); f[3] = bf2f((bf16_t)(u.y >> 16));
+  f[4] = bf2f((bf16_t)(u.z & 0xffff)); f[5] = bf2f((bf16_t)(u.z >> 16));
+  f[6] = bf2f((bf16_t)(u.w & 0xffff)); f[7] = bf2f((bf16_t)(u.w >> 16));
+}
+
+// dz = dropout'(dy) * act'(preact) AND the column sums of dz in the same pass (dvla_act_bwd_colsum): the gradient of a
+// `y = dropout(act(x W + b))` branch is needed both as the operand of the two backward GEMMs and, summed over the rows, as db.
+// Round 3 summed db from the fragments of the weight-gradient GEMM (ring kernels only); the phase kernel cannot carry those
+// sums, so its launches paid a separate column-sum pass over dz -- which this elementwise pass has in registers anyway.
+// Same strip decomposition as colsum_partial_kernel: block = 4 waves over a 512-column strip of one row slab, a lane owns 8
+// consecutive columns (16-byte loads and stores), the sums are taken of the ROUNDED dz values (what a column sum over the stored
+// tensor gives) and combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ pre,
+                                                             bf16_t* __restrict__ dz, int64_t rows, int64_t cols, int act, int has_drop,
+                                                             uint32_t thr, float scale, uint32_t seed_lo, uint32_t seed_hi,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t slab = blockIdx.y, nslab = gridDim.y;
+  const int64_t r_begin = rows * slab / nslab, r_end = rows * (slab + 1) / nslab;
+  const int64_t c0 = (int64_t)blockIdx.x * 512 + lane * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < cols) {       // cols % 8 == 0 (host check): the octet is whole
+#pragma unroll 4
+    for (int64_t r = r_begin + wave; r < r_end; r += 4) {
+      const uint4 u = *reinterpret_cast<const uint4*>(dy + r * cols + c0);
+      float g[8];
+      unpack8(u, g);
+      if (has_drop) {
+        const uint32_t rowkey = drop_rowkey(seed_lo, seed_hi, (uint32_t)r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (drop_hash_rk(rowkey, (uint32_t)(c0 + e)) >= thr) ? g[e] * scale : 0.f;
+      }
+      if (pre) {
+        float a[8];
+        unpack8(*reinterpret_cast<const uint4*>(pre + r * cols + c0), a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] *= act_bwd(a[e], act);
+      }
+      const uint4 o = make_uint4(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]), pack2bf(g[4], g[5]), pack2bf(g[6], g[7]));
+      *reinterpret_cast<uint4*>(dz + r * cols + c0) = o;
+      float z[8];
+      unpack8(o, z);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += z[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = s[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int64_t c = (int64_t)blockIdx.x * 512 + i;
+    if (c < cols) partial[slab * cols + c] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+  }
+}
+
 __global__ void act_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n, int act) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = f2bf(act_fwd(bf2f(x[i]), act));
@@ -219,6 +277,29 @@ extern "C" int dvla_act_bwd(const void* dy, const void* preact, void* dz, int64_
                      reinterpret_cast<const bf16_t*>(dy), reinterpret_cast<const bf16_t*>(preact),
                      reinterpret_cast<bf16_t*>(dz), rows, cols, act, has_drop, thr_of(dropout_p),
                      has_drop ? 1.0f / (1.0f - dropout_p) : 1.0f, seed_lo, seed_hi);
+  return dvla_check_launch();
+}
+
+extern "C" int dvla_act_bwd_colsum(const void* dy, const void* preact, void* dz, int64_t rows, int64_t cols, int32_t act,
+                                   float dropout_p, uint32_t seed_lo, uint32_t seed_hi, void* colsum, int32_t colsum_dtype,
+                                   float* partial, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!dy || !dz || !colsum || !partial || rows < 0 || cols <= 0 || dropout_p < 0.f || dropout_p >= 1.f) return DVLA_ERR_ARG;
+  if (colsum_dtype != DVLA_DT_F32 && colsum_dtype != DVLA_DT_BF16) return DVLA_ERR_ARG;
+  auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+  if (cols % 8 != 0 || !al16(dy) || !al16(dz) || (preact && !al16(preact))) return DVLA_ERR_UNSUPPORTED;   // 16-byte octets
+  const int has_drop = dropout_p > 0.f;
+  const int64_t colblocks = (cols + 511) / 512;
+  int64_t nslab = rows / 16;
+  if (nslab > CS_BLOCKS) nslab = CS_BLOCKS;
+  if (nslab < 1) nslab = 1;
+  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((unsigned)colblocks, (unsigned)nslab), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(dy), reinterpret_cast<const bf16_t*>(preact), reinterpret_cast<bf16_t*>(dz), rows,
+                     cols, act, has_drop, thr_of(dropout_p), has_drop ? 1.0f / (1.0f - dropout_p) : 1.0f, seed_lo, seed_hi, partial);
+  int rc = dvla_check_launch();
+  if (rc != DVLA_OK) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, stream, partial, colsum,
+                     colsum_dtype == DVLA_DT_BF16 ? 1 : 0, (int)nslab, cols, cols);
   return dvla_check_launch();
 }
 

@@ -440,6 +440,29 @@ def act_bwd_raw(dy2, preact2, act, dropout_p=0.0, seed=(0, 0)):
     return dz
 
 
+def act_bwd_colsum(dy2, preact2, act, dropout_p, seed, out_dtype, bias_param=None):
+    """(dz, column sums of dz) in one pass (dvla_act_bwd_colsum) -- None when the shape does not allow 16-byte octets (the caller
+    then takes act_bwd_raw and sums elsewhere).  bias_param: the parameter whose gradient the sums are (its reducer slot, if it
+    has one, is written in place -- claimed only once the shape is known to be taken)"""
+    lib = _lib.load()
+    if dy2.stride(1) != 1 or dy2.stride(0) != dy2.shape[1]:
+        dy2 = dy2.contiguous()
+    if preact2 is not None and not preact2.is_contiguous():
+        preact2 = preact2.contiguous()
+    rows, cols = dy2.shape
+    if cols % 8 or dy2.data_ptr() % 16 or (preact2 is not None and preact2.data_ptr() % 16):
+        return None
+    dz = torch.empty(dy2.shape, dtype=BF16, device=dy2.device)
+    out = _grad_dest(bias_param, out_dtype) if bias_param is not None else None
+    if out is None:
+        out = torch.empty(cols, dtype=out_dtype, device=dy2.device)
+    part = torch.empty(lib.dvla_colsum_partial_rows() * cols, dtype=torch.float32, device=dy2.device)
+    check(lib.dvla_act_bwd_colsum(dy2.data_ptr(), _ptr(preact2), dz.data_ptr(), rows, cols, int(act), float(dropout_p), int(seed[0]),
+                                  int(seed[1]), out.data_ptr(), DT_F32 if out.dtype == torch.float32 else DT_BF16, part.data_ptr(),
+                                  _stream()), "dvla_act_bwd_colsum")
+    return dz, out
+
+
 def dropout_raw(x2, p, seed):
     lib = _lib.load()
     x2 = x2.contiguous()
@@ -858,20 +881,26 @@ class _Linear(torch.autograd.Function):
         N = w.shape[1] if conv1d else w.shape[0]
         K = w.shape[0] if conv1d else w.shape[1]
         dy2 = _rows2d(_req(dy, "linear.grad_output"), N)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dw = db = dres = None
         if ctx.act != 0 or ctx.dropout_p > 0:
-            dz = act_bwd_raw(dy2, pre, ctx.act, ctx.dropout_p, ctx.seed)
+            # the elementwise backward pass has dz in registers: the bias gradient (its column sums) comes out of the same pass,
+            # and the weight-gradient GEMM below needs no summing code -- any configuration may take it (the phase kernel included)
+            both = act_bwd_colsum(dy2, pre, ctx.act, ctx.dropout_p, ctx.seed, ctx.bias_dtype, bias_param=b) if want_db else None
+            if both is not None:
+                dz, db = both
+            else:
+                dz = act_bwd_raw(dy2, pre, ctx.act, ctx.dropout_p, ctx.seed)
         else:
             dz = dy2
         M = dz.shape[0]
-        dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             # dx[m,k] = sum_n dz[m,n] W(n,k)
             dx = gemm(dz, w, b_trans=not conv1d).view(ctx.x_shape)
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dst = _grad_dest(w, BF16)      # the reducer's bucket slot, written in place (None: a fresh tensor)
             ks = None
-            if want_db and _KSUM_FUSED:    # db = sum_m dz[m, :] rides on the dW GEMM, which streams dz anyway
+            if want_db and db is None and _KSUM_FUSED:    # db = sum_m dz[m, :] rides on the dW GEMM, which streams dz anyway
                 db = _bias_grad_out(b, ctx.bias_dtype, N, dz.device)
                 ks = ("b" if conv1d else "a", db)
             if conv1d:   # dW[k,n] = sum_m x[m,k] dz[m,n]
@@ -946,16 +975,22 @@ class _Mlp(torch.autograd.Function):
         Hd = w1.shape[1] if conv1d else w1.shape[0]
         K = w1.shape[0] if conv1d else w1.shape[1]
         dy2 = _rows2d(_req(dy, "mlp.grad_output"), N)
-        dz = act_bwd_raw(dy2, None, 0, ctx.dropout_p, ctx.seed) if ctx.dropout_p > 0 else dy2
+        dx = dw1 = db1 = dw2 = db2 = dres = None
+        want_db2 = ctx.has_b2 and ctx.needs_input_grad[4]
+        dz = dy2
+        if ctx.dropout_p > 0:       # dropout backward + the second bias gradient (column sums of dz) in one pass
+            both = act_bwd_colsum(dy2, None, 0, ctx.dropout_p, ctx.seed, ctx.b2_dtype, bias_param=b2) if want_db2 else None
+            if both is not None:
+                dz, db2 = both
+            else:
+                dz = act_bwd_raw(dy2, None, 0, ctx.dropout_p, ctx.seed)
         M = dz.shape[0]
         # du = (dz . W2) * act'(u)
         du = gemm(dz, w2, b_trans=not conv1d, dact_aux=u, dact=ctx.act)
-        dx = dw1 = db1 = dw2 = db2 = dres = None
-        want_db2 = ctx.has_b2 and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3]:
             dst = _grad_dest(w2, BF16)
             ks = None
-            if want_db2 and _KSUM_FUSED:
+            if want_db2 and db2 is None and _KSUM_FUSED:
                 db2 = _bias_grad_out(b2, ctx.b2_dtype, N, dz.device)
                 ks = ("b" if conv1d else "a", db2)
             dw2 = (gemm(h, dz, a_trans=True, b_trans=True, split_k=auto_split_k(Hd, N, M), out=dst, ksum=ks) if conv1d else

@@ -37,7 +37,8 @@ extern "C" {
 
 /* ABI revision of this header; dreamvla_amd/_lib.py refuses a library that reports another one (a stale prebuilt .so then fails
  * with a clear message instead of a missing-symbol error).  3 = round 3 (dvla_last_gemm_variant, variant 10, ...); 4 = k-sums on the
- * weight-gradient GEMM (ksum_* fields of dvla_gemm_params); 5 = dvla_ddim_cfg_step, GEMM configuration 11. */
+ * weight-gradient GEMM (ksum_* fields of dvla_gemm_params); 5 = dvla_ddim_cfg_step, dvla_act_bwd_colsum, a_layernorm,
+ * GEMM configuration 11. */
 #define DVLA_ABI_VERSION 5
 int dvla_abi_version(void);
 
@@ -213,6 +214,12 @@ int dvla_dropout(const void* x, void* y, int64_t rows, int64_t cols, float p, ui
 /* dz = dy * act'(preact) (optionally after dropout mask of dy): backward of a fused activation. */
 int dvla_act_bwd(const void* dy, const void* preact, void* dz, int64_t rows, int64_t cols, int32_t act,
                  float dropout_p, uint32_t seed_lo, uint32_t seed_hi, void* stream);
+/* The same dz, plus colsum[c] = sum_r dz[r, c] (fp32 sums of the stored bf16 values, written as colsum_dtype) from the same pass:
+ * the bias gradient of `y = dropout(act(x W + b))` (models/gpt2.py:160,172-173,329-339: c_proj and the MLP's second Conv1D),
+ * which otherwise costs either a column-sum pass over dz or the summing code inside the weight-gradient GEMM.  partial:
+ * dvla_colsum_partial_rows() x cols floats.  cols % 8 == 0 and 16-byte aligned operands, else DVLA_ERR_UNSUPPORTED. */
+int dvla_act_bwd_colsum(const void* dy, const void* preact, void* dz, int64_t rows, int64_t cols, int32_t act, float dropout_p,
+                        uint32_t seed_lo, uint32_t seed_hi, void* colsum, int32_t colsum_dtype, float* partial, void* stream);
 /* y = act(x) */
 int dvla_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream);
 /* One step of the action sampler's algebra, evaluation path (models/dreamvla_model.py:935-987): classifier-free guidance

@@ -135,6 +135,26 @@ def check_gemm_skinny(forced=True, **kw):
     return out
 
 
+def check_act_bwd_colsum(rows, cols, act="none", dropout_p=0.0, out_bf16=False, seed=0):
+    """dvla_act_bwd_colsum: dropout / activation backward and the bias gradient (column sums of dz) in one pass -- dz bit-identical
+    to dvla_act_bwd's, the sums against an fp64 sum of those stored values"""
+    from dreamvla_amd import ops
+    from dreamvla_amd._lib import ACT
+    g = torch.Generator().manual_seed(99 + seed)
+    dy = rnd((rows, cols), g).to(DEV, BF)
+    pre = rnd((rows, cols), g).to(DEV, BF) if act != "none" else None
+    sd = (123, 456)
+    dz_ref = ops.act_bwd_raw(dy, pre, ACT[act], dropout_p, sd)
+    r = ops.act_bwd_colsum(dy, pre, ACT[act], dropout_p, sd, BF if out_bf16 else torch.float32)
+    tag = f"act_bwd+colsum {rows}x{cols} {act} p{dropout_p} bf16out{int(out_bf16)}"
+    if r is None:
+        return [{"name": tag + ": shape not taken", "rel_l2": 0.0, "tol": 0.0, "ok": cols % 8 != 0}]
+    dz, db = r
+    want = dz_ref.double().sum(0).float().cpu()
+    return [{"name": tag + " dz bit-identical to dvla_act_bwd", "rel_l2": 0.0, "tol": 0.0, "ok": bool(torch.equal(dz, dz_ref))},
+            metrics(tag + " column sums", db, want, TOL_FWD if out_bf16 else 1e-5, round_ref=out_bf16)]
+
+
 def check_gemm_tail(**kw):
     """the phase kernel with a PARTIAL last K-tile (gemm_phase.h DBG & 128: K % 64 = 16 / 32 / 48, k-major operands, fp32 class):
     forced configuration 8 + the assertion that it ran -- before round 4 such a problem fell back to the BK-32 ring kernel"""
@@ -777,6 +797,11 @@ def all_checks(quick=False):
         (check_gemm_skinny, dict(M=128, N=1000, K=80, act="relu", out_f32=True)),
         (check_gemm_skinny, dict(M=100, N=40, K=48, bias=True, act="gelu_erf", want_preact=True)),
         (check_gemm_skinny, dict(M=33, N=96, K=4096, bias=True, dropout_p=0.1, residual=True)),
+        (check_act_bwd_colsum, dict(rows=20832, cols=1024, dropout_p=0.1)),                        # trunk c_proj / fc2 branches
+        (check_act_bwd_colsum, dict(rows=1000, cols=4096, act="gelu_tanh", dropout_p=0.1, out_bf16=True)),
+        (check_act_bwd_colsum, dict(rows=333, cols=520, act="relu")),                              # ragged strip (520 = 512 + 8)
+        (check_act_bwd_colsum, dict(rows=7, cols=64, dropout_p=0.5)),                              # fewer rows than row slabs
+        (check_act_bwd_colsum, dict(rows=100, cols=36, dropout_p=0.1)),                            # cols % 8 != 0: not taken
         (check_gemm_tail, dict(M=256, N=256, K=160, out_f32=True)),                                # 2.5 K-tiles
         (check_gemm_tail, dict(M=512, N=256, K=208, out_f32=True)),                                # tail of one k16-step
         (check_gemm_tail, dict(M=256, N=768, K=1264, out_f32=True)),                               # tail of three, 19.75 K-tiles
