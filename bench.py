@@ -404,9 +404,9 @@ def main():
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command (tests/pmc_traffic.sh), stored with the
         # commit they were measured on; a file from another tree is reported as stale, never presented as current
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))      # the newest round's passes
+        pmc = cands[-1] if cands else ""
         if os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)

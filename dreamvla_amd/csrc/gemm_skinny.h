@@ -156,7 +156,7 @@ inline void launch_skinny(const GemmKArgs& a, hipStream_t stream) {
   // long K on few tiles (the DiT head's fc2: K = 3072, 96 tiles): a workgroup alone on its CU is latency-bound -- 14.6 us with
   // twelve steps in flight and two refills (profiles/r04_skinny_perf.jsonl); twenty of the 24 steps of a wave's share in flight at once (24 would spill)
   const bool deep = a.K > 16 * 12 * 8 && a.K <= 16 * 24 * 8 && (int64_t)grid.x * grid.y <= 2 * 256;
-  if (cfg == 0) cfg = a.K < 512 ? 1 : (short_k ? 3 : (deep ? 4 : 2));
+  if (cfg == 0) cfg = a.K < 512 ? 1 : (short_k ? 3 : 2);      // (cfg 4 measured: 16.1 us against 14.6 for cfg 2 at K = 3072 -- not the default)
   if (cfg == 4 && !deep) cfg = 2;
   if (cfg == 1) hipLaunchKernelGGL((gemm_skinny_kernel<4, false, 12>), grid, dim3(256), 0, stream, a);
   else if (cfg == 3) hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 6>), grid, dim3(512), 0, stream, a);

@@ -12,11 +12,17 @@ BF = torch.bfloat16
 
 
 def main():
+    from dreamvla_amd.dreamvla_model import generate_attention_mask
     torch.manual_seed(0)
-    for (B, H, L) in [(32, 16, 651), (448, 12, 197), (448, 16, 265)]:
+    # the step's attention mix: the trunk under its real mask with dropout (ring kernels), the ViT and the decoders (short-sequence
+    # kernels of round 4), one dense long sequence
+    mask = generate_attention_mask(7, 36, 57, 0, False, False, False, 0.0, 54, 3)
+    mt = ops.build_mask_tables(mask, device="cuda")
+    for (B, H, L, tables, p) in [(32, 16, 651, mt, 0.1), (448, 12, 197, None, 0.0), (448, 16, 205, None, 0.0), (448, 16, 265, None, 0.0),
+                                 (32, 16, 651, None, 0.0)]:
         qkv = torch.randn(B, L, 3 * H * 64, device="cuda", dtype=BF, requires_grad=True)
         for _ in range(3):
-            o = ops.self_attention(qkv, num_heads=H)
+            o = ops.self_attention(qkv, num_heads=H, mask_tables=tables, dropout_p=p)
             o.backward(torch.ones_like(o))
         torch.cuda.synchronize()
 

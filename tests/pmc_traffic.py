@@ -24,7 +24,8 @@ def main():
     alg = sum(r["launches"] * 2.0 * (r["M"] * r["K"] + r["N"] * r["K"] + r["M"] * r["N"] * (2.0 if r["epilogue"] == "fused" else 1.0) / 1.0)
               for r in rows) / n
     # (fused launches write or read a second M x N tensor: pre-activation / act' operand / residual -- counted once more)
-    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    import os
+    commit = os.environ.get("DVLA_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()   # (the GPU box has no .git: the launching script passes the commit)
     res = {"gemm_bytes_per_launch": fbytes / launches + wbytes / wl,
            "fetch_bytes_per_launch_corrected": fbytes / launches, "write_bytes_per_launch": wbytes / wl,
            "launches_in_pass": launches, "algorithmic_bytes_per_launch": alg, "commit": commit,

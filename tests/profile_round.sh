@@ -23,6 +23,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$C -f csv -- $BENCH --steps 2 --warmup 0 --plan $OUT/${TAG}_gemm_plan.json --no-roofline --no-fwd --no-rollout > $OUT/${TAG}_pmc_$C.log 2>&1
   python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_$C $OUT/${TAG}_pmc_$C.json > $OUT/${TAG}_pmc_$C.txt 2>&1
 done
+python $REPO/tests/pmc_traffic.py $OUT/${TAG}_pmc_FETCH_SIZE.json $OUT/${TAG}_pmc_WRITE_SIZE.json $OUT/${TAG}_gemm_breakdown.json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.log 2>&1
 # 2b. GEMM matrix-pipe busy over the tuned step
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_pmc_gemm_mfma -f csv -- $BENCH --steps 2 --warmup 0 --plan $OUT/${TAG}_gemm_plan.json --no-roofline --no-fwd --no-rollout > $OUT/${TAG}_pmc_gemm_mfma.log 2>&1
 python $REPO/tests/pmc_summary.py $OUT/${TAG}_pmc_gemm_mfma $OUT/${TAG}_pmc_gemm_mfma.json > $OUT/${TAG}_pmc_gemm_mfma.txt 2>&1
