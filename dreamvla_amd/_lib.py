@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVLA_LIB") or os.path.join(_HERE, "libdvla_hip.so")
 
 DT_BF16, DT_F32 = 0, 1
-ABI_VERSION = 5          # DVLA_ABI_VERSION of include/dvla.h
+ABI_VERSION = 6          # DVLA_ABI_VERSION of include/dvla.h
 ACT = {"none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "gelu_new": 2, "relu": 3, "silu": 4,
        "quick_gelu": 5, "tanh": 6, "sigmoid": 7}
 
@@ -74,6 +74,17 @@ class TokenSrc(C.Structure):
                 ("tok_count", C.c_int32)]
 
 
+class DitSampleParams(C.Structure):
+    _fields_ = [("blocks", C.c_void_p),
+                ("xemb_w", C.c_void_p), ("xemb_b", C.c_void_p), ("final_w", C.c_void_p), ("final_b", C.c_void_p),
+                ("pos", C.c_void_p), ("cond", C.c_void_p),
+                ("coef", C.c_void_p), ("noise", C.c_void_p), ("out", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("cfg_scale", C.c_float), ("ln_eps", C.c_float),
+                ("depth", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("channels", C.c_int32),
+                ("tokens", C.c_int32), ("bs", C.c_int32), ("steps", C.c_int32), ("reserved", C.c_int32)]
+
+
 class FrameView(C.Structure):
     _fields_ = [("base", C.c_void_p), ("stride_b", C.c_int64), ("stride_t", C.c_int64), ("T", C.c_int32)]
 
@@ -104,6 +115,8 @@ SYMBOLS = {
     "dvla_act_bwd_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _F, _U32, _U32, _P, _I32, _P, _P]),
     "dvla_act_fwd": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "dvla_ddim_cfg_step": (C.c_int, [_P, _I64, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
+    "dvla_dit_sample_workspace_bytes": (C.c_int64, [_I32]),
+    "dvla_dit_sample": (C.c_int, [C.POINTER(DitSampleParams), _P]),
     "dvla_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_cast_bf16_to_f32": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),

@@ -86,16 +86,48 @@ class ActionModel(nn.Module):
         pos = net.positional_embedding.to(wdt)
         f32 = np.float32
         x = noise.float().contiguous()
+
+        def coefficients(i):
+            # the coefficients as `_extract_into_tensor` gathers them: float64 tables read as float32, sqrt taken in float32
+            acp_prev = f32(dd.alphas_cumprod_prev[i])
+            return (f32(dd.sqrt_recip_alphas_cumprod[i]), f32(dd.sqrt_recipm1_alphas_cumprod[i]), np.sqrt(acp_prev),
+                    np.sqrt(f32(1.0) - acp_prev))
+
+        hidden = net.x_embedder.linear.out_features
+        if getattr(self, "team_sampler", True) and ops.dit_team_ok(hidden, net.num_heads, net.in_channels, T, bs, cond.device):
+            # the whole loop below as ONE persistent kernel on the CUs of one XCD (csrc/dit_team.hip): same arithmetic and
+            # rounding points, the ~60 launches of a sampler step become exchanges through that XCD's L2
+            ck = ("team", str(cond.device), dd.num_timesteps)
+            if ck not in cache:
+                cache[ck] = {"coef": torch.tensor(np.array([coefficients(i) for i in steps], dtype=np.float32), device=cond.device),
+                             "ws": ops.dit_team_workspace(hidden, cond.device), "ptrs": None, "table": None}
+            st = cache[ck]
+            ws = [ops.shadow(w).contiguous() for blk in net.blocks
+                  for w in (blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias,
+                            blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias)]
+            ptrs = tuple(w.data_ptr() for w in ws)
+            if st["ptrs"] != ptrs:          # (re)built outside a capture: the engine's eager warm-up calls come first
+                st["table"] = torch.tensor(ptrs, dtype=torch.int64, device=cond.device).view(len(net.blocks), 8)
+                st["ptrs"], st["keep"] = ptrs, ws
+            cond_tab = (z_emb.unsqueeze(0) + t_emb.view(t_emb.shape[0], 1, 1, -1)).contiguous()    # z_emb + t_emb[j], all steps
+            sh = lambda w: ops.shadow(w).contiguous()
+            out = ops.dit_team_sample(st["table"], len(net.blocks), hidden, net.num_heads, sh(net.x_embedder.linear.weight),
+                                      sh(net.x_embedder.linear.bias), sh(net.final_layer.linear.weight),
+                                      sh(net.final_layer.linear.bias), pos.contiguous(), cond_tab, st["coef"], x, cfg_scale,
+                                      net.blocks[0].norm1.eps, st["ws"])
+            if not torch.cuda.is_current_stream_capturing():
+                status, xcc = ops.dit_team_status(st["ws"])
+                self.team_xcc_mask = xcc
+                if status != 0:
+                    raise RuntimeError(f"dvla_dit_sample: an exchange inside the kernel timed out (status {status}, XCC mask {xcc:#x})")
+            return out
         for j, i in enumerate(steps):
             xe = net.x_embedder(x.to(wdt))                                               # (bs, T, H)
             tok = torch.cat((z_emb + t_emb[j], torch.cat((xe, xe), 0)), dim=1) + pos     # (2 bs, 2 T, H)
             for blk in net.blocks:
                 tok = blk(tok)
             out = net.final_layer(tok)[:, T:, :]                                         # (2 bs, T, C)
-            # the coefficients as `_extract_into_tensor` gathers them: float64 tables read as float32, sqrt taken in float32
-            acp_prev = f32(dd.alphas_cumprod_prev[i])
-            x = ops.ddim_cfg_step(out, x, cfg_scale, f32(dd.sqrt_recip_alphas_cumprod[i]), f32(dd.sqrt_recipm1_alphas_cumprod[i]),
-                                  np.sqrt(acp_prev), np.sqrt(f32(1.0) - acp_prev))
+            x = ops.ddim_cfg_step(out, x, cfg_scale, *coefficients(i))
         return x
 
 

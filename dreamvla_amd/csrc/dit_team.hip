@@ -1,0 +1,594 @@
+// dit_team.hip -- the evaluation-time DiT action sampler as ONE persistent kernel on the 32 CUs of one XCD.
+//
+//   What it replaces.  A closed-loop control step samples the executed action with ten DDIM steps of classifier-free guidance
+//   through the DiT head (models/dreamvla_model.py:935-987 -> models/action_model/models.py:162-268): per step 12 blocks of
+//   LayerNorm -> qkv -> attention -> proj (+x) -> LayerNorm -> fc1 -> GELU -> fc2 (+x) on 2 x bs x 6 token rows (12 rows at one
+//   episode).  Launch by launch that is ~600 few-row GEMM / attention launches per control step, each living for two memory round
+//   trips behind a ~5 us launch boundary: 4.7 of the 9.9 ms of a single-episode control step (profiles/r04_rollout_step_summary_*).
+//   The work itself is a weight stream: 170 MB of bf16 weights per DiT-B forward and ~0.1 GFLOP.
+//
+//   Why one XCD.  tests/probes/sync_probe.cpp (profiles/r04_sync_probe.jsonl) measures what a dependent exchange between
+//   workgroups costs inside a kernel on this chip: 7.6 us across all 256 CUs with release / acquire fences (buffer_wbl2 /
+//   buffer_inv: what a cooperative-groups grid sync does), 4.2 us when the exchanged data moves with device-scope (sc1)
+//   accesses and nothing is flushed -- and 1.03 us among the 32 workgroups of ONE XCD, whose exchange stays in that XCD's L2.
+//   One XCD streams 1.32 TB/s (170 MB in 134 us); the whole chip 6.5 TB/s (27 us) -- but a DiT forward is a chain of 60
+//   dependent exchanges, so the chip-wide variant pays 60 x 4.2 = 250 us of latency per forward to save 107 us of streaming.
+//   The team of one XCD is the faster machine for this problem: ~134 us of weight stream per forward with the exchanges
+//   (60 x ~1 us) overlapped by prefetching the next phase's weights across each barrier.
+//
+//   Team.  The grid is one workgroup per CU; consecutive workgroups go to consecutive XCCs (round-robin placement: the probe
+//   finds workgroup b on XCC b % 8; inside a process that has launched other kernels the rotation starts elsewhere, but every
+//   eighth workgroup still shares an XCC), the 32 workgroups with b % 8 == 0 form the team, the others exit at once.  CORRECTNESS DOES NOT DEPEND ON THE PLACEMENT: every
+//   access to data another workgroup wrote is a device-scope (sc1) access, coherent across XCDs as well -- a team that straddles
+//   XCDs is only slower.  All spins are bounded; a timeout raises `status` and poisons the output with NaN.
+//
+//   Phase = one exchange.  Every GEMM of the chain is cut into tiles of 16 output columns; tile i belongs to team member i % 32.
+//   A workgroup's 8 waves split K eight ways; a wave's weight fragments for ALL its workgroup's tiles of the phase (at most 32 x
+//   16 B per lane) are requested BEFORE the barrier that ends the previous phase is waited on -- the weights do not depend on
+//   the activations -- so the stream keeps running through the exchange.  After the barrier the wave reads its K-share of the
+//   (at most 32) activation rows, LayerNorm is applied on the fly where the chain has one (row statistics exchanged through
+//   LDS), the 16x16x32 MFMAs run, the eight partial tiles meet in LDS, and wave j finishes tile j: bias, GELU, residual,
+//   rounding points exactly where the launch-by-launch path has them (csrc/gemm_impl.h epilogue_oct, csrc/gemm_skinny.h).
+//   Attention (6 tokens, head_dim 64) is one wave per (sample, head) on the VALU with the rounding points of csrc/attention.hip
+//   (integer running maximum in the log2 domain, probabilities rounded to bf16 before P.V).  The final LayerNorm + linear, the
+//   guidance + DDIM update (csrc/elementwise.hip ddim_cfg_step_kernel, operation by operation) and the next step's token
+//   embedding run on team member 0 between two steps.  One launch = the whole sampler: steps x (1 + 5 x depth) exchanges.
+#include "common.h"
+#include "../../include/dvla.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int TEAM = 32;        // workgroups of the team = CUs of one XCD
+constexpr int NWAVES = 8;
+constexpr int LDP = 20;         // row stride (floats) of a partial tile in LDS
+constexpr int MAX_L = 8;        // tokens per sample the attention phase holds (2 x action_pred_steps)
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+// ---- memory operations issued by hand.  The compiler does not see them as memory operations in flight: nothing it emits waits
+// for them, so a phase can leave its successor's weight loads outstanding across barriers; every consumer sits behind vm_wait()
+// + pin().  (Compiler-tracked loads / atomics in between stay correct: s_waitcnt vmcnt(n) retires in order, uncounted younger
+// operations only make it wait longer.)
+// (OFF: byte offset in the instruction's immediate field -- one address register pair per row, not one per load)
+template <int OFF = 0>
+__device__ __forceinline__ u32x4 ldg16(const void* p) {          // weights: read-only for the whole launch, ordinary caching
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF = 0>
+__device__ __forceinline__ u32x4 ldd16(const void* p) {          // device scope: data another workgroup wrote in this launch
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ u32x2 ldg8(const void* p) {
+  u32x2 v;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ u32x2 ldd8(const void* p) {
+  u32x2 v;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void std16(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void std8(void* p, u32x2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void std4(void* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <class T>
+__device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }      // uses of v stay behind the preceding vm_wait()
+__device__ __forceinline__ void wg_barrier() { __builtin_amdgcn_s_barrier(); }  // no fence: LDS hand-offs add their own lgkmcnt wait
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 15u;
+}
+
+// dynamic LDS, in floats: [row statistics 8 x 32 x 2][model output 32 x 16][sampler state 256][flags 16][partial tiles | attention]
+// (the phase functions are not inlined: each declares the array itself, so that its accesses are LDS instructions, not flat ones)
+constexpr int STAT_OFF = 0, MO_OFF = 512, XS_OFF = 1024, DEAD_OFF = 1280, PART_OFF = 1296;
+#define DIT_LDS() extern __shared__ float dit_lds[]
+
+struct Team {
+  unsigned* ctr;       // arrivals since the launch
+  unsigned* status;    // != 0: a wait timed out
+  unsigned epoch;      // exchanges this workgroup has arrived at
+  int rank;
+};
+
+// every store of this workgroup to shared buffers has completed (vm_wait + workgroup barrier by the caller).  Called at the very end
+// of a phase function -- before it restores its callee-saved registers; the caller counts the exchange (tm.epoch += 1).
+__device__ __forceinline__ void team_arrive(const Team& tm) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(tm.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave 0: until all team members have arrived `epoch` times
+__device__ __forceinline__ void team_wait(const Team& tm) {
+  DIT_LDS();
+  int* dead = reinterpret_cast<int*>(dit_lds + DEAD_OFF);      // this workgroup stopped waiting (after a timeout)
+  if (threadIdx.x == 0 && !*dead) {
+    const unsigned target = (unsigned)TEAM * tm.epoch;
+    unsigned spins = 0;
+    while (__hip_atomic_load(tm.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > SPIN_LIMIT) {
+        *dead = 1;
+        __hip_atomic_store(tm.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+}
+
+struct Args {
+  const dvla_dit_block_weights* blocks;
+  const bf16_t *xemb_w, *xemb_b, *final_w, *final_b, *pos, *cond;
+  const float* coef;
+  const float* noise;
+  float* out;
+  bf16_t *X, *QKV, *O, *HID;
+  unsigned* ctr;       // [0] team counter, [16] workgroups that have left, [32] status, [64 + r] XCC id of member r (last launch)
+  float cfg, eps;
+  int depth, D, H, C, T, bs, steps;
+};
+
+enum { EPI_BIAS = 0, EPI_BIAS_RES = 1, EPI_BIAS_GELU = 2, EPI_FINAL = 3 };
+
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void unpack8(u32x4 u, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(u[i] << 16); v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+}
+
+// KS consecutive k32-steps of one operand row: 16 B per lane each, 64 B apart, offsets as immediates
+template <int KS, bool DEV, int S = 0>
+__device__ __forceinline__ void load_steps(u32x4 (&f)[KS], const bf16_t* p) {
+  if constexpr (S < KS) {
+    f[S] = DEV ? ldd16<64 * S>(p) : ldg16<64 * S>(p);
+    load_steps<KS, DEV, S + 1>(f, p);
+  }
+}
+
+// One GEMM phase:  out[R, N] = epilogue( [LayerNorm](A[R, K]) . W[N, K]^T ),  K = 8 waves x KS x 32.
+// KS: k32-steps per wave; MT: tiles per workgroup (>= ceil(N / 16 / TEAM), <= 8); RB: blocks of 16 rows (R <= 16 RB).
+template <int KS, int MT, int RB, bool LN, int EPI>
+__device__ __attribute__((noinline)) void gemm_phase(const Team tm, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias, int N, const bf16_t* A,
+                                                     int lda, bf16_t* out, int ldo, int R, float eps) {
+  static_assert(MT <= NWAVES, "wave j finishes tile j");
+  DIT_LDS();
+  float* part = dit_lds + PART_OFF;
+  float* stat = dit_lds + STAT_OFF;
+  float* mo = dit_lds + MO_OFF;
+  constexpr int K = NWAVES * KS * 32;
+  const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ntiles = (N + 15) >> 4;
+  const int kb = wave * (KS * 32) + 8 * g;
+  // 1. this workgroup's weight fragments: in flight across the exchange below
+  u32x4 wf[MT][KS];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    int n = (tm.rank + TEAM * j) * 16 + l15;
+    n = n < N ? n : N - 1;                                        // (tiles / columns past the end: a valid address, zeroed below)
+    const bf16_t* wp = W + (int64_t)n * K + kb;
+    load_steps<KS, false>(wf[j], wp);
+  }
+  // the epilogue's bias quad of wave j's tile (lane: row lane / 4, columns 4 (lane % 4) .. + 3 of the tile)
+  const int etile = tm.rank + TEAM * wave, erow = lane >> 2, ec = (lane & 3) * 4;
+  const bool ewave = wave < MT && etile < ntiles;
+  const int en = etile * 16 + ec;
+  const bool evec = ewave && en + 3 < N;
+  u32x2 bq2 = ldg8(bias + (evec ? en : 0));
+  // 2. the producers of A have arrived
+  if (wave == 0) team_wait(tm);
+  wg_barrier();
+  // 3. this wave's K-share of the rows; the residual quad of the epilogue
+  u32x4 af[RB][KS];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    int row = rb * 16 + l15;
+    row = row < R ? row : R - 1;
+    const bf16_t* ap = A + (int64_t)row * lda + kb;
+    load_steps<KS, true>(af[rb], ap);
+  }
+  u32x2 rq[RB];
+  if (EPI == EPI_BIAS_RES) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      int row = rb * 16 + erow;
+      row = row < R ? row : R - 1;
+      int n = etile * 16 + ec;
+      n = n + 3 < N ? n : 0;
+      rq[rb] = ldd8(out + (int64_t)row * ldo + n);               // the residual stream is updated in place: out IS the residual
+    }
+  }
+  vm_wait();
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) pin(wf[j][s]);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) pin(af[rb][s]);
+    if (EPI == EPI_BIAS_RES) pin(rq[rb]);
+  }
+  pin(bq2);
+  float bq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (evec) {
+    bq[0] = __uint_as_float(bq2[0] << 16); bq[1] = __uint_as_float(bq2[0] & 0xffff0000u);
+    bq[2] = __uint_as_float(bq2[1] << 16); bq[3] = __uint_as_float(bq2[1] & 0xffff0000u);
+  } else if (ewave) {                      // (the final layer's 7 columns)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (en + e < N) bq[e] = bf2f(bias[en + e]);
+  }
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const bool ok = (tm.rank + TEAM * j) * 16 + l15 < N;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wf[j][s][e] = ok ? wf[j][s][e] : 0u;
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const bool ok = rb * 16 + l15 < R;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) af[rb][s][e] = ok ? af[rb][s][e] : 0u;
+  }
+  if (LN) {
+    // row statistics: this lane holds 8 KS elements of row l15 (+ 16 rb); the four 16-lane groups and the eight waves hold the rest
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        float v[8];
+        unpack8(af[rb][s], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sm += v[e]; sq = fmaf(v[e], v[e], sq); }
+      }
+      sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+      sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+      if (g == 0) { stat[(wave * 32 + rb * 16 + l15) * 2] = sm; stat[(wave * 32 + rb * 16 + l15) * 2 + 1] = sq; }
+    }
+    lds_wait();
+    wg_barrier();
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) { S += stat[(w * 32 + rb * 16 + l15) * 2]; Q += stat[(w * 32 + rb * 16 + l15) * 2 + 1]; }
+      const float inv_k = 1.0f / (float)K;
+      const float mean = S * inv_k;
+      const float var = fmaxf(Q * inv_k - mean * mean, 0.f);
+      const float rstd = rsqrtf(var + eps);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        float v[8];
+        unpack8(af[rb][s], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[rb][s][i] = pack2bf(v[2 * i], v[2 * i + 1]);
+      }
+    }
+  }
+  // 4. products
+  f32x4 acc[MT][RB];
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      acc[j][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc[j][rb] = mfma16(af[rb][s], wf[j][s], acc[j][rb]);
+    }
+  // acc[j][rb][r] = C(16 rb + 4 g + r, 16 tile_j + l15), this wave's eighth of K
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(((wave * MT + j) * RB + rb) * 16 + 4 * g + r) * LDP + l15] = acc[j][rb][r];
+  lds_wait();
+  wg_barrier();
+  // 5. wave j finishes tile j
+  if (ewave) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int row = rb * 16 + erow;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) {                          // fixed order: deterministic
+        const float4 q = *reinterpret_cast<const float4*>(part + (((w * MT + wave) * RB + rb) * 16 + erow) * LDP + ec);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bq[e];
+      if (EPI == EPI_BIAS_GELU) {
+        const f32x2 a = act_fwd2(f32x2{v[0], v[1]}, ACT_GELU_TANH), b = act_fwd2(f32x2{v[2], v[3]}, ACT_GELU_TANH);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+      }
+      if (EPI == EPI_BIAS_RES) {
+        // the branch value is rounded before the residual joins it (the reference materialises it as a bf16 tensor)
+        const float r0 = __uint_as_float(rq[rb][0] << 16), r1 = __uint_as_float(rq[rb][0] & 0xffff0000u);
+        const float r2 = __uint_as_float(rq[rb][1] << 16), r3 = __uint_as_float(rq[rb][1] & 0xffff0000u);
+        v[0] = bf2f(f2bf(v[0])) + r0; v[1] = bf2f(f2bf(v[1])) + r1; v[2] = bf2f(f2bf(v[2])) + r2; v[3] = bf2f(f2bf(v[3])) + r3;
+      }
+      if (EPI == EPI_FINAL) {
+        if (row < R) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mo[row * 16 + ec + e] = bf2f(f2bf(v[e]));      // the model's bf16 output, as floats
+        }
+      } else if (row < R) {
+        const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        std8(out + (int64_t)row * ldo + etile * 16 + ec, o);
+      }
+    }
+  }
+  vm_wait();
+  lds_wait();
+  wg_barrier();
+  if (EPI != EPI_FINAL) team_arrive(tm);
+}
+
+// attention of one (sample, head) per wave: L <= 8 tokens, head_dim 64; qkv rows (3 D wide: q | k | v), o rows (D wide)
+__device__ __attribute__((noinline)) void attention_phase(const Team tm, const bf16_t* QKV, bf16_t* O, int nsamp, int H, int L, int D) {
+  DIT_LDS();
+  float* scratch = dit_lds + PART_OFF;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (wave == 0) team_wait(tm);
+  wg_barrier();
+  float* qf = scratch + wave * (3 * MAX_L * 68 + MAX_L * 8 + MAX_L);      // [8][68] x 3, p [8][8], l [8]
+  float* kf = qf + MAX_L * 68;
+  float* vf = kf + MAX_L * 68;
+  float* pf = vf + MAX_L * 68;
+  float* lf = pf + MAX_L * 8;
+  const int units = nsamp * H;
+  for (int u = tm.rank + TEAM * wave; u < units; u += TEAM * NWAVES) {
+    const int smp = u / H, h = u - smp * H;
+    const int i = lane >> 3, c = lane & 7;
+    const int ic = i < L ? i : L - 1;
+    const bf16_t* base = QKV + (int64_t)(smp * L + ic) * (3 * D) + h * 64 + c * 8;
+    u32x4 q4 = ldd16(base), k4 = ldd16(base + D), v4 = ldd16(base + 2 * D);
+    vm_wait();
+    pin(q4); pin(k4); pin(v4);
+    float a[8];
+    unpack8(q4, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[i * 68 + c * 8 + e] = a[e];
+    unpack8(k4, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kf[i * 68 + c * 8 + e] = a[e];
+    unpack8(v4, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vf[i * 68 + c * 8 + e] = a[e];
+    lds_wait();
+    // scores: lane (i, j)
+    const int j = c;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      const float4 qa = *reinterpret_cast<const float4*>(qf + i * 68 + d), ka = *reinterpret_cast<const float4*>(kf + j * 68 + d);
+      s = fmaf(qa.x, ka.x, s); s = fmaf(qa.y, ka.y, s); s = fmaf(qa.z, ka.z, s); s = fmaf(qa.w, ka.w, s);
+    }
+    const bool vis = i < L && j < L;
+    const float s2 = vis ? s * (0.125f * 1.4426950408889634f) : -INFINITY;      // head_dim 64: scale 1/8, log2 domain
+    float mx = s2;
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    const float M = ceilf(mx);                                                  // integer running maximum (csrc/attention.hip)
+    const float p = vis ? fast_exp2(s2 - M) : 0.f;
+    float l = p;
+    l += __shfl_xor(l, 1, 64); l += __shfl_xor(l, 2, 64); l += __shfl_xor(l, 4, 64);
+    pf[i * 8 + j] = bf2f(f2bf(p));
+    if (j == 0) lf[i] = l;
+    lds_wait();
+    // o[i][d], d = lane
+    for (int ii = 0; ii < L; ++ii) {
+      float o = 0.f;
+      for (int jj = 0; jj < L; ++jj) o = fmaf(pf[ii * 8 + jj], vf[jj * 68 + lane], o);
+      o = o / lf[ii];
+      const float hi = __shfl_down(o, 1, 64);
+      if ((lane & 1) == 0) std4(O + (int64_t)(smp * L + ii) * D + h * 64 + lane, pack2bf(o, hi));
+    }
+    lds_wait();
+  }
+  vm_wait();
+  wg_barrier();
+  team_arrive(tm);
+}
+
+// team member 0, between two sampler steps: [final LayerNorm + linear of step j - 1 -> guidance + DDIM update] -> token embedding
+// of step j.  xs: the sampler state (bs, T, C) fp32 in LDS; mo: the model output (R, 16) in LDS.
+template <int KS, int RB>
+__device__ __attribute__((noinline)) void step_boundary(const Team tm, const Args& a, int j) {
+  DIT_LDS();
+  float* mo = dit_lds + MO_OFF;
+  float* xs = dit_lds + XS_OFF;
+  const int t = threadIdx.x;
+  const int L = 2 * a.T, R = 2 * a.bs * L, per = a.T * a.C, n = a.bs * per;
+  if (j > 0) {
+    gemm_phase<KS, 1, RB, true, EPI_FINAL>(tm, a.final_w, a.final_b, a.C, a.X, a.D, nullptr, 0, R, a.eps);
+    const float ca = a.coef[4 * (j - 1)], cb = a.coef[4 * (j - 1) + 1], sp = a.coef[4 * (j - 1) + 2], sq = a.coef[4 * (j - 1) + 3];
+    for (int i = t; i < n; i += 64 * NWAVES) {
+      const int s = i / per, r = i - s * per, tok = r / a.C, c = r - tok * a.C;
+      const float cond = mo[(s * L + a.T + tok) * 16 + c], unc = mo[((s + a.bs) * L + a.T + tok) * 16 + c];
+      // csrc/elementwise.hip ddim_cfg_step_kernel, operation by operation
+      const float d = bf2f(f2bf(__fsub_rn(cond, unc)));
+      const float sd = bf2f(f2bf(__fmul_rn(a.cfg, d)));
+      const float e = bf2f(f2bf(__fadd_rn(unc, sd)));
+      const float ax = __fmul_rn(ca, xs[i]);
+      const float px = __fsub_rn(ax, __fmul_rn(cb, e));
+      const float e2 = __fdiv_rn(__fsub_rn(ax, px), cb);
+      const float xn = __fadd_rn(__fmul_rn(px, sp), __fmul_rn(sq, e2));
+      xs[i] = xn;
+      if (j == a.steps) {
+        const unsigned st = __hip_atomic_load(tm.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.out[i] = st ? __uint_as_float(0x7fc00000u) : xn;
+      }
+    }
+    __syncthreads();
+  } else {
+    if (tm.rank == 0) {
+      for (int i = t; i < n; i += 64 * NWAVES) xs[i] = a.noise[i];
+    }
+    __syncthreads();
+  }
+  if (j == a.steps) return;
+  // tokens of step j: row (s, i): i < T the condition tokens (z_emb + t_emb[j], precomputed) + pos; i >= T x_embedder(x) + pos
+  const int octs = a.D >> 3;
+  for (int idx = t; idx < R * octs; idx += 64 * NWAVES) {
+    const int row = idx / octs, oc = idx - row * octs, s = row / L, i = row - s * L, d0 = oc * 8;
+    float v[8], pv[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.pos + (int64_t)i * a.D + d0), pv);
+    if (i < a.T) {
+      unpack8(*reinterpret_cast<const u32x4*>(a.cond + ((int64_t)(j * 2 * a.bs + s) * a.T + i) * a.D + d0), v);
+    } else {
+      const float* xr = xs + ((s % a.bs) * a.T + (i - a.T)) * a.C;
+      float bv[8];
+      unpack8(*reinterpret_cast<const u32x4*>(a.xemb_b + d0), bv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float acc = 0.f;
+        for (int k = 0; k < a.C; ++k) acc = fmaf(bf2f(f2bf(xr[k])), bf2f(a.xemb_w[(int64_t)(d0 + e) * a.C + k]), acc);
+        v[e] = bf2f(f2bf(acc + bv[e]));
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = pack2bf(v[2 * q] + pv[2 * q], v[2 * q + 1] + pv[2 * q + 1]);
+    std16(a.X + (int64_t)row * a.D + d0, o);
+  }
+  vm_wait();
+  wg_barrier();
+  team_arrive(tm);
+}
+
+// KS = hidden / 256 (3: DiT-B, 4: DiT-L); RB = blocks of 16 token rows
+template <int KS, int RB>
+__global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel(Args a) {
+  DIT_LDS();
+  if ((blockIdx.x & 7) != 0) return;                 // the team: workgroups placed on XCC 0
+  constexpr int D = KS * 256;
+  constexpr int MT_QKV = (3 * D / 16 + TEAM - 1) / TEAM, MT_D = (D / 16 + TEAM - 1) / TEAM, MT_FC1 = (4 * D / 16 + TEAM - 1) / TEAM;
+  Team tm;
+  tm.ctr = a.ctr; tm.status = a.ctr + 32; tm.epoch = 0; tm.rank = (int)(blockIdx.x >> 3);
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<int*>(dit_lds + DEAD_OFF) = 0;
+    a.ctr[64 + tm.rank] = xcc_id();                  // diagnostics: where the team runs (all members on one XCC = the fast case)
+  }
+  __syncthreads();
+  const int L = 2 * a.T, R = 2 * a.bs * L;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  for (int j = 0; j <= a.steps; ++j) {
+    // exchange 0 of a step: the step boundary, on member 0.  The other members only pass through it -- but they WAIT for the
+    // previous exchange first: one counter serves all exchanges, so nobody may arrive twice before everybody has arrived once.
+    if (tm.rank == 0) {
+      step_boundary<KS, RB>(tm, a, j);
+    } else if (j < a.steps) {
+      if (j > 0) {
+        if (wave == 0) team_wait(tm);
+        wg_barrier();
+      }
+      team_arrive(tm);
+    }
+    if (j == a.steps) break;
+    tm.epoch += 1;
+    for (int l = 0; l < a.depth; ++l) {
+      const dvla_dit_block_weights bw = a.blocks[l];
+      gemm_phase<KS, MT_QKV, RB, true, EPI_BIAS>(tm, (const bf16_t*)bw.qkv_w, (const bf16_t*)bw.qkv_b, 3 * D, a.X, D, a.QKV, 3 * D, R, a.eps);
+      tm.epoch += 1;
+      attention_phase(tm, a.QKV, a.O, 2 * a.bs, a.H, L, D);
+      tm.epoch += 1;
+      gemm_phase<KS, MT_D, RB, false, EPI_BIAS_RES>(tm, (const bf16_t*)bw.proj_w, (const bf16_t*)bw.proj_b, D, a.O, D, a.X, D, R, a.eps);
+      tm.epoch += 1;
+      gemm_phase<KS, MT_FC1, RB, true, EPI_BIAS_GELU>(tm, (const bf16_t*)bw.fc1_w, (const bf16_t*)bw.fc1_b, 4 * D, a.X, D, a.HID, 4 * D, R, a.eps);
+      tm.epoch += 1;
+      gemm_phase<4 * KS, MT_D, RB, false, EPI_BIAS_RES>(tm, (const bf16_t*)bw.fc2_w, (const bf16_t*)bw.fc2_b, D, a.HID, 4 * D, a.X, D, R, a.eps);
+      tm.epoch += 1;
+    }
+  }
+  // The counters are reset BY THE TEAM, from the XCC that counts on them -- not by a memset node in front of the launch: under
+  // hipGraph replay a memset's zeros (written by another agent) were not reliably what this XCC's L2 served to the next launch's
+  // device-scope atomics (intermittent barriers that did not wait, round 4).  The last member to leave finds nobody polling.
+  if (threadIdx.x == 0) {
+    const unsigned left = __hip_atomic_fetch_add(a.ctr + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == TEAM - 1) {
+      __hip_atomic_store(a.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctr + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+size_t team_smem_bytes(int KS, int RB) {
+  const int D = KS * 256, mt_fc1 = (4 * D / 16 + TEAM - 1) / TEAM;
+  size_t part = (size_t)NWAVES * mt_fc1 * RB * 16 * LDP;
+  const size_t attn = (size_t)NWAVES * (3 * MAX_L * 68 + MAX_L * 8 + MAX_L);
+  if (attn > part) part = attn;
+  return (PART_OFF + part) * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" int64_t dvla_dit_sample_workspace_bytes(int32_t hidden) {
+  if (hidden <= 0) return 0;
+  return 1024 + (int64_t)32 * (1 + 3 + 1 + 4) * hidden * 2;
+}
+
+extern "C" int dvla_dit_sample(const dvla_dit_sample_params* q, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!q || !q->blocks || !q->xemb_w || !q->xemb_b || !q->final_w || !q->final_b || !q->pos || !q->cond || !q->coef || !q->noise ||
+      !q->out || !q->workspace)
+    return DVLA_ERR_ARG;
+  if (q->depth < 1 || q->steps < 1 || q->bs < 1 || q->tokens < 1 || q->channels < 1 || q->heads < 1) return DVLA_ERR_ARG;
+  const int L = 2 * q->tokens, R = 2 * q->bs * L;
+  const int KS = q->hidden / 256;
+  if (q->hidden % 256 != 0 || (KS != 3 && KS != 4) || q->heads * 64 != q->hidden || L > MAX_L || R > 32 || q->channels > 16 ||
+      q->bs * q->tokens * q->channels > 256 || (KS == 4 && R > 16))
+    return DVLA_ERR_UNSUPPORTED;
+  if (q->workspace_bytes < dvla_dit_sample_workspace_bytes(q->hidden) || (reinterpret_cast<uintptr_t>(q->workspace) & 15))
+    return DVLA_ERR_ARG;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return DVLA_ERR_LAUNCH;
+  if (cus < 8 * TEAM) return DVLA_ERR_UNSUPPORTED;      // the team is the 32 CUs of one XCD of a whole MI355X
+  Args a;
+  a.blocks = q->blocks;
+  a.xemb_w = (const bf16_t*)q->xemb_w; a.xemb_b = (const bf16_t*)q->xemb_b;
+  a.final_w = (const bf16_t*)q->final_w; a.final_b = (const bf16_t*)q->final_b;
+  a.pos = (const bf16_t*)q->pos; a.cond = (const bf16_t*)q->cond;
+  a.coef = q->coef; a.noise = q->noise; a.out = q->out;
+  char* ws = reinterpret_cast<char*>(q->workspace);
+  a.ctr = reinterpret_cast<unsigned*>(ws);
+  a.X = reinterpret_cast<bf16_t*>(ws + 1024);
+  a.QKV = a.X + (int64_t)32 * q->hidden;
+  a.O = a.QKV + (int64_t)32 * 3 * q->hidden;
+  a.HID = a.O + (int64_t)32 * q->hidden;
+  a.cfg = q->cfg_scale; a.eps = q->ln_eps;
+  a.depth = q->depth; a.D = q->hidden; a.H = q->heads; a.C = q->channels; a.T = q->tokens; a.bs = q->bs; a.steps = q->steps;
+  const int RB = R > 16 ? 2 : 1;
+  const size_t smem = team_smem_bytes(KS, RB);
+  // >= 80 KB of LDS per workgroup: one workgroup per CU, so that workgroup b lands on XCC b % 8 of an idle chip
+  const size_t lds = smem > 81920 ? smem : 81920;
+  const void* fn = KS == 3 ? (RB == 1 ? (const void*)dit_team_kernel<3, 1> : (const void*)dit_team_kernel<3, 2>) : (const void*)dit_team_kernel<4, 1>;
+  static bool attr_set[3] = {false, false, false};
+  const int slot = KS == 3 ? RB - 1 : 2;
+  if (!attr_set[slot]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DVLA_ERR_LAUNCH;
+    attr_set[slot] = true;
+  }
+  const dim3 grid((unsigned)(8 * TEAM)), block(64 * NWAVES);
+  if (KS == 3 && RB == 1) hipLaunchKernelGGL((dit_team_kernel<3, 1>), grid, block, lds, stream, a);
+  else if (KS == 3) hipLaunchKernelGGL((dit_team_kernel<3, 2>), grid, block, lds, stream, a);
+  else hipLaunchKernelGGL((dit_team_kernel<4, 1>), grid, block, lds, stream, a);
+  return dvla_check_launch();
+}

@@ -73,6 +73,59 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, void* C, 
         make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
   }
 }
+// the same reduction with the GEMM's epilogue on the sums: bias -> activation -> (+ residual, joined to the ROUNDED branch value
+// for bf16 outputs, like epilogue_oct) -> store.  8 columns per thread, N % 8 == 0, 16-byte aligned operands.
+struct SplitEpi {
+  const void* bias; int bias_f32; int act;
+  const bf16_t* residual; int64_t ld_res; int64_t res_rows;
+};
+__global__ void splitk_reduce_epi_kernel(const float* __restrict__ ws, void* C, int64_t ldc, int c_f32, int64_t M, int64_t N,
+                                         int splits, SplitEpi e) {
+  const int64_t octs = N >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * octs) return;
+  const int64_t m = idx / octs, n = (idx - m * octs) << 3;
+  const int64_t MN = M * N;
+  const float* src = ws + m * N + n;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < splits; ++k) {          // fixed order: deterministic
+    const float4 x = *reinterpret_cast<const float4*>(src + (int64_t)k * MN);
+    const float4 y = *reinterpret_cast<const float4*>(src + (int64_t)k * MN + 4);
+    v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
+  }
+  if (e.bias) {
+    if (e.bias_f32) {
+      const float4 b0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(e.bias) + n);
+      const float4 b1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(e.bias) + n + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    } else {
+      const uint4 b = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(e.bias) + n);
+      const uint32_t w[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[2 * i] += __uint_as_float(w[i] << 16); v[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u); }
+    }
+  }
+  act_fwd8(v, e.act);
+  if (e.residual) {
+    if (!c_f32) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = bf2f(f2bf(v[i]));
+    }
+    const int64_t rr = e.res_rows > 0 ? (int64_t)((uint32_t)m % (uint32_t)e.res_rows) : m;
+    const uint4 r = *reinterpret_cast<const uint4*>(e.residual + rr * e.ld_res + n);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] += __uint_as_float(w[i] << 16); v[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  if (c_f32) {
+    float* c = reinterpret_cast<float*>(C) + m * ldc + n;
+    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(C) + m * ldc + n) =
+        make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+  }
+}
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* C, int64_t ldc, int c_f32, int accumulate,
                                      int64_t M, int64_t N, int splits, KsumJob kj) {
   if (ksum_tail(kj)) return;
@@ -290,9 +343,18 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   if (q->accumulate && q->c_dtype != DVLA_DT_F32) return DVLA_ERR_ARG;
   if (q->dropout_p < 0.f || q->dropout_p >= 1.f) return DVLA_ERR_ARG;
   const int split_k = q->split_k > 1 ? q->split_k : 1;
+  // split-K: the partial sums go to the workspace raw; bias / activation / residual are applied by the reduction pass
+  // (splitk_reduce_epi_kernel: the forward GEMMs of the evaluation engine with few hundred rows and a long K)
+  const bool split_epi = split_k > 1 && (q->bias || q->act || q->residual);
   if (split_k > 1) {
-    if (!q->workspace || q->bias || q->act || q->preact || q->dact_aux || q->residual || q->dropout_p > 0.f)
-      return DVLA_ERR_ARG;
+    if (!q->workspace || q->preact || q->dact_aux || q->dropout_p > 0.f) return DVLA_ERR_ARG;
+    if (split_epi) {
+      if (q->accumulate || q->ksum_operand != 0) return DVLA_ERR_ARG;
+      const bool c_ok = q->c_dtype == DVLA_DT_F32 ? ((q->ldc % 4 == 0) && aligned(q->C, 16)) : ((q->ldc % 8 == 0) && aligned(q->C, 16));
+      if ((q->N & 7) != 0 || !aligned(q->workspace, 16) || !c_ok || (q->bias && !aligned(q->bias, 16)) ||
+          (q->residual && !((q->ld_res % 8 == 0) && aligned(q->residual, 16))))
+        return DVLA_ERR_UNSUPPORTED;
+    }
   }
   if (q->ksum_operand != 0) {
     if ((q->ksum_operand != 1 && q->ksum_operand != 2) || !q->ksum || !q->ksum_workspace) return DVLA_ERR_ARG;
@@ -332,6 +394,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   if (q->preact && !((q->ld_preact % 8 == 0) && aligned(q->preact, 16))) a.aux_vec = 0;
   if (q->dact_aux && !((q->ld_dact % 8 == 0) && aligned(q->dact_aux, 16))) a.aux_vec = 0;
   if (q->residual && !((q->ld_res % 8 == 0) && aligned(q->residual, 16))) a.aux_vec = 0;
+  if (split_epi) { a.bias = nullptr; a.act = 0; a.residual = nullptr; }      // (the main kernel writes raw partial sums)
   a.epi_vec = 1;  // bias / split-K workspace vector access
   if (q->bias && !aligned(q->bias, 16)) a.epi_vec = 0;
   if (split_k > 1 && ((q->N & 3) != 0 || !aligned(q->workspace, 16))) a.epi_vec = 0;
@@ -432,7 +495,13 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     const unsigned main_blocks = (unsigned)(((vec ? total / 8 : total) + 255) / 256);
     const unsigned tail_blocks = kj.partial ? (unsigned)((kj.len + 15) / 16) : 0u;
     if (kj.partial) kj.main_blocks = main_blocks;
-    if (vec)
+    if (split_epi) {
+      SplitEpi e;
+      e.bias = q->bias; e.bias_f32 = q->bias_dtype == DVLA_DT_F32; e.act = q->act;
+      e.residual = reinterpret_cast<const bf16_t*>(q->residual); e.ld_res = q->ld_res; e.res_rows = q->res_rows;
+      hipLaunchKernelGGL(splitk_reduce_epi_kernel, dim3(main_blocks), dim3(256), 0, stream, a.workspace, q->C, q->ldc, a.c_f32, q->M,
+                         q->N, split_k, e);
+    } else if (vec)
       hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, stream,
                          a.workspace, q->C, q->ldc, a.c_f32, q->accumulate, q->M, q->N, split_k, kj);
     else

@@ -481,12 +481,16 @@ class DreamVLA(nn.Module):
 
         return [text_embedding, state_embedding, image_primary_embedding, image_wrist_embedding, cls_primary, cls_wrist]
 
-    def decode_tokens(self, parts, action_label=None, mode='train', test_noise=None):
+    def decode_tokens(self, parts, action_label=None, mode='train', test_noise=None, test_select=None):
         """Token assembly with the prediction queries, trunk, dream heads (train) and action head
         (dreamvla_model.py:739-991).  `parts`: the list from `encode_frames`, or one (B, S, 36, H) tensor of them.
         `test_noise` (B*S, action_pred_steps, 7), mode='test' with the DiT head only: the sampler's start noise as an INPUT
         (the reference draws it with torch.randn inside forward, dreamvla_model.py:941) -- what lets a hipGraph-captured
-        decode take fresh noise per replay and lets a parity test feed the reference's own draw."""
+        decode take fresh noise per replay and lets a parity test feed the reference's own draw.
+        `test_select` (B,) int64 on the device, mode='test' with the DiT head only: sample the action of ONE window position
+        per sequence (the position the evaluation wrapper executes, utils/eval_utils_calvin.py:141-146) instead of all S --
+        the sampler's batch elements are independent, so the selected position's samples are those of the full call from the
+        same noise rows; the action outputs are then (1, B, steps, .) and `test_noise` is (B, steps, 7)."""
         if torch.is_tensor(parts):
             parts = [parts]
         else:
@@ -607,8 +611,14 @@ class DreamVLA(nn.Module):
                 arm_pred_action = self.action_model.loss(labels.repeat(r, 1, 1), feat.repeat(r, 1, 1))
                 gripper_pred_action = arm_pred_action
             elif mode == 'test':
-                bs = n
-                cond = action_pred_feature.flatten(0, 1)
+                if test_select is None:
+                    bs = n
+                    cond = action_pred_feature.flatten(0, 1)
+                else:
+                    if tuple(test_select.shape) != (B,):
+                        raise ValueError(f"test_select {tuple(test_select.shape)}: expected ({B},)")
+                    bs = B
+                    cond = action_pred_feature[torch.arange(B, device=test_select.device), test_select]
                 cfg_scale = 1.5
                 if test_noise is None:
                     noise = torch.randn(bs, self.action_pred_steps, self.action_model.in_channels,

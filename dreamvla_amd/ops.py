@@ -83,6 +83,23 @@ def next_seed():
 # ---------------------------------------------------------------------------------------------------
 # raw kernel launchers (no autograd)
 # ---------------------------------------------------------------------------------------------------
+FWD_SPLIT_K = os.environ.get("DVLA_FWD_SPLIT_K", "1") != "0"
+
+
+def fwd_split_k(M, N, K, cus=256):
+    """Split-K for a FORWARD GEMM (bias / activation / residual applied by the reduction pass, include/dvla.h): the evaluation
+    engine's trunk at one episode has 930 rows, and its MLP down-projection (N = 1024, K = 4096) is 64 tiles of 128 x 128
+    that each walk all of K -- 43.6 us on a quarter of the chip (profiles/r04_midrows_perf.jsonl).  Only where the few-rows
+    kernel does not apply (M > 512), the output leaves most CUs idle (<= 96 tiles) and K is long enough to pay for the
+    reduction launch: then K is cut so that tiles x splits ~ the CU count, at least 1024 deep per split."""
+    if M <= 512 or K < 2048:
+        return 1
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles > 96:
+        return 1
+    return max(1, min(K // 1024, cus // tiles, 8))
+
+
 def auto_split_k(M, N, K, cus=256):
     """weight-gradient GEMMs: small output (M x N), very long contraction (K = tokens).  The kernels that run them tile the
     output in 256 x 256 (persistent, one workgroup per CU), so the number of work items tiles * split_k should land just
@@ -285,6 +302,11 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
         p.residual, p.ld_res, p.res_rows = residual.data_ptr(), residual.stride(0), int(res_rows)
     p.accumulate = int(accumulate)
     p.split_k = max(1, int(split_k))
+    if split_k is None or int(split_k) == 0:
+        p.split_k = 1
+    if (FWD_SPLIT_K and p.split_k == 1 and split_k != 0 and not a_trans and not want_preact and dact_aux is None and dropout_p == 0.0
+            and not accumulate and ksum is None and a_ln_eps is None and variant is None and N % 8 == 0):
+        p.split_k = fwd_split_k(M, N, K)      # few hundred rows, long K: the evaluation engine's trunk (see fwd_split_k)
     ksum_ws = None
     if ksum is not None:
         which, kout = ksum
@@ -494,6 +516,66 @@ def ddim_cfg_step(model_out, x, cfg_scale, a, b, sqrt_acp_prev, sqrt_1m_acp_prev
     check(lib.dvla_ddim_cfg_step(model_out.data_ptr(), int(model_out.stride(0)), x.data_ptr(), out.data_ptr(), bs, per,
                                  float(cfg_scale), float(a), float(b), float(sqrt_acp_prev), float(sqrt_1m_acp_prev), _stream()),
           "dvla_ddim_cfg_step")
+    return out
+
+
+# The whole evaluation sampler of the DiT head in one launch (csrc/dit_team.hip, include/dvla.h dvla_dit_sample)
+DIT_TEAM = os.environ.get("DVLA_DIT_TEAM", "1") != "0"        # 0: always the launch-by-launch sampler (measurement / A-B)
+_DIT_TEAM_CUS = {}
+
+
+def dit_team_ok(hidden, heads, channels, tokens, bs, device):
+    """the shapes dvla_dit_sample takes (everything else runs the launch-by-launch sampler): DiT-B / DiT-L at head_dim 64,
+    at most 8 tokens per sequence and 32 token rows (16 at hidden 1024) -- one or two episodes -- on a whole MI355X"""
+    if not DIT_TEAM or device.type != "cuda":
+        return False
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _DIT_TEAM_CUS:
+        _DIT_TEAM_CUS[key] = torch.cuda.get_device_properties(key).multi_processor_count
+    rows = 4 * bs * tokens
+    return (hidden in (768, 1024) and heads * 64 == hidden and 2 * tokens <= 8 and rows <= (32 if hidden == 768 else 16)
+            and channels <= 16 and bs * tokens * channels <= 256 and _DIT_TEAM_CUS[key] >= 256)
+
+
+def dit_team_workspace(hidden, device):
+    n = int(_lib.load().dvla_dit_sample_workspace_bytes(int(hidden)))
+    return torch.zeros(n, dtype=torch.uint8, device=device)
+
+
+def dit_team_status(workspace):
+    """(status, xcc_mask) of the last dvla_dit_sample launch on this workspace -- synchronises.  status 0 = every exchange
+    completed; xcc_mask: bit i set = a team member ran on XCC i (one bit = the team shared one L2: the fast case)."""
+    w = workspace[:384].view(torch.int32).cpu()
+    mask = 0
+    for x in w[64:96].tolist():
+        mask |= 1 << (x & 15)
+    return int(w[32]), mask
+
+
+def dit_team_sample(block_ptrs, depth, hidden, heads, xemb_w, xemb_b, final_w, final_b, pos, cond, coef, noise, cfg_scale, ln_eps,
+                    workspace):
+    """block_ptrs: int64 device tensor (depth, 8) of bf16 weight addresses (qkv w, b, proj w, b, fc1 w, b, fc2 w, b);
+    cond (steps, 2 bs, T, hidden) bf16; coef (steps, 4) fp32; noise (bs, T, C) fp32.  Returns the samples (bs, T, C) fp32."""
+    lib = _lib.load()
+    for t, nm in ((xemb_w, "xemb_w"), (xemb_b, "xemb_b"), (final_w, "final_w"), (final_b, "final_b"), (pos, "pos"), (cond, "cond")):
+        _req(t, "dit_team_sample." + nm)
+        if t.dtype != BF16 or not t.is_contiguous():
+            raise ValueError(f"dit_team_sample.{nm}: contiguous bf16")
+    if coef.dtype != torch.float32 or noise.dtype != torch.float32 or not coef.is_contiguous() or not noise.is_contiguous():
+        raise ValueError("dit_team_sample: coef / noise contiguous fp32")
+    steps, two_bs, T = cond.shape[0], cond.shape[1], cond.shape[2]
+    bs, Cn = noise.shape[0], noise.shape[2]
+    if two_bs != 2 * bs or noise.shape[1] != T or tuple(coef.shape) != (steps, 4) or tuple(block_ptrs.shape) != (depth, 8):
+        raise ValueError("dit_team_sample: shapes")
+    out = torch.empty_like(noise)
+    p = _lib.DitSampleParams()
+    p.blocks = block_ptrs.data_ptr()
+    p.xemb_w, p.xemb_b, p.final_w, p.final_b = xemb_w.data_ptr(), xemb_b.data_ptr(), final_w.data_ptr(), final_b.data_ptr()
+    p.pos, p.cond, p.coef, p.noise, p.out = pos.data_ptr(), cond.data_ptr(), coef.data_ptr(), noise.data_ptr(), out.data_ptr()
+    p.workspace, p.workspace_bytes = workspace.data_ptr(), workspace.numel()
+    p.cfg_scale, p.ln_eps = float(cfg_scale), float(ln_eps)
+    p.depth, p.hidden, p.heads, p.channels, p.tokens, p.bs, p.steps = int(depth), int(hidden), int(heads), int(Cn), int(T), int(bs), int(steps)
+    check(lib.dvla_dit_sample(C.byref(p), _stream()), "dvla_dit_sample")
     return out
 
 

@@ -59,7 +59,7 @@ class _Graphed:
 
 
 class RolloutEngine:
-    def __init__(self, model, batch_size, history_len=None, use_graph=True, warmup_decodes=3):
+    def __init__(self, model, batch_size, history_len=None, use_graph=True, warmup_decodes=3, sample="newest"):
         self.model = model.module if hasattr(model, "module") else model
         m = self.model
         if m.training:
@@ -78,6 +78,12 @@ class RolloutEngine:
         self._text_ref = self._text_tok = self._text_emb = None
         self.text_encodes = 0                                             # how often the text tower actually ran
         self.needs_noise = bool(getattr(m, "use_dit_head", False))       # the MLP action head samples nothing
+        if sample not in ("newest", "all"):
+            raise ValueError('sample: "newest" (the sampler runs on the window position the wrapper executes) or "all"')
+        # The reference samples an action for every window position and executes one (eval_utils_calvin.py:141-146).  The
+        # sampler's batch elements are independent, so "newest" -- DDIM over B rows instead of B * S -- returns the same
+        # executed action from the same noise row; "all" keeps the reference's (B, S, steps, .) action outputs.
+        self.sample_all = (sample == "all") or not self.needs_noise
         self._no_noise = torch.zeros(1, device=self.device)
         self._decode_g = _Graphed(self._decode_eager, warmup_decodes) if self.use_graph else None
         self._encode_g = _Graphed(self._encode_eager, warmup_decodes) if self.use_graph else None
@@ -144,21 +150,23 @@ class RolloutEngine:
         self.count = torch.clamp(k + 1, max=S)
 
     # ------------------------------------------------------------------------------------------------------------
-    def _decode_eager(self, tokens, noise):
-        out = self.model.decode_tokens(tokens, mode="test", test_noise=noise if self.needs_noise else None)
+    def _decode_eager(self, tokens, noise, sel):
+        out = self.model.decode_tokens(tokens, mode="test", test_noise=noise if self.needs_noise else None,
+                                       test_select=None if self.sample_all else sel)
         return out[0], out[1]
 
     @torch.no_grad()
-    def _decode(self, tokens, noise):
-        return (self._decode_g if self.use_graph else self._decode_eager)(tokens, noise)
+    def _decode(self, tokens, noise, sel):
+        return (self._decode_g if self.use_graph else self._decode_eager)(tokens, noise, sel)
 
     def draw_noise(self, generator=None):
-        """start noise of the action sampler for one control step, (B*S, action_pred_steps, 7) float32 on the device -- what
-        the reference draws inside forward (dreamvla_model.py:941).  It is an INPUT of the captured decode graph (a graph replays
-        its kernels, not its random draws), drawn here per step unless the caller passes its own to `step`."""
+        """start noise of the action sampler for one control step, float32 on the device: (B*S, action_pred_steps, 7) -- what
+        the reference draws inside forward (dreamvla_model.py:941) -- with sample="all", (B, action_pred_steps, 7) with
+        "newest".  It is an INPUT of the captured decode graph (a graph replays its kernels, not its random draws), drawn here
+        per step unless the caller passes its own to `step`."""
         m = self.model
-        return torch.randn(self.B * self.S, m.action_pred_steps, m.action_model.in_channels, device=self.device,
-                           generator=generator)
+        rows = self.B * self.S if self.sample_all else self.B
+        return torch.randn(rows, m.action_pred_steps, m.action_model.in_channels, device=self.device, generator=generator)
 
     @property
     def graphs_captured(self):
@@ -168,7 +176,9 @@ class RolloutEngine:
     def step(self, image_primary, image_wrist, state, text_token, noise=None):
         """One control step of every episode.  Returns (action (B, 7) float32 on the device: 6 arm values and the
         gripper command in {-1, +1} as ModelWrapper.step builds it (eval_utils_calvin.py:136-146), arm (B,S,steps,6),
-        gripper (B,S,steps,1)).  `noise`: the DiT sampler's start noise (see draw_noise); None = drawn here."""
+        gripper (B,S,steps,1); with the DiT head and sample="newest" the last two are (B,1,steps,.): the executed position
+        only).  `noise`: the DiT sampler's start noise (see draw_noise; a (B*S, steps, 7) draw is accepted with "newest" too --
+        the executed position's rows are taken); None = drawn here."""
         dt = self.dtype
         new_tok = self.encode_newest(image_primary.to(self.device, dt), image_wrist.to(self.device, dt),
                                      state.to(self.device, dt), text_token.to(self.device))
@@ -176,18 +186,24 @@ class RolloutEngine:
         # the wrapper conditions EVERY frame of the window on the current instruction (eval_utils_calvin.py:127-134 repeat the
         # text over the window), so the text token (slot 0 of a frame's 36) is not history: all S frames carry today's embedding
         self.tokens[:, :, 0] = self._text_emb.to(self.tokens.dtype).unsqueeze(1)
+        B, S = self.B, self.S
+        sel = (self.count - 1).to(self.device)                               # newest real frame of each episode
+        bi = torch.arange(B, device=self.device)
         if not self.needs_noise:
             noise = self._no_noise
         elif noise is None:
             noise = self.draw_noise()
         else:
             noise = noise.to(self.device, torch.float32)
-        arm, grip = self._decode(self.tokens, noise)
-        B, S = self.B, self.S
-        if arm.dim() == 4 and arm.shape[0] == 1 and B * S == arm.shape[1]:   # DiT test head returns (1, B*S, steps, .)
+            if not self.sample_all and noise.shape[0] == B * S and S > 1:
+                noise = noise.view(B, S, *noise.shape[1:])[bi, sel]
+        arm, grip = self._decode(self.tokens, noise, sel)
+        if arm.dim() == 4 and arm.shape[0] == 1 and B * S == arm.shape[1] and self.sample_all:   # DiT test head returns (1, B*S, steps, .)
             arm, grip = arm.view(B, S, *arm.shape[2:]), grip.view(B, S, *grip.shape[2:])
-        sel = (self.count - 1).to(self.device)                               # newest real frame of each episode
-        bi = torch.arange(B, device=self.device)
+        elif arm.dim() == 4 and arm.shape[0] == 1 and not self.sample_all:                        # (1, B, steps, .)
+            arm, grip = arm.view(B, 1, *arm.shape[2:]), grip.view(B, 1, *grip.shape[2:])
+        if not self.sample_all:
+            sel = torch.zeros_like(sel)
         a = arm[bi, sel, 0, :].float()
         g = (grip[bi, sel, 0, :].float() > 0.5).float()
         action = torch.cat((a, (g - 0.5) * 2), dim=-1)

@@ -38,8 +38,8 @@ extern "C" {
 /* ABI revision of this header; dreamvla_amd/_lib.py refuses a library that reports another one (a stale prebuilt .so then fails
  * with a clear message instead of a missing-symbol error).  3 = round 3 (dvla_last_gemm_variant, variant 10, ...); 4 = k-sums on the
  * weight-gradient GEMM (ksum_* fields of dvla_gemm_params); 5 = dvla_ddim_cfg_step, dvla_act_bwd_colsum, a_layernorm,
- * GEMM configuration 11. */
-#define DVLA_ABI_VERSION 5
+ * GEMM configuration 11; 6 = dvla_dit_sample (the evaluation sampler as one persistent kernel). */
+#define DVLA_ABI_VERSION 6
 int dvla_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -231,6 +231,40 @@ int dvla_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream);
  * model_out + (bs + i) * sample_stride, per_sample contiguous values each; x, x_next: fp32 (bs, per_sample) contiguous. */
 int dvla_ddim_cfg_step(const void* model_out, int64_t sample_stride, const float* x, float* x_next, int64_t bs, int64_t per_sample,
                        float cfg_scale, float a, float b, float sqrt_acp_prev, float sqrt_1m_acp_prev, void* stream);
+/* The WHOLE evaluation sampler of the DiT action head in one launch (models/dreamvla_model.py:935-987: ddim_sample_loop over
+ * net.forward_with_cfg, eta = 0; models/action_model/models.py:162-268 DiT.forward / forward_with_cfg; gaussian_diffusion.py:
+ * 522-569 ddim_sample): `steps` x { token embedding, `depth` DiT blocks, final layer, guidance + DDIM update } on 2 bs sequences
+ * of 2 tokens tokens (the guided and the unguided half of every sample), as a persistent kernel on the 32 CUs of one XCD whose
+ * workgroups exchange activations through that XCD's L2 (csrc/dit_team.hip; tests/probes/sync_probe.cpp has the measurements
+ * behind the design).  Same arithmetic and rounding points as the launch-by-launch path (ActionModel.sample_ddim_cfg: few-rows
+ * GEMMs with LayerNorm on the fly, flash attention, dvla_ddim_cfg_step), other fp32 summation order inside the products.
+ *   blocks     device array of `depth` entries: bf16 weights in nn.Linear layout (out, in), bf16 biases
+ *   xemb_*     x_embedder Linear(channels -> hidden); final_*: final_layer.linear (hidden -> channels); pos (2 tokens, hidden)
+ *   cond       (steps, 2 bs, tokens, hidden) bf16: z_embedder([cond ; uncondition]) + t_embedder(timestep of step j), j = 0 the
+ *              FIRST sampler step (the largest timestep)
+ *   coef       (steps, 4) fp32 on the device: a, b, sqrt_acp_prev, sqrt_1m_acp_prev of dvla_ddim_cfg_step per sampler step
+ *   noise/out  (bs, tokens, channels) fp32: start noise / samples (NaN if a wait inside the kernel timed out)
+ *   workspace  dvla_dit_sample_workspace_bytes(hidden) bytes, 16-byte aligned, ZERO-INITIALISED by the caller once (the kernel
+ *              leaves its counters at zero); 32-bit word 32 = status (0 ok; sticky), words 64 .. 95 = the XCC id each of the 32
+ *              team members ran on in the last launch (all equal = the fast case), valid after a launch
+ * DVLA_ERR_UNSUPPORTED unless hidden in {768, 1024}, head_dim 64, 2 tokens <= 8, 4 bs tokens <= 32 rows (<= 16 at hidden 1024),
+ * channels <= 16, on a device with 256 CUs: the caller then runs the launch-by-launch sampler. */
+typedef struct dvla_dit_block_weights {
+  const void *qkv_w, *qkv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} dvla_dit_block_weights;
+typedef struct dvla_dit_sample_params {
+  const dvla_dit_block_weights* blocks;
+  const void *xemb_w, *xemb_b, *final_w, *final_b, *pos, *cond;
+  const float* coef;
+  const float* noise;
+  float* out;
+  void* workspace;
+  int64_t workspace_bytes;
+  float cfg_scale, ln_eps;
+  int32_t depth, hidden, heads, channels, tokens, bs, steps, reserved;
+} dvla_dit_sample_params;
+int64_t dvla_dit_sample_workspace_bytes(int32_t hidden);
+int dvla_dit_sample(const dvla_dit_sample_params* p, void* stream);
 /* dst(bf16) = src(fp32) / dst(fp32) = src(bf16) */
 int dvla_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dvla_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

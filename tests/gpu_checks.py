@@ -155,6 +155,57 @@ def check_act_bwd_colsum(rows, cols, act="none", dropout_p=0.0, out_bf16=False, 
             metrics(tag + " column sums", db, want, TOL_FWD if out_bf16 else 1e-5, round_ref=out_bf16)]
 
 
+def check_dit_team(bs=1, model_type="DiT-B", seeds=(0, 1, 2, 3)):
+    """dvla_dit_sample -- the evaluation sampler (DDIM-10 + CFG through all DiT blocks) as one persistent kernel on one XCD --
+    against the launch-by-launch sampler (ActionModel.sample_ddim_cfg with team_sampler = False: few-rows GEMMs, flash attention,
+    dvla_ddim_cfg_step) and the fp32 oracle of the loop (oracle/model_ref.py ddim_sample, the model's bf16 weights in fp32).
+    Both HIP paths are bf16 computations of the same function with the same rounding points; ten sampler steps amplify their
+    rounding noise alike, so the persistent kernel's deviation from the fp32 samples may be at most 1.5 x the launch-by-launch
+    path's (pooled over the seeds) -- and it must be bit-reproducible, finish every exchange, and run on one XCC."""
+    from dreamvla_amd import ops
+    from dreamvla_amd.action_model.action_model import ActionModel
+    from oracle import model_ref, weights
+    depth, heads = {"DiT-B": (12, 12), "DiT-L": (24, 16)}[model_type]
+    am = ActionModel(token_size=1024, model_type=model_type, in_channels=7, future_action_window_size=2, past_action_window_size=0)
+    am.load_state_dict(weights.fill_state_dict(am.state_dict()), strict=True)
+    am = am.to(BF).to(DEV).eval()
+    am.create_ddim(10)
+    sd32 = {k: v.float().cpu() for k, v in am.state_dict().items()}
+    tag = f"dit_team {model_type} bs{bs}"
+    hidden = am.net.x_embedder.linear.out_features
+    taken = ops.dit_team_ok(hidden, heads, 7, 3, bs, torch.device(DEV, torch.cuda.current_device()))
+    res = [{"name": tag + ": shape taken by the persistent kernel", "rel_l2": 0.0, "tol": 0.0, "ok": bool(taken)}]
+    num_t = num_l = num_p = den = 0.0
+    worst_pair = 0.0
+    for sd in seeds:
+        g = torch.Generator().manual_seed(700 + sd)
+        cond = rnd((bs, 3, 1024), g).to(DEV, BF)
+        noise = rnd((bs, 3, 7), g).to(BF).float().to(DEV)
+        am.team_sampler = True
+        out_t = am.sample_ddim_cfg(cond, noise, 1.5)
+        out_t2 = am.sample_ddim_cfg(cond, noise, 1.5)
+        am.team_sampler = False
+        out_l = am.sample_ddim_cfg(cond, noise, 1.5)
+        with torch.no_grad():
+            ref = model_ref.ddim_sample(sd32, "net", cond.float().cpu(), noise.cpu(), 1.5, depth=depth, heads=heads)
+        if sd == seeds[0]:
+            res.append({"name": tag + ": finite, bit-reproducible", "rel_l2": 0.0, "tol": 0.0,
+                        "ok": bool(torch.isfinite(out_t).all()) and bool(torch.equal(out_t, out_t2))})
+        t, l = out_t.float().cpu(), out_l.float().cpu()
+        num_t += float(((t - ref) ** 2).sum()); num_l += float(((l - ref) ** 2).sum()); num_p += float(((t - l) ** 2).sum())
+        den += float((ref ** 2).sum())
+        worst_pair = max(worst_pair, float((t - l).abs().max()))
+    e_t, e_l, e_p = (num_t / den) ** 0.5, (num_l / den) ** 0.5, (num_p / den) ** 0.5
+    res.append({"name": tag + f": rel-L2 to the fp32 samples, persistent kernel (launch-by-launch: {e_l:.3e})", "rel_l2": e_t,
+                "tol": 1.5 * e_l + 1e-3, "ok": e_t <= 1.5 * e_l + 1e-3})
+    res.append({"name": tag + ": persistent kernel vs launch-by-launch", "rel_l2": e_p, "tol": 2.5 * e_l + 1e-3, "max_abs": worst_pair,
+                "ok": e_p <= 2.5 * e_l + 1e-3})
+    mask = int(getattr(am, "team_xcc_mask", 0))
+    res.append({"name": tag + f": team ran on one XCC (mask {mask:#x})", "rel_l2": float(bin(mask).count("1")), "tol": 1.0,
+                "ok": bin(mask).count("1") == 1})
+    return res
+
+
 def check_gemm_tail(**kw):
     """the phase kernel with a PARTIAL last K-tile (gemm_phase.h DBG & 128: K % 64 = 16 / 32 / 48, k-major operands, fp32 class):
     forced configuration 8 + the assertion that it ran -- before round 4 such a problem fell back to the BK-32 ring kernel"""
@@ -802,6 +853,15 @@ def all_checks(quick=False):
         (check_act_bwd_colsum, dict(rows=333, cols=520, act="relu")),                              # ragged strip (520 = 512 + 8)
         (check_act_bwd_colsum, dict(rows=7, cols=64, dropout_p=0.5)),                              # fewer rows than row slabs
         (check_act_bwd_colsum, dict(rows=100, cols=36, dropout_p=0.1)),                            # cols % 8 != 0: not taken
+        # split-K with the epilogue in the reduction pass (forward GEMMs of the evaluation engine's trunk at one episode)
+        (check_gemm, dict(M=930, N=1024, K=4096, b_trans=True, bias=True, residual=True, split_k=4)),   # GPT-2 MLP down-projection, Conv1D
+        (check_gemm, dict(M=930, N=1024, K=4096, b_trans=True, bias=True, residual=True)),             # ... as ops.gemm splits it by itself
+        (check_gemm, dict(M=651, N=1024, K=4096, bias=True, act="gelu_tanh", split_k=2, variant=6)),
+        (check_gemm, dict(M=700, N=520, K=2048, bias=True, act="relu", residual=True, split_k=2)),      # ragged tiles
+        (check_gemm, dict(M=600, N=256, K=2048, residual=True, out_f32=True, split_k=3)),
+        (check_dit_team, dict(bs=1, model_type="DiT-B")),                                           # one episode: 12 token rows
+        (check_dit_team, dict(bs=2, model_type="DiT-B", seeds=(0, 1))),                            # 24 rows: two row blocks
+        (check_dit_team, dict(bs=1, model_type="DiT-L", seeds=(0, 1))),                            # hidden 1024, 24 blocks
         (check_gemm_tail, dict(M=256, N=256, K=160, out_f32=True)),                                # 2.5 K-tiles
         (check_gemm_tail, dict(M=512, N=256, K=208, out_f32=True)),                                # tail of one k16-step
         (check_gemm_tail, dict(M=256, N=768, K=1264, out_f32=True)),                               # tail of three, 19.75 K-tiles

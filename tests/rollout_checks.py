@@ -43,7 +43,7 @@ MLP_TOL = 1.25 * 6.78e-3      # fixture A: the reference's own `--precision bf16
 PAIR = 2.0
 
 
-def gpu_rollout_checks(head="mlp", use_graph=True, steps=7):
+def gpu_rollout_checks(head="mlp", use_graph=True, steps=7, sample="all"):
     """engine vs full-window forward of the HIP module on cuda (same start noise through both), B = 3 episodes, S = 4, one
     episode reset mid-way: queue semantics + cache + graph replay.  Every step compares the ACTIONS (no finite-only branch)."""
     from dreamvla_amd.dreamvla_model import DreamVLA
@@ -60,7 +60,8 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7):
     m = m.to(BF).to("cuda")
     m._init_model_type()
     m.eval()
-    eng = RolloutEngine(m, B, use_graph=use_graph, warmup_decodes=2)
+    eng = RolloutEngine(m, B, use_graph=use_graph, warmup_decodes=2, sample=sample)
+    newest = (sample == "newest" and head == "dit")      # the sampler runs on the executed position only (same noise rows)
     g = torch.Generator().manual_seed(5)
     text = torch.randint(1, 49000, (B, 77), generator=g)
     text[:, 20] = 49407
@@ -91,25 +92,31 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7):
             ra, rg = ra.view(B, S, 3, 6), rg.view(B, S, 3, 1)
         want = torch.stack([ra[b, picks[b], 0].float() for b in range(B)])
         got = action[:, :6]
-        tag = f"rollout.{head}.graph{int(use_graph)}.t{t}"
+        tag = f"rollout.{head}.graph{int(use_graph)}{'.newest' if newest else ''}.t{t}"
         ok_sel = bool((eng.count - 1 == torch.tensor(picks)).all())
         res.append({"name": tag + ".window_pick", "rel_l2": 0.0, "tol": 0.0, "ok": ok_sel})
         finite = bool(torch.isfinite(action).all()) and bool(((action[:, 6].abs() - 1).abs() < 1e-6).all())
         res.append({"name": tag + ".finite", "rel_l2": 0.0, "tol": 0.0, "ok": finite})
         r = float((got - want).norm() / max(float(want.norm()), 1e-12))
         res.append({"name": tag + ".action", "rel_l2": r, "tol": tol, "ok": r <= tol})
+        if newest:         # (B, 1, steps, .): all action_pred_steps of the executed position
+            ra = torch.stack([ra[b, picks[b]] for b in range(B)]).unsqueeze(1)
+            rg = torch.stack([rg[b, picks[b]] for b in range(B)]).unsqueeze(1)
+            res.append({"name": tag + ".shapes", "rel_l2": 0.0, "tol": 0.0,
+                        "ok": tuple(arm.shape) == (B, 1, 3, 6) and tuple(grip.shape) == (B, 1, 3, 1)})
+        which = "executed_position" if newest else "all_positions"
         r2 = float((arm.float() - ra.float()).norm() / max(float(ra.float().norm()), 1e-12))
-        res.append({"name": tag + ".arm_all_positions", "rel_l2": r2, "tol": tol, "ok": r2 <= tol})
+        res.append({"name": tag + ".arm_" + which, "rel_l2": r2, "tol": tol, "ok": r2 <= tol})
         r3 = float((grip.float() - rg.float()).norm() / max(float(rg.float().norm()), 1e-12))
-        res.append({"name": tag + ".gripper_all_positions", "rel_l2": r3, "tol": tol, "ok": r3 <= tol})
+        res.append({"name": tag + ".gripper_" + which, "rel_l2": r3, "tol": tol, "ok": r3 <= tol})
         if use_graph and t >= 2:                   # two eager warm-up decodes, then the capture: later steps are replays
             res.append({"name": tag + ".graph_replayed", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
-    res.append({"name": f"rollout.{head}.graph{int(use_graph)}: text tower ran once per instruction ({eng.text_encodes} of {steps} steps)",
+    res.append({"name": f"rollout.{head}.graph{int(use_graph)}{'.newest' if newest else ''}: text tower ran once per instruction ({eng.text_encodes} of {steps} steps)",
                 "rel_l2": float(eng.text_encodes), "tol": 2.0, "ok": eng.text_encodes == 2})
     return res
 
 
-def gpu_rollout_vs_reference(name, use_graph=True):
+def gpu_rollout_vs_reference(name, use_graph=True, sample="all"):
     """The engine against the REAL reference: fixture `name` (B, E, F: S = 2, 2 layers; C: S = 7, 24 layers; R: S = 10, 24
     layers = the configuration bench.py's rollout leg times) holds fx["test"], the real reference's `mode="test"` outputs
     on a full window with a recorded start noise (oracle/make_golden.py).  The window's S frames are pushed through the
@@ -117,7 +124,9 @@ def gpu_rollout_vs_reference(name, use_graph=True):
     engine's window IS the fixture's window, and its sampled actions -- DDIM-10 + CFG (or the flow-matching Euler loop)
     from the recorded noise, decode replayed from the hipGraph -- are compared with the reference's at 1.25 x the
     reference's own bf16 deviation of that sampler run.  Earlier steps (padded windows) are compared with the HIP
-    module's full-window forward on the same padded window and noise."""
+    module's full-window forward on the same padded window and noise.
+    sample="newest" (the engine's default): the sampler runs on the executed window position only, from that position's row
+    of the recorded noise -- compared with the same position of the reference's full-window outputs."""
     from dreamvla_amd.rollout import RolloutEngine
     from tests.model_checks import BF, build_hip_model, compare_outputs, golden_inputs, load
     fx = load(f"dreamvla_{name}.pt")
@@ -128,7 +137,8 @@ def gpu_rollout_vs_reference(name, use_graph=True):
     m.eval()
     inp = {k: v.to("cuda") for k, v in golden_inputs(fx).items()}
     ip, iw, st, tx = inp["image_primary"].to(BF), inp["image_wrist"].to(BF), inp["state"].to(BF), inp["text_token"]
-    eng = RolloutEngine(m, 1, use_graph=use_graph, warmup_decodes=1)     # step 1 eager, capture at step 2, replays afterwards
+    eng = RolloutEngine(m, 1, use_graph=use_graph, warmup_decodes=1, sample=sample)     # step 1 eager, capture at step 2, replays afterwards
+    newest = (sample == "newest") and eng.needs_noise
     tn = fx["test_noise"].to("cuda")
     tol_arm, tol_grip = _fixture_tols(name)
     res = []
@@ -137,11 +147,23 @@ def gpu_rollout_vs_reference(name, use_graph=True):
         last = k == S - 1
         noise = tn if last else torch.randn(tn.shape, generator=g).to(BF).float().to("cuda")
         action, arm, grip = eng.step(ip[:, k], iw[:, k], st[:, k], tx[:, k], noise=noise)
-        tag = f"rollout.ref.{name}.graph{int(use_graph)}.k{k + 1}"
-        if last:
+        tag = f"rollout.ref.{name}.graph{int(use_graph)}{'.newest' if newest else ''}.k{k + 1}"
+        if last and newest:
+            # (1, 1, steps, .) against position S - 1 of the reference's outputs: 18 + 3 values, judged element-wise by the
+            # bound compare_outputs puts on one bf16 computation (1.5 x the reference's own worst element, or 3 bf16 ulps of
+            # the output's magnitude)
+            rec = fx["ref_test_bf16_deviation"]
+            for i, (nm, a) in enumerate((("arm", arm), ("gripper", grip))):
+                want = fx["test"][i].view(S, *a.shape[2:])[S - 1].float()
+                worst = float((a[0, 0].float().cpu() - want).abs().max())
+                bound = max(1.5 * rec[i]["max_abs"], 3.0 * 2.0 ** -8 * rec[i]["absmax"])
+                res.append({"name": f"{tag}.{nm}_executed_position_vs_real_reference (max abs)", "rel_l2": worst, "tol": bound,
+                            "ok": worst <= bound})
+        elif last:
             out = (arm.reshape(1, S, *arm.shape[2:]), grip.reshape(1, S, *grip.shape[2:])) + (None,) * 8
             want = list(fx["test"][:2]) + [None] * 8
             res += compare_outputs(out, want, 1e-3, tag + ".vs_real_reference", fx=fx, records=("ref_test_bf16_deviation",))
+        if last:
             # the action the wrapper would execute (6 values): no element further from the real reference's than twice the
             # reference's own worst bf16 element deviation on this output (a rel-L2 over 6 numbers is a 6-sample estimate)
             ref_pick = fx["test"][0].view(S, -1, 6)[S - 1, 0].float()
@@ -156,6 +178,8 @@ def gpu_rollout_vs_reference(name, use_graph=True):
                 parts = m.encode_frames(ip[:, idx], iw[:, idx], st[:, idx], tx[:, idx])
                 o = m.decode_tokens(parts, mode="test", test_noise=noise)
             ra, rg = o[0].view(1, S, -1, 6), o[1].view(1, S, -1, 1)
+            if newest:
+                ra, rg = ra[:, k:k + 1], rg[:, k:k + 1]               # the executed position of a padded window: its newest real frame
             rec = fx["ref_test_bf16_deviation"]
             for i, (nm, a, b_, t) in enumerate((("arm", arm, ra, PAIR * tol_arm), ("gripper", grip, rg, PAIR * tol_grip))):
                 d = (a.float() - b_.float())

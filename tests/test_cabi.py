@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/dvla.h but not exported"
     assert set(syms) == set(_lib.SYMBOLS), (set(syms) ^ set(_lib.SYMBOLS))
-    assert lib.dvla_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.dvla_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_structs_match_header_layout():
@@ -56,7 +56,7 @@ def test_struct_offsets_match_the_c_compiler(tmp_path):
     if gcc is None:
         pytest.skip("no gcc")
     structs = {"dvla_gemm_params": _lib.GemmParams, "dvla_attn_params": _lib.AttnParams, "dvla_mask_rule": _lib.MaskRule,
-               "dvla_token_src": _lib.TokenSrc, "dvla_frame_view": _lib.FrameView}
+               "dvla_token_src": _lib.TokenSrc, "dvla_frame_view": _lib.FrameView, "dvla_dit_sample_params": _lib.DitSampleParams}
     txt = open(os.path.join(ROOT, "include", "dvla.h")).read()
     structs = {c: p for c, p in structs.items() if re.search(r"\}\s*%s\s*;" % c, txt)}
     assert "dvla_gemm_params" in structs and "dvla_attn_params" in structs
