@@ -117,6 +117,7 @@ SYMBOLS = {
     "dvla_ddim_cfg_step": (C.c_int, [_P, _I64, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
     "dvla_dit_sample_workspace_bytes": (C.c_int64, [_I32]),
     "dvla_dit_sample": (C.c_int, [C.POINTER(DitSampleParams), _P]),
+    "dvla_dit_sample_set_stamps": (None, [_P]),
     "dvla_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_cast_bf16_to_f32": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),

@@ -99,7 +99,13 @@ struct Team {
   unsigned* status;    // != 0: a wait timed out
   unsigned epoch;      // exchanges this workgroup has arrived at
   int rank;
+  unsigned long long* stamps;   // measurement: 8 wall-clock stamps (100 MHz) per exchange of members 0 and 17, or null
 };
+// stamp k of the current exchange: 0 weights requested, 1 producers arrived, 2 operands landed, 3 partial tiles in LDS, 4 stored
+__device__ __forceinline__ void stamp(const Team& tm, int k) {
+  if (tm.stamps && threadIdx.x == 0 && (tm.rank == 0 || tm.rank == 17))
+    tm.stamps[((size_t)tm.epoch * 2 + (tm.rank == 17)) * 8 + k] = wall_clock64();
+}
 
 // every store of this workgroup to shared buffers has completed (vm_wait + workgroup barrier by the caller).  Called at the very end
 // of a phase function -- before it restores its callee-saved registers; the caller counts the exchange (tm.epoch += 1).
@@ -130,12 +136,24 @@ struct Args {
   const float* noise;
   float* out;
   bf16_t *X, *QKV, *O, *HID;
+  unsigned long long* stamps;
   unsigned* ctr;       // [0] team counter, [16] workgroups that have left, [32] status, [64 + r] XCC id of member r (last launch)
   float cfg, eps;
   int depth, D, H, C, T, bs, steps;
 };
 
 enum { EPI_BIAS = 0, EPI_BIAS_RES = 1, EPI_BIAS_GELU = 2, EPI_FINAL = 3 };
+
+// a block's eight weight addresses through the SCALAR cache (the table is constant for the launch): a vector load here would be
+// waited for with vmcnt(0), i.e. drain whatever weight requests the wave has in flight
+__device__ __forceinline__ dvla_dit_block_weights block_weights(const dvla_dit_block_weights* table, int l) {
+  typedef const unsigned long long __attribute__((address_space(4))) * const_q;
+  const_q q = (const_q)(table + l);
+  dvla_dit_block_weights w;
+  w.qkv_w = (const void*)q[0]; w.qkv_b = (const void*)q[1]; w.proj_w = (const void*)q[2]; w.proj_b = (const void*)q[3];
+  w.fc1_w = (const void*)q[4]; w.fc1_b = (const void*)q[5]; w.fc2_w = (const void*)q[6]; w.fc2_b = (const void*)q[7];
+  return w;
+}
 
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -156,9 +174,43 @@ __device__ __forceinline__ void load_steps(u32x4 (&f)[KS], const bf16_t* p) {
 
 // One GEMM phase:  out[R, N] = epilogue( [LayerNorm](A[R, K]) . W[N, K]^T ),  K = 8 waves x KS x 32.
 // KS: k32-steps per wave; MT: tiles per workgroup (>= ceil(N / 16 / TEAM), <= 8); RB: blocks of 16 rows (R <= 16 RB).
-template <int KS, int MT, int RB, bool LN, int EPI>
-__device__ __attribute__((noinline)) void gemm_phase(const Team tm, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias, int N, const bf16_t* A,
-                                                     int lda, bf16_t* out, int ldo, int R, float eps) {
+// the weight fragments of one phase for one wave (all tiles of its workgroup, its eighth of K) + the bias quad of the tile the
+// wave finishes: MT x KS + 1 loads in flight between weights_request() and the phase body
+template <int KS, int MT>
+struct WSet {
+  u32x4 w[MT][KS];
+  u32x2 b;
+  static constexpr int LOADS = MT * KS + 1;
+};
+template <int N_>
+__device__ __forceinline__ void vm_wait_but() {      // all but the N_ youngest vector-memory operations of this wave have completed
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+template <int KS, int MT>
+__device__ __forceinline__ void weights_request(const Team& tm, WSet<KS, MT>& ws, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias, int N) {
+  constexpr int K = NWAVES * KS * 32;
+  const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kb = wave * (KS * 32) + 8 * g;
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    int n = (tm.rank + TEAM * j) * 16 + l15;
+    n = n < N ? n : N - 1;                                        // (tiles / columns past the end: a valid address, zeroed in the body)
+    const bf16_t* wp = W + (int64_t)n * K + kb;
+    load_steps<KS, false>(ws.w[j], wp);
+  }
+  // the epilogue's bias quad of wave j's tile (lane: row lane / 4, columns 4 (lane % 4) .. + 3 of the tile)
+  const int en = (tm.rank + TEAM * wave) * 16 + (lane & 3) * 4;
+  ws.b = ldg8(bias + ((wave < MT && en + 3 < N) ? en : 0));
+}
+
+// The body of a phase, its weights already requested.  `next()` requests the weights of a LATER phase: it runs after this phase's
+// stores have been issued, NEXT_LOADS loads per wave, and the stores are then waited for with a counted s_waitcnt that leaves
+// those loads in flight (vector memory operations of a wave retire in order).
+template <int KS, int MT, int RB, bool LN, int EPI, int NEXT_LOADS, class Next>
+__device__ __forceinline__ void gemm_body(const Team& tm, WSet<KS, MT>& ws, const bf16_t* __restrict__ bias, int N, const bf16_t* A, int lda,
+                                          bf16_t* out, int ldo, int R, float eps, Next&& next) {
   static_assert(MT <= NWAVES, "wave j finishes tile j");
   DIT_LDS();
   float* part = dit_lds + PART_OFF;
@@ -169,23 +221,15 @@ __device__ __attribute__((noinline)) void gemm_phase(const Team tm, const bf16_t
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ntiles = (N + 15) >> 4;
   const int kb = wave * (KS * 32) + 8 * g;
-  // 1. this workgroup's weight fragments: in flight across the exchange below
-  u32x4 wf[MT][KS];
-#pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    int n = (tm.rank + TEAM * j) * 16 + l15;
-    n = n < N ? n : N - 1;                                        // (tiles / columns past the end: a valid address, zeroed below)
-    const bf16_t* wp = W + (int64_t)n * K + kb;
-    load_steps<KS, false>(wf[j], wp);
-  }
-  // the epilogue's bias quad of wave j's tile (lane: row lane / 4, columns 4 (lane % 4) .. + 3 of the tile)
+  u32x4 (&wf)[MT][KS] = ws.w;
+  u32x2& bq2 = ws.b;
   const int etile = tm.rank + TEAM * wave, erow = lane >> 2, ec = (lane & 3) * 4;
   const bool ewave = wave < MT && etile < ntiles;
   const int en = etile * 16 + ec;
   const bool evec = ewave && en + 3 < N;
-  u32x2 bq2 = ldg8(bias + (evec ? en : 0));
   // 2. the producers of A have arrived
   if (wave == 0) team_wait(tm);
+  stamp(tm, 1);
   wg_barrier();
   // 3. this wave's K-share of the rows; the residual quad of the epilogue
   u32x4 af[RB][KS];
@@ -208,6 +252,7 @@ __device__ __attribute__((noinline)) void gemm_phase(const Team tm, const bf16_t
     }
   }
   vm_wait();
+  stamp(tm, 2);
 #pragma unroll
   for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -300,6 +345,7 @@ __device__ __attribute__((noinline)) void gemm_phase(const Team tm, const bf16_t
       for (int r = 0; r < 4; ++r) part[(((wave * MT + j) * RB + rb) * 16 + 4 * g + r) * LDP + l15] = acc[j][rb][r];
   lds_wait();
   wg_barrier();
+  stamp(tm, 3);
   // 5. wave j finishes tile j
   if (ewave) {
 #pragma unroll
@@ -334,77 +380,101 @@ __device__ __attribute__((noinline)) void gemm_phase(const Team tm, const bf16_t
       }
     }
   }
-  vm_wait();
+  next();
+  vm_wait_but<NEXT_LOADS>();
   lds_wait();
   wg_barrier();
+  stamp(tm, 4);
   if (EPI != EPI_FINAL) team_arrive(tm);
 }
 
-// attention of one (sample, head) per wave: L <= 8 tokens, head_dim 64; qkv rows (3 D wide: q | k | v), o rows (D wide)
-__device__ __attribute__((noinline)) void attention_phase(const Team tm, const bf16_t* QKV, bf16_t* O, int nsamp, int H, int L, int D) {
-  DIT_LDS();
-  float* scratch = dit_lds + PART_OFF;
-  const int t = threadIdx.x, lane = t & 63;
+// request + body behind one call: the variants whose register sets do not fit side by side (two row blocks, hidden 1024) keep
+// every phase's registers to itself
+template <int KS, int MT, int RB, bool LN, int EPI>
+__device__ __attribute__((noinline)) void gemm_phase(const Team tm, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias, int N, const bf16_t* A,
+                                                     int lda, bf16_t* out, int ldo, int R, float eps) {
+  WSet<KS, MT> ws;
+  weights_request<KS, MT>(tm, ws, W, bias, N);
+  stamp(tm, 0);
+  gemm_body<KS, MT, RB, LN, EPI, 0>(tm, ws, bias, N, A, lda, out, ldo, R, eps, [] {});
+}
+
+// attention of one (sample, head) per wave: L <= 8 tokens, head_dim 64; qkv rows (3 D wide: q | k | v), o rows (D wide).
+// Scores on two 16x16x32 MFMAs from fragments loaded in operand layout (lane (l15, g): row l15 of q / k, columns 8 g + 32 s .. + 7);
+// S arrives as lane (j = l15, group g), register r = query 4 g + r; softmax across the 16 lanes of a group; P.V on the VALU with
+// lane = output column: P(i, j) is broadcast from its lane with v_readlane, V(j, lane) comes from L coalesced 2-byte loads.
+template <int NEXT_LOADS, class Next>
+__device__ __forceinline__ void attention_body(const Team& tm, const bf16_t* QKV, bf16_t* O, int nsamp, int H, int L, int D, Next&& next) {
+  const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   if (wave == 0) team_wait(tm);
+  stamp(tm, 1);
   wg_barrier();
-  float* qf = scratch + wave * (3 * MAX_L * 68 + MAX_L * 8 + MAX_L);      // [8][68] x 3, p [8][8], l [8]
-  float* kf = qf + MAX_L * 68;
-  float* vf = kf + MAX_L * 68;
-  float* pf = vf + MAX_L * 68;
-  float* lf = pf + MAX_L * 8;
   const int units = nsamp * H;
   for (int u = tm.rank + TEAM * wave; u < units; u += TEAM * NWAVES) {
     const int smp = u / H, h = u - smp * H;
-    const int i = lane >> 3, c = lane & 7;
-    const int ic = i < L ? i : L - 1;
-    const bf16_t* base = QKV + (int64_t)(smp * L + ic) * (3 * D) + h * 64 + c * 8;
-    u32x4 q4 = ldd16(base), k4 = ldd16(base + D), v4 = ldd16(base + 2 * D);
+    const int rc = l15 < L ? l15 : L - 1;
+    const bf16_t* qb = QKV + (int64_t)(smp * L + rc) * (3 * D) + h * 64 + 8 * g;
+    u32x4 q0 = ldd16<0>(qb), q1 = ldd16<64>(qb), k0 = ldd16<0>(qb + D), k1 = ldd16<64>(qb + D);
+    uint32_t vv[MAX_L];
+#pragma unroll
+    for (int j = 0; j < MAX_L; ++j) {
+      const int jc = j < L ? j : L - 1;
+      asm volatile("global_load_ushort %0, %1, off sc1" : "=v"(vv[j]) : "v"(QKV + (int64_t)(smp * L + jc) * (3 * D) + 2 * D + h * 64 + lane) : "memory");
+    }
     vm_wait();
-    pin(q4); pin(k4); pin(v4);
-    float a[8];
-    unpack8(q4, a);
+    pin(q0); pin(q1); pin(k0); pin(k1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qf[i * 68 + c * 8 + e] = a[e];
-    unpack8(k4, a);
+    for (int j = 0; j < MAX_L; ++j) pin(vv[j]);
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+    sc = mfma16(q0, k0, sc);                     // A = q (rows = queries), B = k (columns = keys)
+    sc = mfma16(q1, k1, sc);
+    // sc[r] = q(4 g + r) . k(l15)
+    float pb[4], lsum[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) kf[i * 68 + c * 8 + e] = a[e];
-    unpack8(v4, a);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) vf[i * 68 + c * 8 + e] = a[e];
-    lds_wait();
-    // scores: lane (i, j)
-    const int j = c;
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < 64; d += 4) {
-      const float4 qa = *reinterpret_cast<const float4*>(qf + i * 68 + d), ka = *reinterpret_cast<const float4*>(kf + j * 68 + d);
-      s = fmaf(qa.x, ka.x, s); s = fmaf(qa.y, ka.y, s); s = fmaf(qa.z, ka.z, s); s = fmaf(qa.w, ka.w, s);
+    for (int r = 0; r < 4; ++r) {
+      const bool vis = l15 < L && 4 * g + r < L;
+      const float s2 = vis ? sc[r] * (0.125f * 1.4426950408889634f) : -INFINITY;      // head_dim 64: scale 1/8, log2 domain
+      float mx = s2;
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+      const float M = ceilf(mx);                                                  // integer running maximum (csrc/attention.hip)
+      const float p = vis ? fast_exp2(s2 - M) : 0.f;
+      float l = p;
+      l += __shfl_xor(l, 1, 64); l += __shfl_xor(l, 2, 64); l += __shfl_xor(l, 4, 64); l += __shfl_xor(l, 8, 64);
+      pb[r] = bf2f(f2bf(p));
+      lsum[r] = l;
     }
-    const bool vis = i < L && j < L;
-    const float s2 = vis ? s * (0.125f * 1.4426950408889634f) : -INFINITY;      // head_dim 64: scale 1/8, log2 domain
-    float mx = s2;
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
-    const float M = ceilf(mx);                                                  // integer running maximum (csrc/attention.hip)
-    const float p = vis ? fast_exp2(s2 - M) : 0.f;
-    float l = p;
-    l += __shfl_xor(l, 1, 64); l += __shfl_xor(l, 2, 64); l += __shfl_xor(l, 4, 64);
-    pf[i * 8 + j] = bf2f(f2bf(p));
-    if (j == 0) lf[i] = l;
-    lds_wait();
-    // o[i][d], d = lane
-    for (int ii = 0; ii < L; ++ii) {
-      float o = 0.f;
-      for (int jj = 0; jj < L; ++jj) o = fmaf(pf[ii * 8 + jj], vf[jj * 68 + lane], o);
-      o = o / lf[ii];
-      const float hi = __shfl_down(o, 1, 64);
-      if ((lane & 1) == 0) std4(O + (int64_t)(smp * L + ii) * D + h * 64 + lane, pack2bf(o, hi));
+    float vf[MAX_L];
+#pragma unroll
+    for (int j = 0; j < MAX_L; ++j) vf[j] = __uint_as_float(vv[j] << 16);
+#pragma unroll
+    for (int i = 0; i < MAX_L; ++i) {
+      if (i < L) {
+        float o = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_L; ++j) {
+          if (j < L) {
+            const float pij = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pb[i & 3]), j + 16 * (i >> 2)));
+            o = fmaf(pij, vf[j], o);
+          }
+        }
+        const float li = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lsum[i & 3]), 16 * (i >> 2)));
+        o = o / li;
+        const float hi = __shfl_down(o, 1, 64);
+        if ((lane & 1) == 0) std4(O + (int64_t)(smp * L + i) * D + h * 64 + lane, pack2bf(o, hi));
+      }
     }
-    lds_wait();
   }
-  vm_wait();
+  next();
+  vm_wait_but<NEXT_LOADS>();
   wg_barrier();
+  stamp(tm, 4);
   team_arrive(tm);
+}
+__device__ __attribute__((noinline)) void attention_phase(const Team tm, const bf16_t* QKV, bf16_t* O, int nsamp, int H, int L, int D) {
+  stamp(tm, 0);
+  attention_body<0>(tm, QKV, O, nsamp, H, L, D, [] {});
 }
 
 // team member 0, between two sampler steps: [final LayerNorm + linear of step j - 1 -> guidance + DDIM update] -> token embedding
@@ -481,7 +551,7 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel(Args a) {
   constexpr int D = KS * 256;
   constexpr int MT_QKV = (3 * D / 16 + TEAM - 1) / TEAM, MT_D = (D / 16 + TEAM - 1) / TEAM, MT_FC1 = (4 * D / 16 + TEAM - 1) / TEAM;
   Team tm;
-  tm.ctr = a.ctr; tm.status = a.ctr + 32; tm.epoch = 0; tm.rank = (int)(blockIdx.x >> 3);
+  tm.ctr = a.ctr; tm.status = a.ctr + 32; tm.epoch = 0; tm.rank = (int)(blockIdx.x >> 3); tm.stamps = a.stamps;
   if (threadIdx.x == 0) {
     *reinterpret_cast<int*>(dit_lds + DEAD_OFF) = 0;
     a.ctr[64 + tm.rank] = xcc_id();                  // diagnostics: where the team runs (all members on one XCC = the fast case)
@@ -493,7 +563,8 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel(Args a) {
     // exchange 0 of a step: the step boundary, on member 0.  The other members only pass through it -- but they WAIT for the
     // previous exchange first: one counter serves all exchanges, so nobody may arrive twice before everybody has arrived once.
     if (tm.rank == 0) {
-      step_boundary<KS, RB>(tm, a, j);
+      const Args boundary_args = a;            // (a copy for the call: the kernel's own arguments stay in scalar registers)
+      step_boundary<KS, RB>(tm, boundary_args, j);
     } else if (j < a.steps) {
       if (j > 0) {
         if (wave == 0) team_wait(tm);
@@ -504,7 +575,7 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel(Args a) {
     if (j == a.steps) break;
     tm.epoch += 1;
     for (int l = 0; l < a.depth; ++l) {
-      const dvla_dit_block_weights bw = a.blocks[l];
+      const dvla_dit_block_weights bw = block_weights(a.blocks, l);
       gemm_phase<KS, MT_QKV, RB, true, EPI_BIAS>(tm, (const bf16_t*)bw.qkv_w, (const bf16_t*)bw.qkv_b, 3 * D, a.X, D, a.QKV, 3 * D, R, a.eps);
       tm.epoch += 1;
       attention_phase(tm, a.QKV, a.O, 2 * a.bs, a.H, L, D);
@@ -529,6 +600,101 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel(Args a) {
   }
 }
 
+// The same schedule in one function (no call per phase: 2.4 us of register saves, argument traffic and a drained memory queue per
+// exchange in the kernel above), with the weight requests AHEAD of the exchange that precedes their use: a phase's end -- after
+// its stores have been issued -- requests the weights of the next GEMM phase (qkv's end proj's, the attention's end fc1's: the two
+// short phases hide a whole stream; fc1's end fc2's, fc2's end the next block's qkv: hidden behind arrival + exchange + operand
+// load).  Requesting fc2's and qkv's a phase earlier as well was built and measured (profiles/r04_dit_team_perf.jsonl): 44
+// spilled registers, and SLOWER (33.2 against 30.8 us per block) -- while the XCD's fabric port is saturated by a weight stream,
+// every L2 access of the exchange itself (the sc1 stores' acknowledgements, the counter, the operand loads) waits in the same
+// queues: stream and exchange do not overlap beyond the first microsecond, they add.  Nothing requested is ever left unconsumed (a load that lands
+// after its register was re-used would corrupt it), and no request is in flight across the only real call (step_boundary).
+template <int KS, int RB>
+__global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel_ahead(Args a) {
+  DIT_LDS();
+  if ((blockIdx.x & 7) != 0) return;
+  constexpr int D = KS * 256;
+  constexpr int MT_QKV = (3 * D / 16 + TEAM - 1) / TEAM, MT_D = (D / 16 + TEAM - 1) / TEAM, MT_FC1 = (4 * D / 16 + TEAM - 1) / TEAM;
+  typedef WSet<KS, MT_QKV> WQ;
+  typedef WSet<KS, MT_D> WP;
+  typedef WSet<KS, MT_FC1> W1;
+  typedef WSet<4 * KS, MT_D> W2;
+  Team tm;
+  tm.ctr = a.ctr; tm.status = a.ctr + 32; tm.epoch = 0; tm.rank = (int)(blockIdx.x >> 3); tm.stamps = a.stamps;
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<int*>(dit_lds + DEAD_OFF) = 0;
+    a.ctr[64 + tm.rank] = xcc_id();
+  }
+  __syncthreads();
+  const int L = 2 * a.T, R = 2 * a.bs * L;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  WQ wq;
+  WP wp;
+  W1 w1;
+  W2 w2;
+  for (int j = 0; j <= a.steps; ++j) {
+    if (tm.rank == 0) {
+      const Args boundary_args = a;            // (a copy for the call: the kernel's own arguments stay in scalar registers)
+      step_boundary<KS, RB>(tm, boundary_args, j);
+    } else if (j < a.steps) {
+      if (j > 0) {
+        if (wave == 0) team_wait(tm);
+        wg_barrier();
+      }
+      team_arrive(tm);
+    }
+    if (j == a.steps) break;
+    tm.epoch += 1;
+    {
+      const dvla_dit_block_weights b0 = block_weights(a.blocks, 0);
+      weights_request<KS, MT_QKV>(tm, wq, (const bf16_t*)b0.qkv_w, (const bf16_t*)b0.qkv_b, 3 * D);
+    }
+    for (int l = 0; l < a.depth; ++l) {
+      const dvla_dit_block_weights bw = block_weights(a.blocks, l);
+      stamp(tm, 0);
+      gemm_body<KS, MT_QKV, RB, true, EPI_BIAS, WP::LOADS>(tm, wq, (const bf16_t*)bw.qkv_b, 3 * D, a.X, D, a.QKV, 3 * D, R, a.eps, [&] {
+        weights_request<KS, MT_D>(tm, wp, (const bf16_t*)bw.proj_w, (const bf16_t*)bw.proj_b, D);
+      });
+      tm.epoch += 1;
+      stamp(tm, 0);
+      attention_body<W1::LOADS>(tm, a.QKV, a.O, 2 * a.bs, a.H, L, D, [&] {
+        weights_request<KS, MT_FC1>(tm, w1, (const bf16_t*)bw.fc1_w, (const bf16_t*)bw.fc1_b, 4 * D);
+      });
+      tm.epoch += 1;
+      stamp(tm, 0);
+      const dvla_dit_block_weights bn = block_weights(a.blocks, l + 1 < a.depth ? l + 1 : 0);
+      // (the last block requests block 0's qkv weights: what the next step starts with -- and every block ends the same way, so
+      // that the qkv registers are written on every path around the loop)
+      gemm_body<KS, MT_D, RB, false, EPI_BIAS_RES, 0>(tm, wp, (const bf16_t*)bw.proj_b, D, a.O, D, a.X, D, R, a.eps, [] {});
+      tm.epoch += 1;
+      stamp(tm, 0);
+      gemm_body<KS, MT_FC1, RB, true, EPI_BIAS_GELU, W2::LOADS>(tm, w1, (const bf16_t*)bw.fc1_b, 4 * D, a.X, D, a.HID, 4 * D, R, a.eps, [&] {
+        weights_request<4 * KS, MT_D>(tm, w2, (const bf16_t*)bw.fc2_w, (const bf16_t*)bw.fc2_b, D);
+      });
+      tm.epoch += 1;
+      stamp(tm, 0);
+      gemm_body<4 * KS, MT_D, RB, false, EPI_BIAS_RES, WQ::LOADS>(tm, w2, (const bf16_t*)bw.fc2_b, D, a.HID, 4 * D, a.X, D, R, a.eps, [&] {
+        weights_request<KS, MT_QKV>(tm, wq, (const bf16_t*)bn.qkv_w, (const bf16_t*)bn.qkv_b, 3 * D);
+      });
+      tm.epoch += 1;
+    }
+    // nothing stays in flight across the step boundary (member 0 makes a call there): the request above has warmed the L2
+    vm_wait();
+#pragma unroll
+    for (int jj = 0; jj < MT_QKV; ++jj)
+#pragma unroll
+      for (int ss = 0; ss < KS; ++ss) pin(wq.w[jj][ss]);
+    pin(wq.b);
+  }
+  if (threadIdx.x == 0) {
+    const unsigned left = __hip_atomic_fetch_add(a.ctr + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == TEAM - 1) {
+      __hip_atomic_store(a.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ctr + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 size_t team_smem_bytes(int KS, int RB) {
   const int D = KS * 256, mt_fc1 = (4 * D / 16 + TEAM - 1) / TEAM;
   size_t part = (size_t)NWAVES * mt_fc1 * RB * 16 * LDP;
@@ -544,6 +710,11 @@ extern "C" int64_t dvla_dit_sample_workspace_bytes(int32_t hidden) {
   return 1024 + (int64_t)32 * (1 + 3 + 1 + 4) * hidden * 2;
 }
 
+// measurement hook (tests/gpu_dit_team_perf.py): a device buffer of 2 x 8 x (exchanges + 1) 64-bit words that the next launches
+// fill with wall-clock stamps of team members 0 and 17 -- null (the default) switches the stamping off
+static unsigned long long* g_dit_stamps = nullptr;
+extern "C" void dvla_dit_sample_set_stamps(void* buf) { g_dit_stamps = reinterpret_cast<unsigned long long*>(buf); }
+
 extern "C" int dvla_dit_sample(const dvla_dit_sample_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!q || !q->blocks || !q->xemb_w || !q->xemb_b || !q->final_w || !q->final_b || !q->pos || !q->cond || !q->coef || !q->noise ||
@@ -551,10 +722,11 @@ extern "C" int dvla_dit_sample(const dvla_dit_sample_params* q, void* stream_) {
     return DVLA_ERR_ARG;
   if (q->depth < 1 || q->steps < 1 || q->bs < 1 || q->tokens < 1 || q->channels < 1 || q->heads < 1) return DVLA_ERR_ARG;
   const int L = 2 * q->tokens, R = 2 * q->bs * L;
-  const int KS = q->hidden / 256;
-  if (q->hidden % 256 != 0 || (KS != 3 && KS != 4) || q->heads * 64 != q->hidden || L > MAX_L || R > 32 || q->channels > 16 ||
-      q->bs * q->tokens * q->channels > 256 || (KS == 4 && R > 16))
+  // DiT-B at one episode: the only shape where the team beats the launch-by-launch sampler (profiles/r04_dit_team_perf.jsonl:
+  // two row blocks or hidden 1024 do not fit the look-ahead schedule's registers, and the call-per-phase kernel loses there)
+  if (q->hidden != 768 || q->heads * 64 != q->hidden || L > MAX_L || R > 16 || q->channels > 16 || q->bs * q->tokens * q->channels > 256)
     return DVLA_ERR_UNSUPPORTED;
+  constexpr int KS = 3, RB = 1;
   if (q->workspace_bytes < dvla_dit_sample_workspace_bytes(q->hidden) || (reinterpret_cast<uintptr_t>(q->workspace) & 15))
     return DVLA_ERR_ARG;
   int dev = 0, cus = 0;
@@ -567,6 +739,7 @@ extern "C" int dvla_dit_sample(const dvla_dit_sample_params* q, void* stream_) {
   a.final_w = (const bf16_t*)q->final_w; a.final_b = (const bf16_t*)q->final_b;
   a.pos = (const bf16_t*)q->pos; a.cond = (const bf16_t*)q->cond;
   a.coef = q->coef; a.noise = q->noise; a.out = q->out;
+  a.stamps = g_dit_stamps;
   char* ws = reinterpret_cast<char*>(q->workspace);
   a.ctr = reinterpret_cast<unsigned*>(ws);
   a.X = reinterpret_cast<bf16_t*>(ws + 1024);
@@ -575,20 +748,20 @@ extern "C" int dvla_dit_sample(const dvla_dit_sample_params* q, void* stream_) {
   a.HID = a.O + (int64_t)32 * q->hidden;
   a.cfg = q->cfg_scale; a.eps = q->ln_eps;
   a.depth = q->depth; a.D = q->hidden; a.H = q->heads; a.C = q->channels; a.T = q->tokens; a.bs = q->bs; a.steps = q->steps;
-  const int RB = R > 16 ? 2 : 1;
   const size_t smem = team_smem_bytes(KS, RB);
-  // >= 80 KB of LDS per workgroup: one workgroup per CU, so that workgroup b lands on XCC b % 8 of an idle chip
+  // >= 80 KB of LDS per workgroup: at most two workgroups per CU, so that consecutive workgroups spread over the XCCs of an idle chip
   const size_t lds = smem > 81920 ? smem : 81920;
-  const void* fn = KS == 3 ? (RB == 1 ? (const void*)dit_team_kernel<3, 1> : (const void*)dit_team_kernel<3, 2>) : (const void*)dit_team_kernel<4, 1>;
-  static bool attr_set[3] = {false, false, false};
-  const int slot = KS == 3 ? RB - 1 : 2;
-  if (!attr_set[slot]) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DVLA_ERR_LAUNCH;
-    attr_set[slot] = true;
+  static int ahead = -1;
+  if (ahead < 0) { const char* e = getenv("DVLA_DIT_AHEAD"); ahead = e ? atoi(e) : 1; }      // 0: the call-per-phase kernel (A/B)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)dit_team_kernel_ahead<KS, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)dit_team_kernel<KS, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return DVLA_ERR_LAUNCH;
+    attr_set = true;
   }
   const dim3 grid((unsigned)(8 * TEAM)), block(64 * NWAVES);
-  if (KS == 3 && RB == 1) hipLaunchKernelGGL((dit_team_kernel<3, 1>), grid, block, lds, stream, a);
-  else if (KS == 3) hipLaunchKernelGGL((dit_team_kernel<3, 2>), grid, block, lds, stream, a);
-  else hipLaunchKernelGGL((dit_team_kernel<4, 1>), grid, block, lds, stream, a);
+  if (ahead) hipLaunchKernelGGL((dit_team_kernel_ahead<KS, RB>), grid, block, lds, stream, a);
+  else hipLaunchKernelGGL((dit_team_kernel<KS, RB>), grid, block, lds, stream, a);
   return dvla_check_launch();
 }

@@ -656,6 +656,9 @@ struct RCfg {
 using RCfgL = RCfg<2, 4, 4, 2, 4, 2, 4, 32>;    // 256 x 256, BK 32, 8 waves of 128 x 64, 128 KiB ring, 1 workgroup / CU
 using RCfgS = RCfg<2, 2, 2, 2, 4, 2, 8, 32>;    // 128 x 128, BK 32, 4 waves of  64 x 64,  64 KiB ring, 2 workgroups / CU
 using RCfgM64 = RCfg<4, 2, 2, 2, 3, 2, 4, 64>;  // 256 x 128, BK 64 (whole 128-B lines of a k-contiguous operand), 144 KiB ring
+// (round 4: a 128 x 128 configuration with BK 64 and four stages -- 96 KiB in flight per workgroup -- was built for the evaluation
+// engine's 930-row trunk GEMMs, which take 15 us on every configuration: 14.4 / 15.4 / 16.6 us against RCfgS's 14.4 / 15.1 / 16.1
+// (profiles/r04_midrows_perf.jsonl, columns v12_*): those launches are not bound by operand latency; removed again.)
 
 // per-lane global source address of chunk c of an operand tile at k0 (the LDS destination of lane l is chunk base + 16 l)
 template <bool TRANS, int ROWS, int BKS>

@@ -83,7 +83,29 @@ def next_seed():
 # ---------------------------------------------------------------------------------------------------
 # raw kernel launchers (no autograd)
 # ---------------------------------------------------------------------------------------------------
-FWD_SPLIT_K = os.environ.get("DVLA_FWD_SPLIT_K", "1") != "0"
+FWD_SPLIT_K_ALLOWED = os.environ.get("DVLA_FWD_SPLIT_K", "1") != "0"
+FWD_SPLIT_K = False          # switched on by the rollout engine around its encode / decode (forward_split_k below)
+
+
+class forward_split_k:
+    """`with ops.forward_split_k():` -- forward GEMMs with few hundred rows and a long K are cut along K (fwd_split_k).  The
+    rollout engine wraps its encode / decode in it.  It is NOT on by default: it changes the fp32 summation order of the GEMMs
+    it touches (the frozen ViT's MLP down-projection among them), and the training-mode parity checks hold the step to
+    tolerances calibrated on row-independent kernels (a two-rank run whose half batches took another split than the full
+    batch's moved an ill-conditioned bias gradient by 100 %)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on) and FWD_SPLIT_K_ALLOWED
+
+    def __enter__(self):
+        global FWD_SPLIT_K
+        self.was, FWD_SPLIT_K = FWD_SPLIT_K, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global FWD_SPLIT_K
+        FWD_SPLIT_K = self.was
+        return False
 
 
 def fwd_split_k(M, N, K, cus=256):
@@ -304,9 +326,11 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     p.split_k = max(1, int(split_k))
     if split_k is None or int(split_k) == 0:
         p.split_k = 1
-    if (FWD_SPLIT_K and p.split_k == 1 and split_k != 0 and not a_trans and not want_preact and dact_aux is None and dropout_p == 0.0
-            and not accumulate and ksum is None and a_ln_eps is None and variant is None and N % 8 == 0):
-        p.split_k = fwd_split_k(M, N, K)      # few hundred rows, long K: the evaluation engine's trunk (see fwd_split_k)
+    if (FWD_SPLIT_K and p.split_k == 1 and split_k != 0 and not torch.is_grad_enabled() and not a_trans and not want_preact
+            and dact_aux is None and dropout_p == 0.0 and not accumulate and ksum is None and a_ln_eps is None and variant is None
+            and N % 8 == 0 and out.dtype == BF16):
+        # few hundred rows, long K: the evaluation engine's trunk (see fwd_split_k; on inside `with forward_split_k()` only)
+        p.split_k = fwd_split_k(M, N, K)
     ksum_ws = None
     if ksum is not None:
         which, kout = ksum
@@ -525,16 +549,16 @@ _DIT_TEAM_CUS = {}
 
 
 def dit_team_ok(hidden, heads, channels, tokens, bs, device):
-    """the shapes dvla_dit_sample takes (everything else runs the launch-by-launch sampler): DiT-B / DiT-L at head_dim 64,
-    at most 8 tokens per sequence and 32 token rows (16 at hidden 1024) -- one or two episodes -- on a whole MI355X"""
+    """the shapes dvla_dit_sample takes (everything else runs the launch-by-launch sampler): DiT-B (hidden 768, head_dim 64),
+    at most 8 tokens per sequence and 16 token rows -- one episode -- on a whole MI355X"""
     if not DIT_TEAM or device.type != "cuda":
         return False
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _DIT_TEAM_CUS:
         _DIT_TEAM_CUS[key] = torch.cuda.get_device_properties(key).multi_processor_count
     rows = 4 * bs * tokens
-    return (hidden in (768, 1024) and heads * 64 == hidden and 2 * tokens <= 8 and rows <= (32 if hidden == 768 else 16)
-            and channels <= 16 and bs * tokens * channels <= 256 and _DIT_TEAM_CUS[key] >= 256)
+    return (hidden == 768 and heads * 64 == hidden and 2 * tokens <= 8 and rows <= 16 and channels <= 16
+            and bs * tokens * channels <= 256 and _DIT_TEAM_CUS[key] >= 256)
 
 
 def dit_team_workspace(hidden, device):

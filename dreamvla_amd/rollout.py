@@ -23,6 +23,7 @@ the episodes selected by a boolean mask (their history is cleared, the others ke
 """
 import torch
 
+from . import ops
 from .ops import GemmTuner
 
 
@@ -98,8 +99,9 @@ class RolloutEngine:
 
     def _encode_eager(self, image_primary, image_wrist, state, text_emb):
         m = self.model
-        parts = m.encode_frames(image_primary.unsqueeze(1), image_wrist.unsqueeze(1), state.unsqueeze(1), None,
-                                text_embedding=text_emb.view(text_emb.shape[0], 1, 1, -1))
+        with ops.forward_split_k():
+            parts = m.encode_frames(image_primary.unsqueeze(1), image_wrist.unsqueeze(1), state.unsqueeze(1), None,
+                                    text_embedding=text_emb.view(text_emb.shape[0], 1, 1, -1))
         return (torch.cat(parts, dim=2)[:, 0],)
 
     @torch.no_grad()
@@ -151,8 +153,9 @@ class RolloutEngine:
 
     # ------------------------------------------------------------------------------------------------------------
     def _decode_eager(self, tokens, noise, sel):
-        out = self.model.decode_tokens(tokens, mode="test", test_noise=noise if self.needs_noise else None,
-                                       test_select=None if self.sample_all else sel)
+        with ops.forward_split_k():       # the trunk at one episode: 930 rows, K = 4096 in the MLP down-projection
+            out = self.model.decode_tokens(tokens, mode="test", test_noise=noise if self.needs_noise else None,
+                                           test_select=None if self.sample_all else sel)
         return out[0], out[1]
 
     @torch.no_grad()

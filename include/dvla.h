@@ -93,7 +93,8 @@ int dvla_gemm_bf16(const dvla_gemm_params* p, void* stream);
  * 2 = register-staged 128x128 kernel; 4 / 6 / 7 = LDS-DMA ring kernels 256x256 / 128x128 / 256x128 (K-tile 64); 8 = phase
  * kernel (256x256, K-tile 64, two wave groups in ping-pong); 9 = the phase kernel under the stream-K hybrid schedule (whole
  * rounds one tile per CU; the last, partial rounds as equal K-iteration ranges per group of 16 CUs, the two halves of a
- * shared tile combined in-kernel through a 256-KiB fp32 slab).  A configuration that does not take a shape falls back
+ * shared tile combined in-kernel through a 256-KiB fp32 slab); 11 = the few-rows kernel (M <= 512).  A configuration that does
+ * not take a shape falls back
  * inside the library.  All differ only in fp32 summation order.  81..89 = ablation / timeline builds of the phase kernel
  * (wrong results by design, tests/probes/gemm_probe.cpp).
  * Stream-K scratch: 64 MiB + flags per (device, stream), hipMalloc'ed on the first launch that uses it (never while the
@@ -247,8 +248,9 @@ int dvla_ddim_cfg_step(const void* model_out, int64_t sample_stride, const float
  *   workspace  dvla_dit_sample_workspace_bytes(hidden) bytes, 16-byte aligned, ZERO-INITIALISED by the caller once (the kernel
  *              leaves its counters at zero); 32-bit word 32 = status (0 ok; sticky), words 64 .. 95 = the XCC id each of the 32
  *              team members ran on in the last launch (all equal = the fast case), valid after a launch
- * DVLA_ERR_UNSUPPORTED unless hidden in {768, 1024}, head_dim 64, 2 tokens <= 8, 4 bs tokens <= 32 rows (<= 16 at hidden 1024),
- * channels <= 16, on a device with 256 CUs: the caller then runs the launch-by-launch sampler. */
+ * DVLA_ERR_UNSUPPORTED unless hidden = 768 (DiT-B), head_dim 64, 2 tokens <= 8, 4 bs tokens <= 16 rows (one episode),
+ * channels <= 16, on a device with 256 CUs: the caller then runs the launch-by-launch sampler (which is the faster one for two
+ * row blocks and for hidden 1024: profiles/r04_dit_team_perf.jsonl). */
 typedef struct dvla_dit_block_weights {
   const void *qkv_w, *qkv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 } dvla_dit_block_weights;
@@ -265,6 +267,10 @@ typedef struct dvla_dit_sample_params {
 } dvla_dit_sample_params;
 int64_t dvla_dit_sample_workspace_bytes(int32_t hidden);
 int dvla_dit_sample(const dvla_dit_sample_params* p, void* stream);
+/* measurement: a device buffer of 2 x 8 x (steps x (1 + 5 depth) + 1) uint64 that later launches fill with wall-clock stamps
+ * (100 MHz) of team members 0 and 17 -- per exchange: weights requested, producers arrived, operands landed, partial tiles in
+ * LDS, results stored; NULL (the default) switches it off */
+void dvla_dit_sample_set_stamps(void* device_buffer);
 /* dst(bf16) = src(fp32) / dst(fp32) = src(bf16) */
 int dvla_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dvla_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

@@ -18,6 +18,8 @@ rel-L2 = ||a - b||_2 / max(||b||_2, tiny).
 import math
 import os
 
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 import torch
 
 from oracle import torch_ref as R
@@ -92,11 +94,12 @@ def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", re
     a_dev = (A.t().contiguous() if a_trans else A).to(DEV, BF)
     b_dev = (B.t().contiguous() if b_trans else B).to(DEV, BF)
     sd = (77, 4242)
-    r = ops.gemm(a_dev, b_dev, a_trans=a_trans, b_trans=b_trans,
-                 bias=None if bias_t is None else bias_t.to(DEV, BF), act=ACT[act], want_preact=want_preact,
-                 dact_aux=None if aux_t is None else aux_t.to(DEV, BF), dact=ACT[dact] if dact else 0,
-                 dropout_p=dropout_p, seed=sd, residual=None if res_t is None else res_t.to(DEV, BF),
-                 out_dtype=torch.float32 if out_f32 else BF, split_k=split_k, variant=variant)
+    with ops.forward_split_k(), torch.no_grad():      # (the rule of the rollout engine: a no-op for every other case here)
+        r = ops.gemm(a_dev, b_dev, a_trans=a_trans, b_trans=b_trans,
+                     bias=None if bias_t is None else bias_t.to(DEV, BF), act=ACT[act], want_preact=want_preact,
+                     dact_aux=None if aux_t is None else aux_t.to(DEV, BF), dact=ACT[dact] if dact else 0,
+                     dropout_p=dropout_p, seed=sd, residual=None if res_t is None else res_t.to(DEV, BF),
+                     out_dtype=torch.float32 if out_f32 else BF, split_k=split_k, variant=variant)
     got, pre = r if want_preact else (r, None)
     ref = A @ B.t()
     if bias:
@@ -155,7 +158,7 @@ def check_act_bwd_colsum(rows, cols, act="none", dropout_p=0.0, out_bf16=False, 
             metrics(tag + " column sums", db, want, TOL_FWD if out_bf16 else 1e-5, round_ref=out_bf16)]
 
 
-def check_dit_team(bs=1, model_type="DiT-B", seeds=(0, 1, 2, 3)):
+def check_dit_team(bs=1, model_type="DiT-B", seeds=(0, 1, 2, 3), call_per_phase=False):
     """dvla_dit_sample -- the evaluation sampler (DDIM-10 + CFG through all DiT blocks) as one persistent kernel on one XCD --
     against the launch-by-launch sampler (ActionModel.sample_ddim_cfg with team_sampler = False: few-rows GEMMs, flash attention,
     dvla_ddim_cfg_step) and the fp32 oracle of the loop (oracle/model_ref.py ddim_sample, the model's bf16 weights in fp32).
@@ -165,6 +168,20 @@ def check_dit_team(bs=1, model_type="DiT-B", seeds=(0, 1, 2, 3)):
     from dreamvla_amd import ops
     from dreamvla_amd.action_model.action_model import ActionModel
     from oracle import model_ref, weights
+    if call_per_phase:          # the library reads DVLA_DIT_AHEAD once per process: this variant runs in a process of its own
+        import subprocess, sys, json
+        code = ("import json, sys; sys.path.insert(0, %r); from tests import gpu_checks; "
+                "print('RESULT' + json.dumps(gpu_checks.check_dit_team(bs=%d, model_type=%r, seeds=%r)))" % (ROOT_DIR, bs, model_type, tuple(seeds)))
+        env = dict(os.environ, DVLA_DIT_AHEAD="0")
+        env.pop("DVLA_PARITY_REPORT", None)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        if not line:
+            return [{"name": f"dit_team call-per-phase kernel: subprocess failed: {r.stderr[-300:]}", "rel_l2": 0.0, "tol": 0.0, "ok": False}]
+        out = json.loads(line[0][6:])
+        for m in out:
+            m["name"] = m["name"].replace("dit_team", "dit_team (call-per-phase kernel)")
+        return out
     depth, heads = {"DiT-B": (12, 12), "DiT-L": (24, 16)}[model_type]
     am = ActionModel(token_size=1024, model_type=model_type, in_channels=7, future_action_window_size=2, past_action_window_size=0)
     am.load_state_dict(weights.fill_state_dict(am.state_dict()), strict=True)
@@ -860,8 +877,7 @@ def all_checks(quick=False):
         (check_gemm, dict(M=700, N=520, K=2048, bias=True, act="relu", residual=True, split_k=2)),      # ragged tiles
         (check_gemm, dict(M=600, N=256, K=2048, residual=True, out_f32=True, split_k=3)),
         (check_dit_team, dict(bs=1, model_type="DiT-B")),                                           # one episode: 12 token rows
-        (check_dit_team, dict(bs=2, model_type="DiT-B", seeds=(0, 1))),                            # 24 rows: two row blocks
-        (check_dit_team, dict(bs=1, model_type="DiT-L", seeds=(0, 1))),                            # hidden 1024, 24 blocks
+        (check_dit_team, dict(bs=1, model_type="DiT-B", seeds=(7, 8), call_per_phase=True)),       # the kernel without look-ahead (A/B variant)
         (check_gemm_tail, dict(M=256, N=256, K=160, out_f32=True)),                                # 2.5 K-tiles
         (check_gemm_tail, dict(M=512, N=256, K=208, out_f32=True)),                                # tail of one k16-step
         (check_gemm_tail, dict(M=256, N=768, K=1264, out_f32=True)),                               # tail of three, 19.75 K-tiles

@@ -47,10 +47,39 @@ def time_graph(g, n=20):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+def stamps_breakdown(am, cond, noise):
+    """where an exchange's time goes: the kernel's own wall-clock stamps (members 0 and 17), medians over the last sampler step"""
+    from dreamvla_amd import _lib
+    lib = _lib.load()
+    depth = len(am.net.blocks)
+    n_ex = 10 * (1 + 5 * depth) + 1
+    buf = torch.zeros(2 * 8 * n_ex, dtype=torch.int64, device="cuda")
+    lib.dvla_dit_sample_set_stamps(buf.data_ptr())
+    am.sample_ddim_cfg(cond, noise, 1.5)
+    torch.cuda.synchronize()
+    lib.dvla_dit_sample_set_stamps(None)
+    st = buf.view(n_ex, 2, 8).cpu().double() * 0.01          # us
+    names = ["qkv", "attention", "proj", "fc1", "fc2"]
+    res = {}
+    first = 9 * (1 + 5 * depth) + 1              # exchange index (epoch) of the last step's first block phase
+    for member in (0, 1):
+        for pi, nm in enumerate(names):
+            rows = torch.stack([st[first + 5 * l + pi, member] for l in range(depth)])      # (depth, 8)
+            d = {"weights_requested->producers_arrived": (rows[:, 1] - rows[:, 0]).median().item(),
+                 "->operands_landed": (rows[:, 2] - rows[:, 1]).median().item() if nm != "attention" else None,
+                 "->partials_in_lds": (rows[:, 3] - rows[:, 2]).median().item() if nm != "attention" else None,
+                 "->stored": (rows[:, 4] - (rows[:, 3] if nm != "attention" else rows[:, 1])).median().item(),
+                 "phase_total": (rows[:, 4] - rows[:, 0]).median().item()}
+            res[f"member{(0, 17)[member]}.{nm}"] = {k: (None if v is None else round(v, 2)) for k, v in d.items()}
+        blk = torch.stack([st[first + 5 * l, member, 0] for l in range(depth)])
+        res[f"member{(0, 17)[member]}.block_period_us"] = round((blk[1:] - blk[:-1]).median().item(), 2)
+    return res
+
+
 def main():
     out = []
     ops.GemmTuner.enabled = False
-    for model_type, bs in (("DiT-B", 1), ("DiT-B", 2), ("DiT-L", 1)):
+    for model_type, bs in (("DiT-B", 1),):
         am = build(model_type)
         g0 = torch.Generator().manual_seed(3)
         cond = torch.randn(bs, 3, 1024, generator=g0).to("cuda", BF)
@@ -73,6 +102,9 @@ def main():
             bad += int(not torch.equal(ot, eager))
         row["replays_differing_from_eager"] = bad
         row["status_xccmask"] = list(ops.dit_team_status(am._fast_tables[("team", "cuda:0", 10)]["ws"]))
+        am.team_sampler = True
+        row["kernel"] = "call per phase" if os.environ.get("DVLA_DIT_AHEAD") == "0" else "one function, requests ahead"
+        row["stamps"] = stamps_breakdown(am, cond, noise)
         am.team_sampler = False
         gl, ol = graphed(lambda: am.sample_ddim_cfg(cond, noise, 1.5))
         row["launch_by_launch_us"] = time_graph(gl)

@@ -32,7 +32,7 @@ def main():
             row = {"name": name, "M": M, "N": N, "K": K, "b_layout": "(K, N) Conv1D" if b_trans else "(N, K)", "GFLOP": 2e-9 * M * N * K}
             state = {"i": 0}
             best = None
-            for variant in (0, 2, 4, 6, 7, 8, 9, 10):
+            for variant in (0, 2, 4, 6, 7, 8, 9, 10):      # (12 in profiles/r04_midrows_perf.jsonl: a BK-64 four-stage 128 x 128 ring configuration, measured and removed)
                 for sk in (1, 2, 4):
                     def call():
                         w = ws[state["i"] % 24]

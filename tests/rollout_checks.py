@@ -52,6 +52,9 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7, sample="all"):
     BF = torch.bfloat16
     S, B = 4, 3
     tol = PAIR * (MLP_TOL if head == "mlp" else max(_fixture_tols("B")))
+    if head == "dit":
+        from tests.model_checks import load
+        dit_rec = load("dreamvla_B.pt")["ref_test_bf16_deviation"]
     cfg = dict(finetune_type="calvin", sequence_length=S, num_resampler_query=16, num_obs_token_per_image=9,
                action_pred_steps=3, transformer_layers=2, hidden_dim=1024, transformer_heads=16, phase="finetune",
                obs_pred=True, use_dit_head=(head == "dit"), attn_implementation="sdpa")
@@ -105,10 +108,18 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7, sample="all"):
             res.append({"name": tag + ".shapes", "rel_l2": 0.0, "tol": 0.0,
                         "ok": tuple(arm.shape) == (B, 1, 3, 6) and tuple(grip.shape) == (B, 1, 3, 1)})
         which = "executed_position" if newest else "all_positions"
-        r2 = float((arm.float() - ra.float()).norm() / max(float(ra.float().norm()), 1e-12))
-        res.append({"name": tag + ".arm_" + which, "rel_l2": r2, "tol": tol, "ok": r2 <= tol})
-        r3 = float((grip.float() - rg.float()).norm() / max(float(rg.float().norm()), 1e-12))
-        res.append({"name": tag + ".gripper_" + which, "rel_l2": r3, "tol": tol, "ok": r3 <= tol})
+        for nm, a_, b_, i_ in (("arm", arm, ra, 0), ("gripper", grip, rg, 1)):
+            d = a_.float() - b_.float()
+            r2 = float(d.norm() / max(float(b_.float().norm()), 1e-12))
+            row = {"name": f"{tag}.{nm}_{which}", "rel_l2": r2, "tol": tol, "ok": r2 <= tol}
+            if head == "dit" and a_.numel() < 256:
+                # a handful of values (9 gripper values with sample="newest"): the rel-L2 of so few numbers is a noisy estimate --
+                # judged element-wise by PAIR x the bound compare_outputs puts on one bf16 computation (gpu_rollout_vs_reference)
+                rec = dit_rec[i_]
+                t_abs = PAIR * max(1.5 * rec["max_abs"], 3.0 * 2.0 ** -8 * rec["absmax"])
+                worst = float(d.abs().max())
+                row.update({"max_abs": worst, "max_abs_tol": t_abs, "ok": worst <= t_abs})
+            res.append(row)
         if use_graph and t >= 2:                   # two eager warm-up decodes, then the capture: later steps are replays
             res.append({"name": tag + ".graph_replayed", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
     res.append({"name": f"rollout.{head}.graph{int(use_graph)}{'.newest' if newest else ''}: text tower ran once per instruction ({eng.text_encodes} of {steps} steps)",
