@@ -1,0 +1,70 @@
+"""CPU: host-side rules added in round 4 for the evaluation engine -- the forward split-K rule and its scoping, the shapes the
+one-XCD sampler kernel takes, the engine's `sample=` modes (no GPU, no library calls)."""
+import pytest
+import torch
+
+from dreamvla_amd import ops
+from dreamvla_amd.rollout import RolloutEngine
+
+
+def test_fwd_split_k_rule():
+    # the evaluation engine's trunk at one episode (S = 10 / 7): the MLP down-projection is cut four ways, nothing else
+    assert ops.fwd_split_k(930, 1024, 4096) == 4 and ops.fwd_split_k(651, 1024, 4096) == 4
+    assert ops.fwd_split_k(930, 3072, 1024) == 1 and ops.fwd_split_k(930, 1024, 1024) == 1 and ops.fwd_split_k(930, 4096, 1024) == 1
+    # the few-rows kernel's territory, and problems that fill the chip by themselves
+    assert ops.fwd_split_k(512, 1024, 4096) == 1 and ops.fwd_split_k(120, 768, 3072) == 1
+    assert ops.fwd_split_k(20832, 1024, 4096) == 1 and ops.fwd_split_k(59520, 1024, 4096) == 1
+    # at least 1024 of K per split, at most tiles x splits ~ the CU count
+    for (M, N, K) in [(600, 256, 2048), (1576, 768, 3072), (700, 512, 8192), (1000, 128, 65536)]:
+        s = ops.fwd_split_k(M, N, K)
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        assert 1 <= s <= 8 and K // s >= 1024 and tiles * s <= 256 + tiles
+
+
+def test_forward_split_k_is_scoped():
+    assert ops.FWD_SPLIT_K is False                  # not a default: training-mode kernels stay row-independent
+    with ops.forward_split_k():
+        assert ops.FWD_SPLIT_K is ops.FWD_SPLIT_K_ALLOWED
+        with ops.forward_split_k(False):
+            assert ops.FWD_SPLIT_K is False
+        assert ops.FWD_SPLIT_K is ops.FWD_SPLIT_K_ALLOWED
+    assert ops.FWD_SPLIT_K is False
+    with pytest.raises(RuntimeError):
+        with ops.forward_split_k():
+            raise RuntimeError("x")
+    assert ops.FWD_SPLIT_K is False                  # restored on the way out of an exception too
+
+
+def test_dit_team_shapes():
+    cpu = torch.device("cpu")
+    assert not ops.dit_team_ok(768, 12, 7, 3, 1, cpu)            # no GPU: never
+
+
+class _Act:
+    in_channels = 7
+
+
+class _FakeDiTModel(torch.nn.Module):
+    sequence_length = 4
+    hidden_dim = 8
+    use_dit_head = True
+    action_pred_steps = 3
+    action_model = _Act()
+
+    def __init__(self):
+        super().__init__()
+        self.transformer_backbone = torch.nn.Linear(8, 8)
+        self.eval()
+
+
+def test_engine_sample_modes():
+    m = _FakeDiTModel()
+    with pytest.raises(ValueError):
+        RolloutEngine(m, 2, use_graph=False, sample="last")
+    newest = RolloutEngine(m, 2, use_graph=False)                 # the default
+    assert newest.sample_all is False and tuple(newest.draw_noise().shape) == (2, 3, 7)
+    every = RolloutEngine(m, 2, use_graph=False, sample="all")
+    assert every.sample_all is True and tuple(every.draw_noise().shape) == (2 * 4, 3, 7)
+    m.use_dit_head = False                                          # the MLP head samples nothing: always all positions
+    mlp = RolloutEngine(m, 2, use_graph=False)
+    assert mlp.sample_all is True and mlp.needs_noise is False
