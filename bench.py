@@ -457,7 +457,9 @@ def main():
             r = gpu_rollout_bench.run(Bs=(64, 1), naive=False, eager_engine=False, steps=12)
             rows = {row["B"]: row for row in r["rows"]}
             rollout = {"metric": "closed-loop control steps/s (BASELINE configs[4]: eval rollout, 64 episodes in lock-step, S = 10 "
-                                 "history, DiT head with DDIM-10 + CFG, hipGraph-captured encode / decode, per-frame token cache)",
+                                 "history, DiT head with DDIM-10 + CFG, hipGraph-captured encode / decode, per-frame token cache; "
+                                 "the sampler runs on the window position the wrapper executes -- RolloutEngine(sample='newest') -- "
+                                 "and, at one episode, as one persistent kernel on one XCD)",
                        "value": rows[64]["episode_steps_per_s"]["graph"], "unit": "episode-steps/s", "episodes": 64,
                        "ms_per_lockstep": rows[64]["graph_ms_per_step"], "single_episode_ms_per_step": rows[1]["graph_ms_per_step"],
                        "dtype": "bf16", "data": "synthetic"}
