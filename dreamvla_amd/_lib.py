@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVLA_LIB") or os.path.join(_HERE, "libdvla_hip.so")
 
 DT_BF16, DT_F32 = 0, 1
-ABI_VERSION = 6          # DVLA_ABI_VERSION of include/dvla.h
+ABI_VERSION = 7          # DVLA_ABI_VERSION of include/dvla.h
 ACT = {"none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "gelu_new": 2, "relu": 3, "silu": 4,
        "quick_gelu": 5, "tanh": 6, "sigmoid": 7}
 
@@ -118,6 +118,7 @@ SYMBOLS = {
     "dvla_dit_sample_workspace_bytes": (C.c_int64, [_I32]),
     "dvla_dit_sample": (C.c_int, [C.POINTER(DitSampleParams), _P]),
     "dvla_dit_sample_set_stamps": (None, [_P]),
+    "dvla_dit_sample_inject_timeouts": (None, [_I32]),
     "dvla_cast_f32_to_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_cast_bf16_to_f32": (C.c_int, [_P, _P, _I64, _P]),
     "dvla_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),

@@ -100,7 +100,7 @@ class ActionModel(nn.Module):
             ck = ("team", str(cond.device), dd.num_timesteps)
             if ck not in cache:
                 cache[ck] = {"coef": torch.tensor(np.array([coefficients(i) for i in steps], dtype=np.float32), device=cond.device),
-                             "ws": ops.dit_team_workspace(hidden, cond.device), "ptrs": None, "table": None}
+                             "ws": ops.dit_team_workspace(hidden, cond.device), "ptrs": None, "table": None, "timeouts": 0}
             st = cache[ck]
             ws = [ops.shadow(w).contiguous() for blk in net.blocks
                   for w in (blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias,
@@ -115,11 +115,19 @@ class ActionModel(nn.Module):
                                       sh(net.x_embedder.linear.bias), sh(net.final_layer.linear.weight),
                                       sh(net.final_layer.linear.bias), pos.contiguous(), cond_tab, st["coef"], x, cfg_scale,
                                       net.blocks[0].norm1.eps, st["ws"])
+            self.team_launches = getattr(self, "team_launches", 0) + 1       # (a captured launch counts once: RolloutEngine reads
+            #                                                                    "did the decode graph contain the team kernel" off it)
             if not torch.cuda.is_current_stream_capturing():
-                status, xcc = ops.dit_team_status(st["ws"])
+                # eager calls check at once.  Under hipGraph replay no Python runs: RolloutEngine.step checks the ACTION it is about
+                # to hand out and falls back to the launch-by-launch sampler (round-4 ADVICE); the kernel retires its own status,
+                # so the launch after a timeout is clean.
+                timeouts, xcc = ops.dit_team_status(st["ws"])
                 self.team_xcc_mask = xcc
-                if status != 0:
-                    raise RuntimeError(f"dvla_dit_sample: an exchange inside the kernel timed out (status {status}, XCC mask {xcc:#x})")
+                if timeouts != st["timeouts"]:
+                    st["timeouts"] = timeouts
+                    raise ops.DitTeamTimeout(f"dvla_dit_sample: an exchange inside the kernel timed out (the output of this call is NaN; "
+                                       f"{timeouts} launches so far, XCC mask {xcc:#x}); set `team_sampler = False` on the action "
+                                       f"model for the launch-by-launch sampler")
             return out
         for j, i in enumerate(steps):
             xe = net.x_embedder(x.to(wdt))                                               # (bs, T, H)

@@ -80,36 +80,37 @@ class DeviceCollator:
             t = t.pin_memory()
         return t
 
-    def _shifts(self, n, pad):
-        if pad == -1:
-            return None, 0
-        # RandomShiftsAug.forward draws randint(0, 2 pad + 1) per image, forward_traj randint(1, 2 pad + 1) per frame
-        # (data_utils.py:344-348 / 371-375): one (sx, sy) pair per frame either way
-        return P.draw_shifts(n, pad, traj=self.traj_cons, generator=self.generator), pad
+    def _shifts(self, n, pad, key):
+        """the (n, 2) integer shifts of one RandomShiftsAug call; `key` names the entry they are for ("rgb_static",
+        "depth_static", "rgb_gripper", "depth_gripper" -- drawn in this order, the order of the reference's calls,
+        data_utils.py:1336-1355).  RandomShiftsAug.forward draws randint(0, 2 pad + 1) per image, forward_traj
+        randint(1, 2 pad + 1) per frame (data_utils.py:344-348 / 371-375): one (sx, sy) pair per frame either way.
+        The parity test replaces this method to inject the shifts the real collator drew (tests/test_collate.py)."""
+        return P.draw_shifts(n, pad, traj=self.traj_cons, generator=self.generator)
 
     def _camera(self, sample, cam, pad):
         u8 = self._frames_u8(sample, cam)
         B, T = u8.shape[:2]
-        shifts, pad = self._shifts(B * T, pad)
+        shifts = None if pad == -1 else self._shifts(B * T, pad, cam)
         dev = u8.to(self.device, non_blocking=True)
-        return P.preprocess_frames(dev, shifts, pad)             # (B, T, 3, H, W) bf16, one kernel
+        return P.preprocess_frames(dev, shifts, 0 if pad == -1 else pad)             # (B, T, 3, H, W) bf16, one kernel
 
     def _depth(self, sample, cam, pad):
         d = torch.stack([depth_image_fn(s["depth_obs"][cam], self.n_px) for s in sample])      # (B, T, 1, H, W) fp32, host
         if pad != -1 and self.traj_cons:         # (the reference shifts the depth maps only on the traj_cons path, with their OWN draw)
             B, T = d.shape[:2]
-            sh = P.draw_shifts(B * T, pad, traj=True, generator=self.generator)
+            sh = self._shifts(B * T, pad, cam)
             d = P.shift_gather_reference(d.view(B * T, *d.shape[2:]), sh, pad).view_as(d)
         return d
 
     def __call__(self, sample):
         action_tensors = torch.from_numpy(np.array([np.stack(s["actions"]) for s in sample]))
         state_tensors = torch.from_numpy(np.array([np.stack(s["robot_obs"]) for s in sample]))
-        image_tensors = self._camera(sample, "rgb_static", self.rgb_pad)
-        gripper_tensors = self._camera(sample, "rgb_gripper", self.gripper_pad)
         libero = self.dataset == "libero"
         has_depth = (not libero) and "depth_obs" in sample[0]
+        image_tensors = self._camera(sample, "rgb_static", self.rgb_pad)
         depth_static = self._depth(sample, "depth_static", self.rgb_pad) if has_depth else None
+        gripper_tensors = self._camera(sample, "rgb_gripper", self.gripper_pad)
         depth_gripper = self._depth(sample, "depth_gripper", self.gripper_pad) if has_depth else None
         if libero:
             _ = [s["episode_id"] for s in sample]        # KeyError on a sample without one, like the reference

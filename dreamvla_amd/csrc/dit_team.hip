@@ -129,6 +129,26 @@ __device__ __forceinline__ void team_wait(const Team& tm) {
   }
 }
 
+// The last member to leave finds nobody polling: it zeroes the counters for the next launch (no memset node: see the file header)
+// and RETIRES a timeout of this launch -- word 32 (which member 0 has already turned into a NaN output) is moved to the history
+// words 33 (launches that timed out so far) and 34 (the last non-zero status) and cleared, so that one timeout on a busy GPU no
+// longer poisons every later launch on this workspace (round-4 ADVICE; the host compares word 33 with the count it saw last).
+__device__ __forceinline__ void team_leave(unsigned* ctr) {
+  if (threadIdx.x == 0) {
+    const unsigned left = __hip_atomic_fetch_add(ctr + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == TEAM - 1) {
+      const unsigned st = __hip_atomic_load(ctr + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (st != 0u) {
+        __hip_atomic_store(ctr + 34, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(ctr + 33, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctr + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctr + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 struct Args {
   const dvla_dit_block_weights* blocks;
   const bf16_t *xemb_w, *xemb_b, *final_w, *final_b, *pos, *cond;
@@ -137,9 +157,11 @@ struct Args {
   float* out;
   bf16_t *X, *QKV, *O, *HID;
   unsigned long long* stamps;
-  unsigned* ctr;       // [0] team counter, [16] workgroups that have left, [32] status, [64 + r] XCC id of member r (last launch)
+  unsigned* ctr;       // [0] team counter, [16] workgroups that have left, [32] status of the running launch, [33] launches that timed
+                       // out so far, [34] last non-zero status, [64 + r] XCC id of member r (last launch)
   float cfg, eps;
   int depth, D, H, C, T, bs, steps;
+  int inject;          // test hook (dvla_dit_sample_inject_timeouts): member 1 reports a timeout at the start of the launch
 };
 
 enum { EPI_BIAS = 0, EPI_BIAS_RES = 1, EPI_BIAS_GELU = 2, EPI_FINAL = 3 };
@@ -555,6 +577,7 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel(Args a) {
   if (threadIdx.x == 0) {
     *reinterpret_cast<int*>(dit_lds + DEAD_OFF) = 0;
     a.ctr[64 + tm.rank] = xcc_id();                  // diagnostics: where the team runs (all members on one XCC = the fast case)
+    if (a.inject && tm.rank == 1) __hip_atomic_store(tm.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   const int L = 2 * a.T, R = 2 * a.bs * L;
@@ -591,13 +614,7 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel(Args a) {
   // The counters are reset BY THE TEAM, from the XCC that counts on them -- not by a memset node in front of the launch: under
   // hipGraph replay a memset's zeros (written by another agent) were not reliably what this XCC's L2 served to the next launch's
   // device-scope atomics (intermittent barriers that did not wait, round 4).  The last member to leave finds nobody polling.
-  if (threadIdx.x == 0) {
-    const unsigned left = __hip_atomic_fetch_add(a.ctr + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == TEAM - 1) {
-      __hip_atomic_store(a.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.ctr + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  team_leave(a.ctr);
 }
 
 // The same schedule in one function (no call per phase: 2.4 us of register saves, argument traffic and a drained memory queue per
@@ -624,6 +641,7 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel_ahead(Args a) {
   if (threadIdx.x == 0) {
     *reinterpret_cast<int*>(dit_lds + DEAD_OFF) = 0;
     a.ctr[64 + tm.rank] = xcc_id();
+    if (a.inject && tm.rank == 1) __hip_atomic_store(tm.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   const int L = 2 * a.T, R = 2 * a.bs * L;
@@ -686,13 +704,7 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel_ahead(Args a) {
       for (int ss = 0; ss < KS; ++ss) pin(wq.w[jj][ss]);
     pin(wq.b);
   }
-  if (threadIdx.x == 0) {
-    const unsigned left = __hip_atomic_fetch_add(a.ctr + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == TEAM - 1) {
-      __hip_atomic_store(a.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.ctr + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  team_leave(a.ctr);
 }
 
 size_t team_smem_bytes(int KS, int RB) {
@@ -714,6 +726,11 @@ extern "C" int64_t dvla_dit_sample_workspace_bytes(int32_t hidden) {
 // fill with wall-clock stamps of team members 0 and 17 -- null (the default) switches the stamping off
 static unsigned long long* g_dit_stamps = nullptr;
 extern "C" void dvla_dit_sample_set_stamps(void* buf) { g_dit_stamps = reinterpret_cast<unsigned long long*>(buf); }
+
+// test hook (tests/rollout_checks.py): the next n launches report a timeout (status 3) -- their outputs are NaN and word 33 of the
+// workspace counts them -- so that the callers' recovery path can be exercised without a busy GPU
+static int g_dit_inject = 0;
+extern "C" void dvla_dit_sample_inject_timeouts(int32_t n) { g_dit_inject = n > 0 ? n : 0; }
 
 extern "C" int dvla_dit_sample(const dvla_dit_sample_params* q, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -740,6 +757,8 @@ extern "C" int dvla_dit_sample(const dvla_dit_sample_params* q, void* stream_) {
   a.pos = (const bf16_t*)q->pos; a.cond = (const bf16_t*)q->cond;
   a.coef = q->coef; a.noise = q->noise; a.out = q->out;
   a.stamps = g_dit_stamps;
+  a.inject = 0;
+  if (g_dit_inject > 0) { a.inject = 1; --g_dit_inject; }
   char* ws = reinterpret_cast<char*>(q->workspace);
   a.ctr = reinterpret_cast<unsigned*>(ws);
   a.X = reinterpret_cast<bf16_t*>(ws + 1024);

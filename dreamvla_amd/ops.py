@@ -567,13 +567,24 @@ def dit_team_workspace(hidden, device):
 
 
 def dit_team_status(workspace):
-    """(status, xcc_mask) of the last dvla_dit_sample launch on this workspace -- synchronises.  status 0 = every exchange
-    completed; xcc_mask: bit i set = a team member ran on XCC i (one bit = the team shared one L2: the fast case)."""
+    """(timeouts, xcc_mask) of the dvla_dit_sample launches on this workspace -- synchronises.  timeouts = how many launches so
+    far had a wait inside the kernel time out (their outputs are NaN; the count only grows, a launch retires its own status:
+    include/dvla.h); xcc_mask: bit i set = a team member of the LAST launch ran on XCC i (one bit = the team shared one L2: the
+    fast case)."""
     w = workspace[:384].view(torch.int32).cpu()
     mask = 0
     for x in w[64:96].tolist():
         mask |= 1 << (x & 15)
-    return int(w[32]), mask
+    return int(w[33]), mask
+
+
+class DitTeamTimeout(RuntimeError):
+    """a wait inside dvla_dit_sample timed out (the 32 workgroups were not co-resident: shared / busy GPU); the call's output is NaN"""
+
+
+def dit_team_inject_timeouts(n):
+    """test hook: the next n dvla_dit_sample launches report a timeout (tests/rollout_checks.py exercises the recovery path)"""
+    _lib.load().dvla_dit_sample_inject_timeouts(int(n))
 
 
 def dit_team_sample(block_ptrs, depth, hidden, heads, xemb_w, xemb_b, final_w, final_b, pos, cond, coef, noise, cfg_scale, ln_eps,

@@ -21,6 +21,8 @@ over independent episodes) and removes the redundant work:
 Episodes of one batch advance in lock-step (one `step` = one control step of every episode); `reset(mask)` restarts
 the episodes selected by a boolean mask (their history is cleared, the others keep theirs).
 """
+import warnings
+
 import torch
 
 from . import ops
@@ -60,7 +62,7 @@ class _Graphed:
 
 
 class RolloutEngine:
-    def __init__(self, model, batch_size, history_len=None, use_graph=True, warmup_decodes=3, sample="newest"):
+    def __init__(self, model, batch_size, history_len=None, use_graph=True, warmup_decodes=3, sample="newest", text="latched"):
         self.model = model.module if hasattr(model, "module") else model
         m = self.model
         if m.training:
@@ -85,9 +87,19 @@ class RolloutEngine:
         # sampler's batch elements are independent, so "newest" -- DDIM over B rows instead of B * S -- returns the same
         # executed action from the same noise row; "all" keeps the reference's (B, S, steps, .) action outputs.
         self.sample_all = (sample == "all") or not self.needs_noise
+        # Instruction text.  "latched" = the wrapper's semantics, literally (eval_utils_calvin.py:109-112: `text_queue` is filled
+        # once, when it is empty -- i.e. at the first step after `reset()` -- and kept): an episode's instruction is the one it was
+        # given at its first step after a reset; a different `text_token` row later is ignored until the next reset.  "current" =
+        # every step conditions the whole window on the row passed to that step (the two agree whenever the caller resets when
+        # the instruction changes, as evaluate_sequence does per subtask).  round-4 ADVICE.
+        if text not in ("latched", "current"):
+            raise ValueError('text: "latched" (kept from the first step after reset(), as ModelWrapper.step) or "current"')
+        self.text_mode = text
+        self._latched = None
         self._no_noise = torch.zeros(1, device=self.device)
         self._decode_g = _Graphed(self._decode_eager, warmup_decodes) if self.use_graph else None
         self._encode_g = _Graphed(self._encode_eager, warmup_decodes) if self.use_graph else None
+        self.team_fallbacks = 0                 # times the one-XCD sampler kernel timed out and the engine fell back (see step)
 
     # ------------------------------------------------------------------------------------------------------------
     def reset(self, mask=None):
@@ -181,7 +193,24 @@ class RolloutEngine:
         gripper command in {-1, +1} as ModelWrapper.step builds it (eval_utils_calvin.py:136-146), arm (B,S,steps,6),
         gripper (B,S,steps,1); with the DiT head and sample="newest" the last two are (B,1,steps,.): the executed position
         only).  `noise`: the DiT sampler's start noise (see draw_noise; a (B*S, steps, 7) draw is accepted with "newest" too --
-        the executed position's rows are taken); None = drawn here."""
+        the executed position's rows are taken); None = drawn here.
+        `text_token`: see `text=` of the constructor -- by default an episode keeps the instruction of its first step after a reset."""
+        if self.text_mode == "latched":
+            fresh = (self.count == 0) if self.tokens is not None else torch.ones(self.B, dtype=torch.bool)
+            if self._latched is None or bool(fresh.all()):
+                self._latched = text_token.to(self.device).clone()
+            elif bool(fresh.any()):        # (a new tensor object: text_embedding compares and re-encodes only if a row changed)
+                self._latched = torch.where(fresh.to(self.device).view(-1, 1), text_token.to(self.device), self._latched)
+            text_token = self._latched
+        try:
+            return self._step(image_primary, image_wrist, state, text_token, noise)
+        except ops.DitTeamTimeout:
+            # an EAGER sampler call (warm-up before the capture, or use_graph=False) noticed the timeout itself; the frame was
+            # already pushed: fall back and decode this step again
+            self._team_fallback()
+            return self._finish_step(noise)
+
+    def _step(self, image_primary, image_wrist, state, text_token, noise):
         dt = self.dtype
         new_tok = self.encode_newest(image_primary.to(self.device, dt), image_wrist.to(self.device, dt),
                                      state.to(self.device, dt), text_token.to(self.device))
@@ -189,6 +218,9 @@ class RolloutEngine:
         # the wrapper conditions EVERY frame of the window on the current instruction (eval_utils_calvin.py:127-134 repeat the
         # text over the window), so the text token (slot 0 of a frame's 36) is not history: all S frames carry today's embedding
         self.tokens[:, :, 0] = self._text_emb.to(self.tokens.dtype).unsqueeze(1)
+        return self._finish_step(noise)
+
+    def _finish_step(self, noise):
         B, S = self.B, self.S
         sel = (self.count - 1).to(self.device)                               # newest real frame of each episode
         bi = torch.arange(B, device=self.device)
@@ -200,7 +232,20 @@ class RolloutEngine:
             noise = noise.to(self.device, torch.float32)
             if not self.sample_all and noise.shape[0] == B * S and S > 1:
                 noise = noise.view(B, S, *noise.shape[1:])[bi, sel]
-        arm, grip = self._decode(self.tokens, noise, sel)
+        action, arm, grip = self._actions(*self._decode(self.tokens, noise, sel), sel, bi)
+        if self._team_sampler_in_use() and not bool(torch.isfinite(action).all()):
+            # The one-XCD sampler kernel (dvla_dit_sample) bounds every wait; on a GPU that other work keeps busy its 32 workgroups
+            # may not be co-resident, a wait times out and the kernel returns NaN by design.  Under hipGraph replay no Python runs
+            # inside the sampler, so the check is HERE, on the action about to be handed to the environment (round-4 ADVICE: a NaN
+            # arm command with gripper -1 went straight out).  It costs one host read of 7 values per step, on the single-episode
+            # path only -- whose caller reads the action next anyway.  Recovery: the launch-by-launch sampler (same arithmetic),
+            # decode graph re-captured, this step's action recomputed from the same tokens and noise.
+            self._team_fallback()
+            action, arm, grip = self._actions(*self._decode(self.tokens, noise, sel), sel, bi)
+        return action, arm, grip
+
+    def _actions(self, arm, grip, sel, bi):
+        B, S = self.B, self.S
         if arm.dim() == 4 and arm.shape[0] == 1 and B * S == arm.shape[1] and self.sample_all:   # DiT test head returns (1, B*S, steps, .)
             arm, grip = arm.view(B, S, *arm.shape[2:]), grip.view(B, S, *grip.shape[2:])
         elif arm.dim() == 4 and arm.shape[0] == 1 and not self.sample_all:                        # (1, B, steps, .)
@@ -209,5 +254,20 @@ class RolloutEngine:
             sel = torch.zeros_like(sel)
         a = arm[bi, sel, 0, :].float()
         g = (grip[bi, sel, 0, :].float() > 0.5).float()
-        action = torch.cat((a, (g - 0.5) * 2), dim=-1)
-        return action, arm, grip
+        return torch.cat((a, (g - 0.5) * 2), dim=-1), arm, grip
+
+    def _team_sampler_in_use(self):
+        """did the decode path (eager, or the captured graph) launch the persistent sampler kernel?  (`ActionModel.sample_ddim_cfg`
+        counts its team launches; the shapes that take it are decided there: one episode, DiT-B)"""
+        am = getattr(self.model, "action_model", None)
+        return bool(self.needs_noise and am is not None and getattr(am, "team_sampler", True) and getattr(am, "team_launches", 0) > 0)
+
+    def _team_fallback(self):
+        am = self.model.action_model
+        am.team_sampler = False
+        am.team_launches = 0
+        self.team_fallbacks += 1
+        if self.use_graph:                       # the captured decode contains the team kernel: warm up and capture again
+            self._decode_g = _Graphed(self._decode_eager, self.warmup_decodes)
+        warnings.warn("RolloutEngine: dvla_dit_sample timed out (the GPU is shared or busy: its 32 workgroups were not co-resident); "
+                      "this engine now runs the launch-by-launch sampler", RuntimeWarning)

@@ -38,8 +38,9 @@ extern "C" {
 /* ABI revision of this header; dreamvla_amd/_lib.py refuses a library that reports another one (a stale prebuilt .so then fails
  * with a clear message instead of a missing-symbol error).  3 = round 3 (dvla_last_gemm_variant, variant 10, ...); 4 = k-sums on the
  * weight-gradient GEMM (ksum_* fields of dvla_gemm_params); 5 = dvla_ddim_cfg_step, dvla_act_bwd_colsum, a_layernorm,
- * GEMM configuration 11; 6 = dvla_dit_sample (the evaluation sampler as one persistent kernel). */
-#define DVLA_ABI_VERSION 6
+ * GEMM configuration 11; 6 = dvla_dit_sample (the evaluation sampler as one persistent kernel); 7 = round 5: the sampler's
+ * status word no longer carries over to the next launch (workspace words 33 / 34), dvla_dit_sample_inject_timeouts. */
+#define DVLA_ABI_VERSION 7
 int dvla_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -246,8 +247,10 @@ int dvla_ddim_cfg_step(const void* model_out, int64_t sample_stride, const float
  *   coef       (steps, 4) fp32 on the device: a, b, sqrt_acp_prev, sqrt_1m_acp_prev of dvla_ddim_cfg_step per sampler step
  *   noise/out  (bs, tokens, channels) fp32: start noise / samples (NaN if a wait inside the kernel timed out)
  *   workspace  dvla_dit_sample_workspace_bytes(hidden) bytes, 16-byte aligned, ZERO-INITIALISED by the caller once (the kernel
- *              leaves its counters at zero); 32-bit word 32 = status (0 ok; sticky), words 64 .. 95 = the XCC id each of the 32
- *              team members ran on in the last launch (all equal = the fast case), valid after a launch
+ *              leaves its counters at zero); 32-bit word 33 = number of launches so far in which a wait timed out (their outputs
+ *              are NaN; the launch retires its own status word 32, so a timeout does not carry over to the next launch), word 34 =
+ *              the last non-zero status, words 64 .. 95 = the XCC id each of the 32 team members ran on in the last launch (all
+ *              equal = the fast case), valid after a launch
  * DVLA_ERR_UNSUPPORTED unless hidden = 768 (DiT-B), head_dim 64, 2 tokens <= 8, 4 bs tokens <= 16 rows (one episode),
  * channels <= 16, on a device with 256 CUs: the caller then runs the launch-by-launch sampler (which is the faster one for two
  * row blocks and for hidden 1024: profiles/r04_dit_team_perf.jsonl). */
@@ -271,6 +274,9 @@ int dvla_dit_sample(const dvla_dit_sample_params* p, void* stream);
  * (100 MHz) of team members 0 and 17 -- per exchange: weights requested, producers arrived, operands landed, partial tiles in
  * LDS, results stored; NULL (the default) switches it off */
 void dvla_dit_sample_set_stamps(void* device_buffer);
+/* test hook: the next n dvla_dit_sample launches behave as if a wait inside the kernel had timed out (NaN output, workspace word 33
+ * incremented); a launch captured into a hipGraph while the hook is armed times out on every replay */
+void dvla_dit_sample_inject_timeouts(int32_t n);
 /* dst(bf16) = src(fp32) / dst(fp32) = src(bf16) */
 int dvla_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dvla_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

@@ -158,13 +158,16 @@ def check_act_bwd_colsum(rows, cols, act="none", dropout_p=0.0, out_bf16=False, 
             metrics(tag + " column sums", db, want, TOL_FWD if out_bf16 else 1e-5, round_ref=out_bf16)]
 
 
-def check_dit_team(bs=1, model_type="DiT-B", seeds=(0, 1, 2, 3), call_per_phase=False):
+def check_dit_team(bs=1, model_type="DiT-B", seeds=(0, 1, 2, 3), call_per_phase=False, fp32_master=False):
     """dvla_dit_sample -- the evaluation sampler (DDIM-10 + CFG through all DiT blocks) as one persistent kernel on one XCD --
     against the launch-by-launch sampler (ActionModel.sample_ddim_cfg with team_sampler = False: few-rows GEMMs, flash attention,
     dvla_ddim_cfg_step) and the fp32 oracle of the loop (oracle/model_ref.py ddim_sample, the model's bf16 weights in fp32).
     Both HIP paths are bf16 computations of the same function with the same rounding points; ten sampler steps amplify their
     rounding noise alike, so the persistent kernel's deviation from the fp32 samples may be at most 1.5 x the launch-by-launch
-    path's (pooled over the seeds) -- and it must be bit-reproducible, finish every exchange, and run on one XCC."""
+    path's (pooled over the seeds) -- and it must be bit-reproducible, finish every exchange, and run on one XCC.
+    fp32_master (round-4 ADVICE): the parameters stay fp32 masters (`--precision fp32`, every shipped script); the launch-by-launch
+    path then hands the fp32 BIASES to the GEMM epilogues while the persistent kernel reads their bf16 shadows -- one more rounding
+    of a bias (relative 2^-9 of the bias value), the same bounds must hold."""
     from dreamvla_amd import ops
     from dreamvla_amd.action_model.action_model import ActionModel
     from oracle import model_ref, weights
@@ -185,10 +188,16 @@ def check_dit_team(bs=1, model_type="DiT-B", seeds=(0, 1, 2, 3), call_per_phase=
     depth, heads = {"DiT-B": (12, 12), "DiT-L": (24, 16)}[model_type]
     am = ActionModel(token_size=1024, model_type=model_type, in_channels=7, future_action_window_size=2, past_action_window_size=0)
     am.load_state_dict(weights.fill_state_dict(am.state_dict()), strict=True)
-    am = am.to(BF).to(DEV).eval()
+    if fp32_master:       # values that are NOT bf16-representable: shadows (weights: both paths; biases: the team kernel) really round
+        am.load_state_dict({k: (v * 1.0009765625 if v.is_floating_point() else v) for k, v in am.state_dict().items()})
+        am = am.to(DEV).eval()
+        # the oracle computes on what the kernels' GEMMs compute on: bf16-rounded weight matrices, fp32 biases / vectors
+        sd32 = {k: (v.to(BF).float() if v.dim() >= 2 else v.float()).cpu() for k, v in am.state_dict().items()}
+    else:
+        am = am.to(BF).to(DEV).eval()
+        sd32 = {k: v.float().cpu() for k, v in am.state_dict().items()}
     am.create_ddim(10)
-    sd32 = {k: v.float().cpu() for k, v in am.state_dict().items()}
-    tag = f"dit_team {model_type} bs{bs}"
+    tag = f"dit_team {model_type} bs{bs}" + (" fp32 masters" if fp32_master else "")
     hidden = am.net.x_embedder.linear.out_features
     taken = ops.dit_team_ok(hidden, heads, 7, 3, bs, torch.device(DEV, torch.cuda.current_device()))
     res = [{"name": tag + ": shape taken by the persistent kernel", "rel_l2": 0.0, "tol": 0.0, "ok": bool(taken)}]
@@ -198,6 +207,8 @@ def check_dit_team(bs=1, model_type="DiT-B", seeds=(0, 1, 2, 3), call_per_phase=
         g = torch.Generator().manual_seed(700 + sd)
         cond = rnd((bs, 3, 1024), g).to(DEV, BF)
         noise = rnd((bs, 3, 7), g).to(BF).float().to(DEV)
+        if fp32_master:
+            cond = cond.float()
         am.team_sampler = True
         out_t = am.sample_ddim_cfg(cond, noise, 1.5)
         out_t2 = am.sample_ddim_cfg(cond, noise, 1.5)
@@ -878,6 +889,7 @@ def all_checks(quick=False):
         (check_gemm, dict(M=600, N=256, K=2048, residual=True, out_f32=True, split_k=3)),
         (check_dit_team, dict(bs=1, model_type="DiT-B")),                                           # one episode: 12 token rows
         (check_dit_team, dict(bs=1, model_type="DiT-B", seeds=(7, 8), call_per_phase=True)),       # the kernel without look-ahead (A/B variant)
+        (check_dit_team, dict(bs=1, model_type="DiT-B", seeds=(4, 5), fp32_master=True)),          # fp32 master parameters: bf16 bias shadows
         (check_gemm_tail, dict(M=256, N=256, K=160, out_f32=True)),                                # 2.5 K-tiles
         (check_gemm_tail, dict(M=512, N=256, K=208, out_f32=True)),                                # tail of one k16-step
         (check_gemm_tail, dict(M=256, N=768, K=1264, out_f32=True)),                               # tail of three, 19.75 K-tiles

@@ -38,10 +38,13 @@ def main():
     by_grid = "--by-grid" in sys.argv
     if by_grid:
         sys.argv.remove("--by-grid")
+    full = "--full-names" in sys.argv      # keep the template arguments: one row per instantiation (operand layout, epilogue class)
+    if full:
+        sys.argv.remove("--full-names")
     d = sys.argv[1]
 
     def key_of(r, kn, gs):
-        k = short(r[kn])
+        k = r[kn].split("(")[0].replace("void ", "").strip()[:110] if full else short(r[kn])
         return f"{k} grid={r[gs]}" if (by_grid and gs) else k
     agg = defaultdict(lambda: {"launches": 0, "dur_ns": 0.0, "counters": defaultdict(float), "disp": set()})
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -83,7 +86,9 @@ def main():
     rows = sorted(out.items(), key=lambda kv: -(kv[1]["avg_us"] or 0) * kv[1]["launches"])
     for k, r in rows[:30]:
         extra = " ".join(f"{x}={r[x]:.4g}" for x in ("mfma_busy_frac", "fetch_bytes_per_launch", "write_bytes_per_launch", "fetch_GBps", "write_GBps") if x in r)
-        print(f"{k[:70]:70s} x{r['launches']:5d} avg {r['avg_us'] or 0:9.1f} us  {extra}")
+        if full:
+            extra += " " + " ".join(f"{x}={v:.4g}" for x, v in sorted(r["counters_per_launch"].items()))
+        print(f"{k[:110 if full else 70]:{110 if full else 70}s} x{r['launches']:5d} avg {r['avg_us'] or 0:9.1f} us  {extra}")
     if len(sys.argv) > 2:
         with open(sys.argv[2], "w") as f:
             json.dump(out, f, indent=1)

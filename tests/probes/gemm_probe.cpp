@@ -347,6 +347,15 @@ int main(int argc, char** argv) {
       {"two stores K64", 20832, 4096, 64, 0, 0, "none_preact", 1},
       {"two stores + tanh-GELU K64", 20832, 4096, 64, 0, 0, "gelu_tanh_preact", 1},
     };
+  } else if (which == "pmc") {   // counter passes on the phase kernel: one launch class per operand layout (k- / r-contiguous)
+    cases = {
+      {"square NN", 8192, 8192, 8192, 0, 0, "plain", 1},
+      {"square NT", 8192, 8192, 8192, 0, 1, "plain", 1},
+      {"square TT", 8192, 8192, 8192, 1, 1, "f32", 1},
+      {"K1024 NN", 20832, 4096, 1024, 0, 0, "plain", 1},
+      {"K1024 NT", 20832, 4096, 1024, 0, 1, "plain", 1},
+      {"K1024 NN fused", 20832, 4096, 1024, 0, 0, "gelu_tanh_preact", 1},
+    };
   } else if (which == "small") {
     cases = {
       {"trunk fc1 fwd", 20832, 4096, 1024, 0, 1, "gelu_tanh_preact", 1},

@@ -63,7 +63,9 @@ def gpu_rollout_checks(head="mlp", use_graph=True, steps=7, sample="all"):
     m = m.to(BF).to("cuda")
     m._init_model_type()
     m.eval()
-    eng = RolloutEngine(m, B, use_graph=use_graph, warmup_decodes=2, sample=sample)
+    # text="current": this check changes an instruction WITHOUT a reset (t = 3) and expects the window to follow it; the default
+    # ("latched", the wrapper's literal semantics) is covered by tests/test_rollout.py::test_instruction_is_latched_until_reset
+    eng = RolloutEngine(m, B, use_graph=use_graph, warmup_decodes=2, sample=sample, text="current")
     newest = (sample == "newest" and head == "dit")      # the sampler runs on the executed position only (same noise rows)
     g = torch.Generator().manual_seed(5)
     text = torch.randint(1, 49000, (B, 77), generator=g)
