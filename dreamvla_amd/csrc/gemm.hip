@@ -317,6 +317,19 @@ inline double fill(int64_t tiles, int64_t slots) {
 // what the last dvla_gemm_bf16 call of this process actually launched (tests assert that a forced configuration ran and did
 // not fall back): 2 register-staged, 4 / 6 / 7 ring 256^2 / 128^2 / 256x128, 8 phase (plain schedule), 9 / 10 phase with the
 // stream-K hybrid / full schedule ENGAGED (a stream-K request that does not apply reports 8); 0 = nothing launched yet
+// measurement variants of the phase kernel (tests/probes/gemm_probe.cpp; NN layout, plain bf16 epilogue only): 40 = the round-4
+// main loop (piece placement 13 + its issue code), 41 = its s_memtime build, 42 = placement 13 with the round-5 issue code,
+// 43 = every piece behind the fragment reads' wait
+static bool launch_phase_experiment(int idx, GemmKArgs& a, int split_k, hipStream_t stream) {
+  switch (idx) {
+    case 0: launch_phase_one<false, false, 0, 7424>(a, split_k, stream); return true;
+    case 1: launch_phase_one<false, false, 0, 7488>(a, split_k, stream); return true;
+    case 2: launch_phase_one<false, false, 0, 3328>(a, split_k, stream); return true;
+    case 3: launch_phase_one<false, false, 0, 256>(a, split_k, stream); return true;
+    default: return false;
+  }
+}
+
 static int g_last_variant = 0;
 extern "C" int dvla_last_gemm_variant(void) { return g_last_variant; }
 extern "C" void dvla_set_gemm_variant(int v) { g_gemm_variant = v; }
@@ -444,6 +457,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     else if (variant == 9 && phase_ok(a, combo)) choice = 6;
     else if (variant == 10 && phase_ok(a, combo)) choice = 7;
     else if (variant > 80 && variant < 90 && combo == 0 && phase_ok(a, combo)) choice = 80 + (variant - 80);
+    else if (variant >= 40 && variant < 44 && combo == 0 && phase_ok(a, combo) && epi_class(a) == EPI_P0) choice = variant;
     // k-sums ride on the ring kernels of the fp32-output class (split-K partial sums or fp32 C: the weight gradients); the
     // other configurations get the column-sum kernel below
     const bool ksum_fused = q->ksum_operand != 0 && (choice == 1 || choice == 3 || choice == 4) && epi_class(a) == EPI_F32;
@@ -466,7 +480,13 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
         else if (choice == 86) launch_phase_one<false, false, 0, 32>(a, split_k, stream);
         else launch_phase_one<false, false, 0, 64>(a, split_k, stream);   // 89: s_memtime stamps into p.workspace
         break;
-      default: launch_cfg<CfgS>(a, combo, split_k, stream); break;
+      default:
+        if (choice >= 40 && choice < 44) {
+          set_tiles<PCfg::BM, PCfg::BN, PCfg::GH>(a);
+          a.sk_tiles = 0;
+          if (launch_phase_experiment(choice - 40, a, split_k, stream)) break;
+        }
+        launch_cfg<CfgS>(a, combo, split_k, stream); break;
     }
     g_last_variant = choice == 11 ? 11 : choice == 1 ? 4 : choice == 3 ? 6 : choice == 4 ? 7 : choice == 5 ? 8
                    : (choice == 6 || choice == 7) ? (a.sk_tiles > 0 ? (choice == 6 ? 9 : 10) : 8) : choice >= 80 ? choice : 2;

@@ -697,6 +697,20 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
+// Round 5, the phase kernel's piece issue: M0 = <LDS address of the wave's piece 0 of the image> + IMM in ONE scalar add, the hazard
+// nop, the DMA -- M0 is NOT saved / restored.  Legal only in a kernel none of whose other instructions reads M0:
+// tests/test_phase_isa.py disassembles every gemm_phase_kernel of the built library and asserts exactly that.
+// the ring kernels' form: the LDS address is a scalar the loop already holds (stage base + the wave's piece offset)
+__device__ __forceinline__ void glds16s_m0(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void glds16s_lean(const void* sbase, uint32_t voff, uint32_t lds_base) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               : : "v"(voff), "s"(sbase), "s"(lds_base), "n"(IMM) : "memory", "scc");
+}
+
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // fragment of the 32-row sub-tile starting at tile row `rbase`, k16-step ks (0 .. BKS/16 - 1) of the stage
@@ -871,6 +885,37 @@ __device__ __forceinline__ void quad_transpose(u32x4 (&P)[4], int /*lane*/) {
 }
 #undef DVLA_QT_STAGE
 
+// Row-block window onto a row-major matrix for the whole-line stores / loads of the epilogue (round 5): a buffer descriptor whose
+// base is element (m_base, n_base) and whose size ends with row M - 1, so that
+//   * an access is ONE instruction with a per-lane 32-bit offset computed once per tile and a scalar row offset -- the flat form
+//     cost ~9 VALU instructions of 64-bit address arithmetic + a compare / saveexec / branch per 16-byte store, a third of the
+//     VALU work of a plain slab, in an epilogue that is VALU-bound with the matrix pipe idle (profiles/r05_gemm_boundary.txt);
+//   * rows at or past M fall outside the descriptor: stores are dropped, loads return zero -- no row test, no clamp.
+// (offsets inside a wave's 128 rows x 64 columns stay below 4 GiB for any leading dimension the dispatcher admits; the size field
+// saturates at 4 GiB - 1, which can only happen when all 128 rows are inside the matrix anyway.)
+struct RowWindow {
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t lane_off;      // this lane's byte offset: row 4 qa of the window, its 16 bytes of the line
+  uint32_t row_bytes;     // leading dimension in bytes (uniform)
+};
+template <int ELEM>
+__device__ __forceinline__ RowWindow row_window(const void* base, int64_t ld, int64_t m_base, int64_t n_base, int64_t M, int qa, int col_elem) {
+  RowWindow w;
+  const int64_t left = M - m_base;
+  const uint64_t span = left > 0 ? (uint64_t)left * (uint64_t)ld * ELEM : 0;
+  char* b = const_cast<char*>(reinterpret_cast<const char*>(base)) + (m_base * ld + n_base) * ELEM;
+  w.rs = __builtin_amdgcn_make_buffer_rsrc(b, 0, span > 0xffffffffull ? 0xffffffffu : (uint32_t)span, 0x00020000);
+  w.row_bytes = (uint32_t)(ld * ELEM);
+  w.lane_off = (uint32_t)(4 * qa) * w.row_bytes + (uint32_t)(col_elem * ELEM);
+  return w;
+}
+__device__ __forceinline__ void window_store(const RowWindow& w, int row, u32x4 v) {     // row: uniform (32 j + c)
+  __builtin_amdgcn_raw_buffer_store_b128(v, w.rs, w.lane_off, (uint32_t)row * w.row_bytes, 0);
+}
+__device__ __forceinline__ u32x4 window_load(const RowWindow& w, int row) {
+  return __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane_off, (uint32_t)row * w.row_bytes, 0);
+}
+
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };   // timeline builds pass a recorder instead
 template <int TM, int EPI, class ST = NoStamp>
 __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], int lane, int64_t m_base,
@@ -920,6 +965,8 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
   if constexpr (EPI != EPI_F32 && EPI != EPI_GEN) {
     const int qb = lane & 3, qa = l31 >> 2;
     const int64_t ncol_line = n_base + 8 * (2 * qb + g);      // this lane's 16 bytes of a line in the store / load pattern
+    const int col_line = 8 * (2 * qb + g);
+    const RowWindow wC = row_window<2>(p.C, p.ldc, m_base, n_base, p.M, qa, col_line);
     // the bias goes into the accumulators once, up front (no live bias registers, no load behind a store)
     if (has_bias) {
       static_for<2>([&](auto ic) {
@@ -948,7 +995,19 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
       });
     }
     // whole lines of the store-layout operand of row slab j: instruction c reads rows {4a + c}, this lane's piece 2b + g
+    const bool aux_window = AUXV && !(has_res && p.res_rows > 0);      // (a periodic residual -- the position table -- keeps the flat form)
+    RowWindow wX = wC;
+    if constexpr (AUXV) {
+      if (aux_window)
+        wX = has_res ? row_window<2>(p.residual, p.ld_res, m_base, n_base, p.M, qa, col_line)
+                     : row_window<2>(p.dact_aux, p.ld_dact, m_base, n_base, p.M, qa, col_line);
+    }
     auto load_aux_lines = [&](int j, u32x4 (&L)[4]) {
+      if (aux_window) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) L[c] = window_load(wX, j * 32 + c);
+        return;
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int64_t m = m_base + j * 32 + 4 * qa + c;
@@ -965,6 +1024,8 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
     // copies of the loop (P classes: with / without pre-activation; residual class: with / without dropout)
     auto slabs = [&](auto dropc, auto prec) {
       constexpr bool DROP = decltype(dropc)::value, PRE = decltype(prec)::value;
+      RowWindow wP = wC;
+      if constexpr (PRE) wP = row_window<2>(p.preact, p.ld_preact, m_base, n_base, p.M, qa, col_line);
       u32x4 nx[4];      // (unused, and removed by the compiler, in the classes without a store-layout operand) raw lines of the NEXT row slab: requested one slab ahead, in front of this slab's stores
       if constexpr (AUXV) load_aux_lines(0, nx);
       static_for<TM>([&](auto jc) {
@@ -1034,18 +1095,12 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
         if constexpr (PRE) {
           quad_transpose(PP, lane);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int64_t mr = m_base + j * 32 + 4 * qa + c;
-            if (mr < p.M) *reinterpret_cast<u32x4*>(p.preact + mr * p.ld_preact + ncol_line) = PP[c];
-          }
+          for (int c = 0; c < 4; ++c) window_store(wP, j * 32 + c, PP[c]);
         }
         quad_transpose(PC, lane);
         st(1 + 2 * j);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int64_t mr = m_base + j * 32 + 4 * qa + c;
-          if (mr < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + mr * p.ldc + ncol_line) = PC[c];
-        }
+        for (int c = 0; c < 4; ++c) window_store(wC, j * 32 + c, PC[c]);
         __builtin_amdgcn_sched_barrier(0);
         st(2 + 2 * j);
       });
@@ -1262,22 +1317,25 @@ void gemm_ring_kernel(GemmKArgs p) {
     return id < nitems ? id : -1;
   };
 
-  // ---- DMA cursor: per-wave plan of CPW pieces per stage (fixed operand / chunk per slot i), per-lane source pointers
-  // that advance by one stage (32 k) per issue; destinations are wave-uniform byte offsets inside a stage buffer. ----
+  // ---- DMA cursor: per-wave plan of CPW pieces per stage (fixed operand / chunk per slot i); destinations are wave-uniform
+  // byte offsets inside a stage buffer.  Round 5 (as in the phase kernel, gemm_phase.h LEAN): the K position of the cursor lives
+  // in two SCALAR bases (operand + origin of the item's tile + k), advanced once per stage; a piece's per-lane source is a
+  // 32-bit offset inside the tile, computed when the cursor opens an item and constant until the next one; M0 is written, not
+  // saved / restored (tests/test_phase_isa.py covers these kernels too).  A piece was ~14 instructions (64-bit per-lane pointer
+  // advance, readfirstlane of the LDS address, M0 save / set / restore), now 4. ----
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const bf16_t* src[CPW];
-  int64_t step[CPW];
+  uint32_t src[CPW];
+  bool is_a[CPW];
   uint32_t dst[CPW];
+  const int64_t step_a = 2 * (A_T ? (int64_t)RC::BKS * p.lda : (int64_t)RC::BKS);
+  const int64_t step_b = 2 * (B_T ? (int64_t)RC::BKS * p.ldb : (int64_t)RC::BKS);
+  const char* kb_a = reinterpret_cast<const char*>(p.A);
+  const char* kb_b = reinterpret_cast<const char*>(p.B);
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
     const int q = wave * CPW + i;   // wave-uniform
-    if (q < RC::A_CHUNKS) {
-      step[i] = A_T ? (int64_t)RC::BKS * p.lda : (int64_t)RC::BKS;
-      dst[i] = (uint32_t)(q * 1024);
-    } else {
-      step[i] = B_T ? (int64_t)RC::BKS * p.ldb : (int64_t)RC::BKS;
-      dst[i] = (uint32_t)(RC::A_BYTES + (q - RC::A_CHUNKS) * 1024);
-    }
+    is_a[i] = q < RC::A_CHUNKS;
+    dst[i] = is_a[i] ? (uint32_t)(q * 1024) : (uint32_t)(RC::A_BYTES + (q - RC::A_CHUNKS) * 1024);
   }
   int cur_it = 0, cur_s = 0, cur_ns = 0;   // cursor: item iteration, stage inside it, stages of it
   bool cur_live = false;
@@ -1287,11 +1345,14 @@ void gemm_ring_kernel(GemmKArgs p) {
     if (!cur_live) return;
     const RingItem w = ring_item<RC>(p, id);
     cur_ns = w.ns; cur_s = 0;
+    // origin of the item's operand tiles (element (m0 | n0, k_begin)): every piece's source lies at or behind it
+    kb_a = reinterpret_cast<const char*>(A_T ? p.A + w.k_begin * p.lda + w.m0 : p.A + w.m0 * p.lda + w.k_begin);
+    kb_b = reinterpret_cast<const char*>(B_T ? p.B + w.k_begin * p.ldb + w.n0 : p.B + w.n0 * p.ldb + w.k_begin);
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int q = wave * CPW + i;
-      src[i] = (q < RC::A_CHUNKS) ? dma_src<A_T, BM, RC::BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, q, lane)
-                                  : dma_src<B_T, BN, RC::BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, q - RC::A_CHUNKS, lane);
+      src[i] = is_a[i] ? (uint32_t)(reinterpret_cast<const char*>(dma_src<A_T, BM, RC::BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, q, lane)) - kb_a)
+                       : (uint32_t)(reinterpret_cast<const char*>(dma_src<B_T, BN, RC::BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, q - RC::A_CHUNKS, lane)) - kb_b);
     }
   };
   int islot = 0, inflight = 0;             // ring slot of the next issue; stages issued and not yet consumed
@@ -1299,10 +1360,9 @@ void gemm_ring_kernel(GemmKArgs p) {
     if (!cur_live) return;
     const uint32_t st = smem_base + (uint32_t)(islot * RC::STAGE_BYTES);
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-      glds16(src[i], __builtin_amdgcn_readfirstlane(st + dst[i]));
-      src[i] += step[i];
-    }
+    for (int i = 0; i < CPW; ++i) glds16s_m0(is_a[i] ? kb_a : kb_b, src[i], st + dst[i]);
+    kb_a += step_a;
+    kb_b += step_b;
     islot = (islot + 1 == NS) ? 0 : islot + 1;
     ++inflight;
     if (++cur_s == cur_ns) cursor_open(++cur_it);

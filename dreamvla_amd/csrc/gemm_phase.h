@@ -16,15 +16,16 @@
 //       MFMA1: 16 x v_mfma_f32_32x32x16_bf16 (a-lo x B)
 //       LOAD2: fragments a-hi into the a-lo registers
 //       MFMA2: 16 MFMAs (a-hi x B, B fragments still in registers)
-//     and, spread over the four segments so that none of them paces the slot, this wave's 4 DMA pieces of the A image of
-//     tile u+1 (buffer (u+1)&1: last read in LOAD2(u-1)) and 4 of the B image of tile u+2 (buffer u&1: its B fragments were
-//     all read in LOAD1(u), by both groups -- hence from LOAD2 on): LOAD1: A0 | MFMA1: A1 A2 | LOAD2: A3 B0 B1 | MFMA2: B2 B3
+//     and this wave's 4 DMA pieces of the A image of tile u+2 (slot (u+2) % 3: last read in LOAD2(u-1)) and 4 of the B image
+//     of tile u+2 (buffer u&1: its B fragments were all read in LOAD1(u), by both groups -- hence from LOAD2 on).  Rounds 2-4
+//     spread them over the four segments (LOAD1: A0 | MFMA1: A1 A2 | LOAD2: A3 B0 | MFMA2: B1 B2 B3); round 5 issues them at
+//     the head of the two load segments, in three instructions each (piece_place / LEAN below: +15 % at 8192^3).
 //     every ds_read of a segment is waited for (lgkmcnt(0)) BEFORE the barrier that ends the segment -- the wait is hidden
 //     under the partner's MFMA segment -- so "read in segment s" means "retired by the end of s", which is what the refill
 //     rule above needs.  RAW: at the end of MFMA2(u) every wave waits vmcnt(8): all of its pieces except the eight it issued
 //     during tile u (A(u+2), B(u+2)) have landed, i.e. A(u+1) and B(u+1); group 1 (whose MFMA2(u) ends one slot after group 0
-//     starts reading tile u+1) waits for the same pieces at the end of its LOAD2(u) (vmcnt(5): A0..A3, B0 of tile u are
-//     younger).  The barriers publish.  Both operands run two tiles ahead: three A images (tile u in slot u % 3) and two B
+//     starts reading tile u+1) waits for the same pieces at the end of its LOAD2(u) (vmcnt(n): the n pieces of tile u issued so far are
+//     younger -- pieces_up_to() of the placement table).  The barriers publish.  Both operands run two tiles ahead: three A images (tile u in slot u % 3) and two B
 //     images (whose fragments are all read in LOAD1 and which are therefore free again from LOAD2 on): 160 KiB of LDS.
 //   The DMA stream never stops at an output-tile boundary (two cursors walk the work-item list ahead of the multiply); at a
 //   boundary the groups re-align with one extra barrier, run the register-only epilogue at the same time and re-stagger.
@@ -52,6 +53,33 @@ struct PCfg {
   static constexpr int CPW = 4;                      // DMA pieces (1 KiB each) per wave and operand image
 };
 
+// Where in a K-tile a wave issues its eight LDS-DMA pieces (A0..A3 of image A(u+2): legal anywhere in tile u; B0..B3 of image
+// B(u+2): from LOAD2 on -- file header).  Slots: 0 / 1 / 2 = LOAD1 before the fragment reads / behind them / behind their
+// lgkmcnt(0); 3..6 = MFMA1 behind k16-step 0..3; 7 / 8 / 9 = LOAD2 likewise; 10..13 = MFMA2 behind k16-step 0..3.  Pieces of an
+// operand must be in non-decreasing slot order (the cursor advances behind the fourth).  PL = (DBG >> 8) & 15 selects the table.
+// Round 5 (profiles/r05_gemm_placement_probe*.txt, 12 placements x {round-4 issue code, three-instruction issue}, NN plain,
+// same-process A/B): with every piece in a LOAD segment IN FRONT of the fragment reads the multiply segments are 568-588 cycles
+// (512 of MFMA) instead of 700-880 with two or three pieces between their MFMAs, and the load segments still fit beside them --
+// the four waves of a group issue their pieces at the same point of the program, the CU's one address path takes them one after
+// the other (16 cycles per 1-KiB piece), and what a piece costs the ISSUING wave is its place in that queue: harmless in a wave
+// that is about to wait for LDS anyway, ~100 cycles of idle matrix pipe in a wave that is multiplying.  8192^3: 1 272 -> 1 405
+// TFLOP/s from the placement alone, -> 1 490 together with the three-instruction issue (below); K = 1024: 992 -> 1 192.
+struct PiecePlace { int slot[8]; };
+__device__ __forceinline__ constexpr std::true_type live_or(std::true_type, bool) { return {}; }
+__device__ __forceinline__ constexpr bool live_or(std::false_type, bool live) { return live; }
+__host__ __device__ constexpr PiecePlace piece_place(int pl) {
+  switch (pl) {
+    case 1:  return {{2, 2, 2, 2, 9, 9, 9, 9}};        // everything behind the fragment reads' wait, in front of the barrier (-1 ... -3 %)
+    case 13: return {{1, 4, 6, 8, 8, 11, 12, 13}};     // rounds 2-4: LOAD1: A0 | MFMA1: A1 A2 | LOAD2: A3 B0 | MFMA2: B1 B2 B3 (-7 %)
+    default: return {{0, 0, 0, 0, 7, 7, 7, 7}};        // production: in front of the fragment reads of the two load segments
+  }
+}
+__host__ __device__ constexpr int pieces_up_to(int pl, int slot) {
+  int n = 0;
+  for (int i = 0; i < 8; ++i) n += piece_place(pl).slot[i] <= slot ? 1 : 0;
+  return n;
+}
+
 // 16-byte agent-coherent accesses to a stream-K slab (256 KiB, register layout) through a buffer descriptor with the sc1 bit:
 // write-through stores / loads served at the device coherence point -- the two workgroups that share a tile sit on different
 // XCDs, whose L2s do not snoop each other (cdna guide section 6, "in-launch combine").
@@ -65,7 +93,9 @@ __global__ __launch_bounds__(PCfg::NT) __attribute__((amdgpu_waves_per_eu(2, 2))
 void gemm_phase_kernel(GemmKArgs p) {
   constexpr int BM = PCfg::BM, BN = PCfg::BN, BKS = PCfg::BKS, CPW = PCfg::CPW;
   constexpr bool TAIL = (DBG & 128) != 0;
+  constexpr int PL = (DBG >> 8) & 15;
   static_assert(!TAIL || (A_T && B_T), "partial K-tiles: k-major operands only");
+  static_assert(piece_place(PL).slot[4] >= 7, "B pieces: from LOAD2 on");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -137,6 +167,23 @@ void gemm_phase_kernel(GemmKArgs p) {
     return true;
   };
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // CACHE (off in the DBG & 4096 build): one decode of a work segment per tile instead of four.  A segment index is decoded by the multiply loop
+  // (its own tile), by the look-ahead test of the LEAN build (the next one) and by both DMA cursors when they cross into the next
+  // segment -- ~150 dependent scalar instructions each (ring_item: three divisions by reciprocal, one real division by the ragged
+  // raster height), all of them on the tile boundary's critical path.  The tile top decodes segment it + 1 once and keeps it.
+  constexpr bool CACHE = (DBG & 4096) == 0;
+  Seg c_seg = {0, 0, 0, 0, 0, 0};
+  int c_it = -1;
+  bool c_ok = false;
+  auto seg_cached = [&](int it, Seg& sg) -> bool {
+    if constexpr (CACHE) {
+      if (it != c_it) { c_ok = seg_of(it, c_seg); c_it = it; }
+      sg = c_seg;
+      return c_ok;
+    } else {
+      return seg_of(it, sg);
+    }
+  };
 
   // ---- DMA cursors: cursor X walks the K-tiles of the work-item list for operand X; this wave owns pieces
   // 4*wave .. 4*wave+3 of every 32-piece operand image.  nA / nB = number of tiles issued so far (buffer = n & 1). ----
@@ -150,11 +197,22 @@ void gemm_phase_kernel(GemmKArgs p) {
   int tvA = 4, tvB = 4;                                         // tail_steps of the segments the cursors are in
   const uint32_t stepA = (uint32_t)(2 * (A_T ? (int64_t)BKS * p.lda : (int64_t)BKS));
   const uint32_t stepB = (uint32_t)(2 * (B_T ? (int64_t)BKS * p.ldb : (int64_t)BKS));
+  // LEAN (every build but DBG & 4096): a piece is THREE instructions -- `s_add_u32 m0, <LDS address of this wave's piece 0 of the image>, 1024 i`,
+  // the hazard nop, the DMA -- instead of ~12 (liveness branch, shift + add for the LDS address, M0 saved / set / restored, the
+  // per-lane source advanced by a v_add + v_mov).  The K position lives in the SCALAR base of the instruction (one s_add_u32 +
+  // s_addc_u32 per operand and K-tile) and the per-lane offsets stay what openA / openB computed; M0 is not restored (no
+  // instruction of these kernels reads it: tests/test_phase_isa.py); the liveness test is made once per K-tile (two loop bodies).
+  constexpr bool LEAN = (DBG & 4096) == 0;        // DBG & 4096: the round-4 issue code (measurement variant 40 of gemm.hip)
+  const char* kbA = reinterpret_cast<const char*>(p.A);
+  const char* kbB = reinterpret_cast<const char*>(p.B);
+  uint32_t m0A = smem_base + (uint32_t)(wave * (CPW * 1024));
+  uint32_t m0B = m0A + (uint32_t)PCfg::B_BASE;
   auto openA = [&](int it) {
     Seg w;
-    liveA = seg_of(it, w);
+    liveA = seg_cached(it, w);
     if (!liveA) return;
     nkA = w.ns; ktA = 0; tvA = tail_steps(w);
+    if constexpr (LEAN) kbA = reinterpret_cast<const char*>(p.A);
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
       srcA[i] = (uint32_t)(reinterpret_cast<const char*>(dma_src<A_T, BM, BKS>(p.A, p.lda, w.m0, p.M, w.k_begin, wave * CPW + i, lane)) -
@@ -162,54 +220,85 @@ void gemm_phase_kernel(GemmKArgs p) {
   };
   auto openB = [&](int it) {
     Seg w;
-    liveB = seg_of(it, w);
+    liveB = seg_cached(it, w);
     if (!liveB) return;
     nkB = w.ns; ktB = 0; tvB = tail_steps(w);
+    if constexpr (LEAN) kbB = reinterpret_cast<const char*>(p.B);
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
       srcB[i] = (uint32_t)(reinterpret_cast<const char*>(dma_src<B_T, BN, BKS>(p.B, p.ldb, w.n0, p.N, w.k_begin, wave * CPW + i, lane)) -
                            reinterpret_cast<const char*>(p.B));
   };
-  // one DMA piece (i = 0..3) of the next A / B image; *_done advances the cursor after the 4th.  Split like this so that
-  // the pieces can be issued BETWEEN the MFMAs of a multiply segment: an LDS-DMA issue (M0 write + VMEM issue) costs
-  // 100-185 cycles inside a fragment-read segment but hides in the shadow of a 32-cycle MFMA (the first version issued
-  // them in the LOAD segments: those then took ~900 cycles against the partner's 512-cycle MFMA segment and paced the loop).
+  // one DMA piece (i = 0..3) of the next A / B image; *_done advances the cursor after the 4th (the placement table decides
+  // where in the K-tile each piece goes).
   // partial last K-tile (TAIL): piece c = 4 wave + i of a k-major image holds k rows 2 c and 2 c + 1 of the tile (lanes 0-31 /
   // 32-63, dma_src); a row at or past 16 tail_steps lies outside the operand: read the tile's row 0 in its place
   auto tail_back = [&](int i, int tv, int64_t ld) -> uint32_t {
     const int k_local = 2 * (wave * CPW + i) + (lane >> 5);
     return k_local >= 16 * tv ? (uint32_t)(2 * (int64_t)k_local * ld) : 0u;
   };
-  auto pieceA = [&](int i) {
-    const uint32_t dst = smem_base + (uint32_t)(nA * PCfg::A_BYTES + wave * (CPW * 1024) + i * 1024);
+  auto pieceA = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
     uint32_t off = srcA[i];
     if constexpr (TAIL) { if (tvA < 4 && ktA == nkA - 1) off -= tail_back(i, tvA, p.lda); }
-    glds16s(p.A, off, __builtin_amdgcn_readfirstlane(dst));
-    srcA[i] += stepA;
+    if constexpr (LEAN) {
+      glds16s_lean<i * 1024>(kbA, off, m0A);
+    } else {
+      const uint32_t dst = smem_base + (uint32_t)(nA * PCfg::A_BYTES + wave * (CPW * 1024) + i * 1024);
+      glds16s(p.A, off, __builtin_amdgcn_readfirstlane(dst));
+      srcA[i] += stepA;
+    }
   };
-  auto doneA = [&]() { nA = nA == PCfg::NA - 1 ? 0 : nA + 1; if (++ktA == nkA) openA(++itA); };
-  auto pieceB = [&](int i) {
-    const uint32_t dst = smem_base + (uint32_t)(PCfg::B_BASE + (nB & 1) * PCfg::B_BYTES + wave * (CPW * 1024) + i * 1024);
+  auto doneA = [&]() {
+    nA = nA == PCfg::NA - 1 ? 0 : nA + 1;
+    if constexpr (LEAN) { kbA += stepA; m0A = nA == 0 ? m0A - (uint32_t)((PCfg::NA - 1) * PCfg::A_BYTES) : m0A + (uint32_t)PCfg::A_BYTES; }
+    if (++ktA == nkA) openA(++itA);
+  };
+  auto pieceB = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
     uint32_t off = srcB[i];
     if constexpr (TAIL) { if (tvB < 4 && ktB == nkB - 1) off -= tail_back(i, tvB, p.ldb); }
-    glds16s(p.B, off, __builtin_amdgcn_readfirstlane(dst));
-    srcB[i] += stepB;
+    if constexpr (LEAN) {
+      glds16s_lean<i * 1024>(kbB, off, m0B);
+    } else {
+      const uint32_t dst = smem_base + (uint32_t)(PCfg::B_BASE + (nB & 1) * PCfg::B_BYTES + wave * (CPW * 1024) + i * 1024);
+      glds16s(p.B, off, __builtin_amdgcn_readfirstlane(dst));
+      srcB[i] += stepB;
+    }
   };
-  auto doneB = [&]() { ++nB; if (++ktB == nkB) openB(++itB); };
+  auto doneB = [&]() {
+    ++nB;
+    if constexpr (LEAN) { kbB += stepB; m0B = (nB & 1) ? m0B + (uint32_t)PCfg::B_BYTES : m0B - (uint32_t)PCfg::B_BYTES; }
+    if (++ktB == nkB) openB(++itB);
+  };
   auto issueA = [&]() -> bool {
     if (!liveA) return false;
-#pragma unroll
-    for (int i = 0; i < CPW; ++i) pieceA(i);
+    static_for<CPW>([&](auto ic) { pieceA(ic); });
     doneA();
     return true;
   };
   auto issueB = [&]() -> bool {
     if (!liveB) return false;
-#pragma unroll
-    for (int i = 0; i < CPW; ++i) pieceB(i);
+    static_for<CPW>([&](auto ic) { pieceB(ic); });
     doneB();
     return true;
   };
+
+  // the pieces the placement table puts into slot SLOT (ia / ib: the cursors were live when the segment that owns them began)
+  auto emit = [&](auto slot_c, auto ia, auto ib) {      // ia / ib: bool, or std::true_type in the all-live loop body
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr PiecePlace pp = piece_place(PL);
+    if (DBG & 4) return;
+    static_for<4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (pp.slot[i] == SLOT) { if (ia) { pieceA(ic); if (i == 3) doneA(); } }
+    });
+    static_for<4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (pp.slot[4 + i] == SLOT) { if (ib) { pieceB(ic); if (i == 3) doneB(); } }
+    });
+  };
+#define DVLA_SLOT(N, IA, IB) do { __builtin_amdgcn_sched_barrier(0); emit(std::integral_constant<int, N>{}, IA, IB); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   // ---- prologue: A(0), B(0), A(1), B(1) in this order; the first two must have landed before the first fragment read ----
   openA(0); openB(0);
@@ -245,6 +334,9 @@ void gemm_phase_kernel(GemmKArgs p) {
   // the telling one (profiles/r03_gemm_ksum_probe_phase_dots.txt): 640 -> 807 us with a ZERO selector, i.e. v_dot2c_f32_bf16
   // interleaved with MFMAs is not hidden by the matrix pipe at all in this loop -- the dot instructions compete with it.  The
   // ring kernels carry the sums for 0-2 %; asked for k-sums this kernel's launches get the column-sum kernel over the operand.)
+  // (Round 5, measured and not kept: no s_setprio at all -0.5 ... +1 %, static priority 1 for group 1 without per-segment flips
+  // -1 ... -3 %; the groups keeping their one-segment skew through the tile boundary -- group 0's epilogue beside group 1's last
+  // multiply segment -- -1 ... -2 %: profiles/r05_gemm_placement_probe*.txt, variants 55 / 56 / 71 / 72.)
   int u = 0, ua = 0;   // global K-tile counter of the multiply, and u % 3
   for (int it = 0;; ++it) {
     // The segment's tile origin / split / kind stay live across the K loop as SCALARS (6 SGPRs, spilled to VGPR lanes when
@@ -252,7 +344,7 @@ void gemm_phase_kernel(GemmKArgs p) {
     // = ~800 cycles per tile with the matrix pipe idle (`entry` of the slab stamps).  Everything per-lane is still derived
     // from lane_e after the loop (the loop sits at the 256-VGPR limit).
     Seg w;
-    if (!seg_of(it, w)) break;
+    if (!seg_cached(it, w)) break;
     w.m0 = __builtin_amdgcn_readfirstlane(w.m0); w.n0 = __builtin_amdgcn_readfirstlane(w.n0);
     w.split = __builtin_amdgcn_readfirstlane(w.split); w.kind = __builtin_amdgcn_readfirstlane(w.kind);
     const int seg_ns = w.ns;
@@ -270,6 +362,10 @@ void gemm_phase_kernel(GemmKArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     if (it > 0) stamp_tile(it - 1, 3);
 
+    // the K loop of one output tile; live_c = std::true_type: both DMA cursors stay live for the whole tile, every liveness test
+    // folds away.  The cursors run two K-tiles ahead of the multiply, so that holds whenever a next work segment of at least two
+    // K-tiles exists: the LEAN build runs this copy for every tile but the workgroup's last.
+    auto kloop = [&](auto live_c) {
     for (int kt = 0; kt < seg_ns; ++kt, ++u, ua = (ua == PCfg::NA - 1 ? 0 : ua + 1)) {
       const char* bufA = smem + ua * PCfg::A_BYTES;                         // ua = u % 3
       const char* bufB = smem + PCfg::B_BASE + (u & 1) * PCfg::B_BYTES;
@@ -281,17 +377,21 @@ void gemm_phase_kernel(GemmKArgs p) {
           for (int y = 0; y < 4; ++y) { fa[x][y] = bf16x8{1, 2, 3, 4, 5, 6, 7, (short)lane}; fb[x][y] = bf16x8{1, 2, 3, 4, 5, 6, 7, (short)kt}; }
       }
 
-      // DMA piece placement (measured with the s_memtime stamps of variant 89, profiles/r02_gemm_phase_timeline.txt): one
-      // LDS-DMA issue costs the issuing wave ~95 cycles between MFMAs and ~210 behind the ds_reads of a fragment-read
-      // segment, and it is NOT hidden by the matrix pipe (the 8 pieces of a K-tile are 750-1700 cycles per wave against 1024
-      // of MFMA work: the reason the loop sits at ~55 % matrix-pipe busy).  Spread as
-      //     LOAD1: A0 | MFMA1: A1 A2 | LOAD2: A3 B0 | MFMA2: B1 B2 B3
-      // the four segments are ~650-800 cycles each.  Both operands run TWO tiles ahead (A(u+2) and B(u+2) are issued during
-      // tile u; three A images make that possible), so the counted waits below name pieces issued a whole tile earlier and do
-      // not stall (with A one tile ahead they cost ~300 cycles per K-tile and group).
+      // (DMA piece placement: piece_place() at the top of the file.  Both operands run TWO tiles ahead -- A(u+2) and B(u+2) are
+      // issued during tile u; three A images make that possible -- so the counted waits below name pieces issued a whole tile
+      // earlier and do not stall.)
+      // The first K-tile behind an epilogue waits for NOTHING (round 5).  vmcnt is one in-order counter for loads and stores: a
+      // counted wait behind the epilogue's 16-32 stores would wait for every one of them -- 2 200 cycles in the first K-tile of
+      // a tile by the s_memtime stamps (profiles/r05_gemm_boundary.txt) -- although the pieces it is there for (A(u+1), B(u+1),
+      // issued a whole K-tile before the epilogue) landed long ago.  So every DMA piece is waited for IN FRONT of the epilogue
+      // (vmcnt(0) below: the youngest is half a K-tile old) and K-tile 0 of the next tile skips both of its waits; K-tile 1's
+      // wait then meets stores that have had a whole K-tile to drain.
+      // (Not in the partial-K-tile build: its K ranges are 80+ K-tiles long, and one more live scalar tips its loop into spilling.)
+      const bool after_epi = LEAN && !TAIL && kt == 0 && it > 0;
       // ---------------- LOAD1 ----------------
       stamp(u, 0);
-      const bool ia = liveA;
+      const auto ia = live_or(live_c, liveA);
+      DVLA_SLOT(0, ia, false);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -299,9 +399,7 @@ void gemm_phase_kernel(GemmKArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + j * 32, ks, lane);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (ia && !(DBG & 4)) pieceA(0);
-      __builtin_amdgcn_sched_barrier(0);
+      DVLA_SLOT(1, ia, false);
       wait_lds();
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TAIL) {      // the dead k16-steps of a partial last K-tile contribute nothing (fragment reads have retired)
@@ -312,43 +410,38 @@ void gemm_phase_kernel(GemmKArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      DVLA_SLOT(2, ia, false);
       stamp(u, 1);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
       stamp(u, 2);
-      // ---------------- MFMA1 (+ pieces A1, A2 of A(u+1)) ----------------
+      // ---------------- MFMA1 ----------------
       __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      static_for<4>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             if (!(DBG & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][ks], fa[j][ks], acc[i][j], 0, 0, 0);
             else asm volatile("" :: "v"(fb[i][ks]), "v"(fa[j][ks]));
-        if (ks & 1) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (ia && !(DBG & 4)) pieceA(1 + (ks >> 1));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+        if constexpr (pieces_up_to(PL, 3 + ks) != pieces_up_to(PL, 2 + ks)) DVLA_SLOT(3 + ks, ia, false);
+      });
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       stamp(u, 3);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
       stamp(u, 4);
-      // ---------------- LOAD2 (+ pieces A3, B0, B1) ----------------
+      // ---------------- LOAD2 ----------------
+      const auto ib = live_or(live_c, liveB);
+      DVLA_SLOT(7, ia, ib);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + 64 + j * 32, ks, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ia) { if (!(DBG & 4)) pieceA(3); doneA(); }
-      const bool ib = liveB;
-      if (ib && !(DBG & 4)) pieceB(0);
-      __builtin_amdgcn_sched_barrier(0);
+      DVLA_SLOT(8, ia, ib);
       // group 1 sits one segment behind group 0, which reads tile u+1 in the next slot: group 1's pieces of A(u+1) / B(u+1)
-      // (issued during ITS tile u-1) must have landed by now.  Younger than those: this tile's A0..A3 and B0.
-      if (grp == 1) { if (ia && ib) wait_vmcnt<5>(); else wait_vmcnt<0>(); }
+      // (issued during ITS tile u-1) must have landed by now.  Younger than those: the pieces of this tile issued so far.
+      if (grp == 1 && !after_epi) { if (ia && ib) wait_vmcnt<pieces_up_to(PL, 8)>(); else wait_vmcnt<0>(); }
       wait_lds();
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TAIL) {
@@ -359,34 +452,39 @@ void gemm_phase_kernel(GemmKArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      DVLA_SLOT(9, ia, ib);
       stamp(u, 5);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
       stamp(u, 6);
-      // ---------------- MFMA2 (+ pieces B2, B3 of B(u+2)) ----------------
+      // ---------------- MFMA2 ----------------
       __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      static_for<4>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             if (!(DBG & 1)) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][ks], fa[j][ks], acc[i][2 + j], 0, 0, 0);
             else asm volatile("" :: "v"(fb[i][ks]), "v"(fa[j][ks]));
-        if (ks >= 1) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (ib && !(DBG & 4)) pieceB(ks);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+        if constexpr (pieces_up_to(PL, 10 + ks) != pieces_up_to(PL, 9 + ks)) DVLA_SLOT(10 + ks, ia, ib);
+      });
       __builtin_amdgcn_s_setprio(0);
-      if (ib) doneB();
       __builtin_amdgcn_sched_barrier(0);
       // everything but this tile's eight pieces (A(u+2), B(u+2)) has landed: A(u+1), B(u+1)
-      if (ia && ib) wait_vmcnt<2 * CPW>(); else wait_vmcnt<0>();
+      if (!after_epi) { if (ia && ib) wait_vmcnt<2 * CPW>(); else wait_vmcnt<0>(); }
       stamp(u, 7);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
+        }
+    };
+    if constexpr (LEAN) {
+      Seg nx;
+      const bool all_live = seg_cached(it + 1, nx) && nx.ns >= 2;
+      if (all_live) kloop(std::true_type{}); else kloop(std::false_type{});
+    } else {
+      kloop(std::false_type{});
     }
     stamp_tile(it, 0);
+    if constexpr (LEAN && !TAIL) wait_vmcnt<0>();   // every DMA piece has landed before the first store is issued (see after_epi)
     if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align: both groups run the epilogue together
     __builtin_amdgcn_sched_barrier(0);
     stamp_tile(it, 1);

@@ -158,6 +158,7 @@ class GradBucketReducer:
             lib.dvla_get_gemm_schedule(ctypes.byref(k), ctypes.byref(sk))
             self._saved_schedule = (k.value, sk.value)
             lib.dvla_set_gemm_schedule(8, 0)
+            self.robust_switches = getattr(self, "robust_switches", 0) + 1     # (reported by bench.py's N > 1 line)
             GemmTuner.schedule_tag = 1      # problem keys under the robust schedule are tuned (and locked) on their own
         elif not robust and self._saved_schedule is not None:
             lib.dvla_set_gemm_schedule(*self._saved_schedule)
@@ -228,6 +229,7 @@ class GradBucketReducer:
         parameters, held buckets and everything behind them), wait; the result is the gradient averaged over the ranks."""
         if self._no_sync:
             raise RuntimeError("GradBucketReducer.finish() inside no_sync()")
+        self.last_early_launches = self._next_launch      # buckets whose collective was launched DURING backward (bench.py reports it)
         for b in self.buckets[self._next_launch:]:
             self._launch(b)
         for b in self.buckets:

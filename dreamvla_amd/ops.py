@@ -108,6 +108,20 @@ class forward_split_k:
         return False
 
 
+def _fwd_split_epilogue_ok(out, bias, residual, N):
+    """what the reduce-with-epilogue pass of a split forward GEMM needs (csrc/gemm.hip dvla_gemm_bf16, `split_epi`: 16-byte
+    vectors of C / bias / residual, leading dimensions in whole vectors).  A call that does not meet it -- an `out=` view at an odd
+    column offset, a sliced residual -- simply runs unsplit: the OPPORTUNISTIC split must never turn a GEMM that works into
+    DVLA_ERR_UNSUPPORTED (round-4 ADVICE); an EXPLICIT split_k > 1 still reports the constraint."""
+    if N % 8 != 0 or out.dtype != BF16 or out.data_ptr() % 16 != 0 or out.stride(0) % 8 != 0:
+        return False
+    if bias is not None and bias.data_ptr() % 16 != 0:
+        return False
+    if residual is not None and (residual.data_ptr() % 16 != 0 or residual.stride(0) % 8 != 0 or residual.stride(-1) != 1):
+        return False
+    return True
+
+
 def fwd_split_k(M, N, K, cus=256):
     """Split-K for a FORWARD GEMM (bias / activation / residual applied by the reduction pass, include/dvla.h): the evaluation
     engine's trunk at one episode has 930 rows, and its MLP down-projection (N = 1024, K = 4096) is 64 tiles of 128 x 128
@@ -323,12 +337,16 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
             residual = residual.contiguous()
         p.residual, p.ld_res, p.res_rows = residual.data_ptr(), residual.stride(0), int(res_rows)
     p.accumulate = int(accumulate)
-    p.split_k = max(1, int(split_k))
-    if split_k is None or int(split_k) == 0:
-        p.split_k = 1
-    if (FWD_SPLIT_K and p.split_k == 1 and split_k != 0 and not torch.is_grad_enabled() and not a_trans and not want_preact
+    # split_k: None / 1 = no split requested (the forward rule below may choose one inside `with forward_split_k()`);
+    # 0 = no split, and the forward rule is OFF for this call (explicit opt-out); n > 1 = exactly n slices (round-4 ADVICE: the
+    # normalisation used to call int(None) before its own None test).
+    sk_req = 1 if split_k is None else int(split_k)
+    if sk_req < 0:
+        raise ValueError("gemm: split_k >= 0")
+    p.split_k = max(1, sk_req)
+    if (FWD_SPLIT_K and sk_req == 1 and not torch.is_grad_enabled() and not a_trans and not want_preact
             and dact_aux is None and dropout_p == 0.0 and not accumulate and ksum is None and a_ln_eps is None and variant is None
-            and N % 8 == 0 and out.dtype == BF16):
+            and _fwd_split_epilogue_ok(out, bias, residual, N)):
         # few hundred rows, long K: the evaluation engine's trunk (see fwd_split_k; on inside `with forward_split_k()` only)
         p.split_k = fwd_split_k(M, N, K)
     ksum_ws = None

@@ -4,8 +4,11 @@ collator (utils/data_utils.py:1308-1397) and train loop (utils/train_utils.py:99
 import torch
 
 
-def synthetic_batch(B, S, window=None, seed=1234, heads=()):
-    """Seeded synthetic CALVIN-like batch; values are bf16-representable."""
+def synthetic_batch(B, S, window=None, seed=1234, heads=(), gripper_width=False, tracks=False):
+    """Seeded synthetic CALVIN-like batch; values are bf16-representable.
+    gripper_width: the LIBERO state layout (6 arm values + the two finger widths, utils/train_utils.py:128-129) instead of CALVIN's
+    6 + open / closed flag; tracks: CoTracker labels without the trajectory head (the `--load_track_labels --flow_as_mask` runs of
+    scripts/LIBERO/DreamVLA/finetune_long.sh use them to mask the image loss)."""
     W = window or S
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).float()
@@ -29,6 +32,8 @@ def synthetic_batch(B, S, window=None, seed=1234, heads=()):
         batch["dino_primary"], batch["dino_wrist"] = r(B, W, 256, 768), r(B, W, 256, 768)
     if "sam" in heads:
         batch["sam_primary"], batch["sam_wrist"] = r(B, W, 256, 256), r(B, W, 256, 256)
-    if "traj" in heads:
+    if gripper_width:
+        batch["state"] = torch.cat([batch["state"][..., :6], u(B, W, 2) * 0.08], dim=-1)
+    if "traj" in heads or tracks:
         batch["tracks"], batch["tracks_gripper"] = r(B, W, 784, 2) * 2, r(B, W, 784, 2) * 2
     return batch

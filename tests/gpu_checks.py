@@ -620,10 +620,14 @@ def check_self_attention(B, H, L, mask_kind="none", dropout_p=0.0, grad=True, se
         # the REAL trunk mask of the benchmarked head set (obs + depth + sam dream heads: 54 query tokens + 3 action tokens per
         # window step, 36 conditioning tokens): L = 93 S; S = 7 is the training window (L = 651, key compaction 651 -> 378),
         # S = 10 the evaluation window (L = 930).  The generator is pinned bit for bit against the reference (tests/test_mask.py).
+        # "dreamvla_D" / "dreamvla_E" (round 5): the same generator for the other shipped head sets -- D = LIBERO finetune_long.sh
+        # (obs + sam: 36 + 39 tokens per step, L = 525 at S = 7), E = all dream heads of BASELINE configs[3] (obs + dino + sam +
+        # traj: 36 + 75, L = 777).  L = 1302 = 93 x 14 is the survey's maximum (head set C at the pretrain window).
         from dreamvla_amd.dreamvla_model import generate_attention_mask
-        S = L // 93
-        assert L == 93 * S
-        mask = generate_attention_mask(S, 36, 57, 0, False, False, False, 0.0, 54, 3)
+        num_b = {"dreamvla": 57, "dreamvla_D": 39, "dreamvla_E": 75}[mask_kind]
+        S = L // (36 + num_b)
+        assert L == (36 + num_b) * S
+        mask = generate_attention_mask(S, 36, num_b, 0, False, False, False, 0.0, num_b - 3, 3)
     mt = None
     if mask_kind == "pretrain":
         # the shipped PRETRAIN mask (pretrain.sh:37-52: S = 14, obs head + 3 action tokens -> 36 + 21 tokens per step, L = 798,
@@ -1011,6 +1015,14 @@ def all_checks(quick=False):
         # dropout), the decoders' B = 2 * 32 * 7 = 448 sequences of 9 + 196 / 9 + 256 tokens, the DiT head's 1792 x 6
         (check_self_attention, dict(B=2, H=16, L=798, mask_kind="pretrain")),
         (check_self_attention, dict(B=2, H=16, L=798, mask_kind="pretrain", dropout_p=0.1)),
+        # round-4 VERDICT missing #4: the real mask at the other shipped lengths -- LIBERO (L = 525), all dream heads (L = 777) and
+        # the survey's maximum L = 1302, where the dK/dV kernel's 80-KiB LDS cap decides between the ring kernel and the staged one
+        (check_self_attention, dict(B=2, H=16, L=525, mask_kind="dreamvla_D")),
+        (check_self_attention, dict(B=2, H=16, L=525, mask_kind="dreamvla_D", dropout_p=0.1)),
+        (check_self_attention, dict(B=2, H=16, L=777, mask_kind="dreamvla_E")),
+        (check_self_attention, dict(B=2, H=16, L=777, mask_kind="dreamvla_E", dropout_p=0.1)),
+        (check_self_attention, dict(B=1, H=16, L=1302, mask_kind="dreamvla")),
+        (check_self_attention, dict(B=1, H=16, L=1302, mask_kind="dreamvla", dropout_p=0.1)),
         (check_self_attention, dict(B=32, H=16, L=651, mask_kind="dreamvla", dropout_p=0.1, rows=8)),
         (check_self_attention, dict(B=32, H=16, L=651, mask_kind="dreamvla", rows=6, period=5)),
         (check_self_attention, dict(B=448, H=16, L=205, rows=10, period=9)),
@@ -1021,6 +1033,7 @@ def all_checks(quick=False):
         (check_self_attention_small, dict(B=3, H=2, L=33, D=128, seed=1)),
         (check_self_attention_small, dict(B=2, H=3, L=64, D=40, seed=2)),
         (check_cross_attention, dict(B=3, H=8, Lq=16, Lk=212)),
+        (check_cross_attention, dict(B=448, H=8, Lq=16, Lk=212, seed=2)),     # the resampler at the step's batch: 2 views x 32 x 7
         (check_cross_attention, dict(B=2, H=2, Lq=40, Lk=33)),
     ]
     L += [

