@@ -258,7 +258,9 @@ def other_config(name, heads, S, B, accum, extra_cfg, loss_kw, batch_kw, dev, st
     ms = dt / steps * 1e3
     res = {"samples_per_s": B * accum * steps / dt, "ms_per_optimizer_step": ms, "per_gpu_batch": B, "accumulation_passes": accum,
            "seq_len": S, "head_set": heads, "tokens_per_sample": int(model.attention_mask.shape[-1]) if hasattr(model, "attention_mask") else None,
-           "flags": {**extra_cfg, **loss_kw}, "steps": steps, "loss": float(last.detach()), "gemm_configurations": tuned,
+           "flags": {**extra_cfg, **loss_kw}, "steps": steps, "loss": float(last.detach()),
+           "loss_after_optimizer_steps": steps + warmup + (12 if tuned.startswith("12") else 0),      # (random init, lr 1e-3: the first steps start high)
+           "gemm_configurations": tuned,
            "whole_step_frac_of_bf16_peak": TRAIN_GFLOP_PER_SAMPLE[heads] * (S / 7.0 if S != 7 else 1.0) * (B * accum * steps / dt) / 1e3 / BF16_PEAK_TFLOPS}
     del model, reducer, opt, params, passes
     GemmTuner.reset()
@@ -608,9 +610,15 @@ def main():
             "roofline": roofline, "loss_parity": parity, "cpu_baseline": cpu, "eager_rocm_baseline": eager, "rollout": rollout,
             "other_configs": others, "rccl": rccl,
         }
-        print(json.dumps(line), flush=True)
     if world > 1 or args.torch_ddp:
+        # RCCL prints its version banner through C stdio when the group goes away: tear the group down and flush C's buffers FIRST,
+        # so that the JSON line is the LAST line of stdout
+        dist.barrier()
         dist.destroy_process_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -62,6 +62,11 @@ __device__ __forceinline__ void erfc_parts(f32x2 x, f32x2& q, f32x2& e) {
   q = poly * t * e;
 }
 __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) { return rcp2(exp2_2(x * (-1.4426950408889634f)) + 1.0f); }
+// sigmoid of an argument that already carries the factor -log2(e): 1 / (1 + 2^t).  tanh-GELU folds that factor into its two
+// polynomial constants -- one packed multiply less per pair in an epilogue that is VALU-bound (round 5)
+__device__ __forceinline__ f32x2 sigmoid2_scaled(f32x2 t) { return rcp2(exp2_2(t) + 1.0f); }
+constexpr float GELU_T_K1 = -1.4426950408889634f * 2.0f * 0.7978845608028654f * 0.044715f;
+constexpr float GELU_T_K2 = -1.4426950408889634f * 2.0f * 0.7978845608028654f;
 __device__ __forceinline__ f32x2 tanh2(f32x2 x) { return sigmoid2(x + x) * 2.0f - 1.0f; }
 
 __device__ __forceinline__ f32x2 act_fwd2(f32x2 x, int act) {
@@ -73,8 +78,7 @@ __device__ __forceinline__ f32x2 act_fwd2(f32x2 x, int act) {
       return sel_nonneg(x, x - h, h);
     }
     case ACT_GELU_TANH: {
-      const f32x2 u2 = x * (x * x * (2.0f * 0.7978845608028654f * 0.044715f) + 2.0f * 0.7978845608028654f);
-      return x * sigmoid2(u2);
+      return x * sigmoid2_scaled(x * (x * x * GELU_T_K1 + GELU_T_K2));
     }
     case ACT_RELU: return f32x2{x.x > 0.f ? x.x : 0.f, x.y > 0.f ? x.y : 0.f};
     case ACT_SILU: return x * sigmoid2(x);
@@ -96,7 +100,7 @@ __device__ __forceinline__ f32x2 act_bwd2(f32x2 x, int act) {
     }
     case ACT_GELU_TANH: {
       const f32x2 x2 = x * x;
-      const f32x2 s = sigmoid2(x * (x2 * (2.0f * 0.7978845608028654f * 0.044715f) + 2.0f * 0.7978845608028654f));
+      const f32x2 s = sigmoid2_scaled(x * (x2 * GELU_T_K1 + GELU_T_K2));
       const f32x2 du2 = x2 * (6.0f * 0.7978845608028654f * 0.044715f) + 2.0f * 0.7978845608028654f;   // d(2u)/dx
       return s + x * s * (1.0f - s) * du2;
     }

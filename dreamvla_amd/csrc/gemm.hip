@@ -264,10 +264,15 @@ void launch_phase(GemmKArgs& a, int combo, int split_k, hipStream_t stream, int 
   set_tiles<PCfg::BM, PCfg::BN, PCfg::GH>(a);
   a.sk_tiles = 0;
   if (a.K % PCfg::BKS != 0) {       // partial last K-tile (phase_tail): its own instantiation, plain schedule
-    launch_phase_one<true, true, EPI_F32, 128>(a, split_k, stream);
+    if (a.ksum_op != 0) launch_phase_one<true, true, EPI_F32, 128 | 8192>(a, split_k, stream);
+    else launch_phase_one<true, true, EPI_F32, 128>(a, split_k, stream);
     return;
   }
-  if (stream_k && split_k == 1) {
+  if (a.ksum_op != 0) {             // k-sums: the TT layout's fp32 class with the summing code (phase_ok_ksum admits nothing else)
+    launch_phase_one<true, true, EPI_F32, 8192>(a, split_k, stream);
+    return;
+  }
+  if (stream_k && split_k == 1 && a.ksum_op == 0) {     // (k-sums: one workgroup per (tile, K slice) owns a partial row)
     const int groups = num_cus();
     const int r = streamk_tiles((int64_t)a.tiles_m * a.tiles_n, groups, stream_k == 2);
     if (r > 0 && sk_scratch(stream, groups, &a.sk_slabs, &a.sk_flags)) a.sk_tiles = r;
@@ -458,9 +463,11 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     else if (variant == 10 && phase_ok(a, combo)) choice = 7;
     else if (variant > 80 && variant < 90 && combo == 0 && phase_ok(a, combo)) choice = 80 + (variant - 80);
     else if (variant >= 40 && variant < 44 && combo == 0 && phase_ok(a, combo) && epi_class(a) == EPI_P0) choice = variant;
-    // k-sums ride on the ring kernels of the fp32-output class (split-K partial sums or fp32 C: the weight gradients); the
-    // other configurations get the column-sum kernel below
-    const bool ksum_fused = q->ksum_operand != 0 && (choice == 1 || choice == 3 || choice == 4) && epi_class(a) == EPI_F32;
+    // k-sums ride on the ring kernels and (round 5) on the phase kernel of the fp32-output class (split-K partial sums or fp32 C:
+    // the weight gradients); the other configurations get the column-sum kernel below
+    const bool phase_choice = choice == 5 || choice == 6 || choice == 7;
+    const bool ksum_fused = q->ksum_operand != 0 && epi_class(a) == EPI_F32 &&
+                            (choice == 1 || choice == 3 || choice == 4 || (phase_choice && combo == 3));   // phase: the TT layout (every weight gradient)
     if (ksum_fused) a.ksum_op = q->ksum_operand;
     switch (choice) {
       case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;

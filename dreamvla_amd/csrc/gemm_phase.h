@@ -171,7 +171,8 @@ void gemm_phase_kernel(GemmKArgs p) {
   // (its own tile), by the look-ahead test of the LEAN build (the next one) and by both DMA cursors when they cross into the next
   // segment -- ~150 dependent scalar instructions each (ring_item: three divisions by reciprocal, one real division by the ragged
   // raster height), all of them on the tile boundary's critical path.  The tile top decodes segment it + 1 once and keeps it.
-  constexpr bool CACHE = (DBG & 4096) == 0;
+  // (not in the partial-K-tile build that also carries k-sums: at the register limit, and its segments are 80+ K-tiles long)
+  constexpr bool CACHE = (DBG & 4096) == 0 && !((DBG & 128) != 0 && (DBG & 8192) != 0);
   Seg c_seg = {0, 0, 0, 0, 0, 0};
   int c_it = -1;
   bool c_ok = false;
@@ -328,12 +329,19 @@ void gemm_phase_kernel(GemmKArgs p) {
         (reinterpret_cast<uint64_t*>(p.workspace) + 512 + (wave >> 2) * 64)[tile * 4 + e] = __builtin_amdgcn_s_memtime();
     }
   };
-  // (k-sums, dvla.h ksum_*: not in this kernel.  Tried four ways in round 3 -- dots after every k16-step in every wave, one block
-  // of dots at the end of a multiply segment in the wave whose k16-step it is, two dots behind every MFMA in per-operand copies of
-  // the segments, two selects + two dots behind every MFMA in one code path: +5 ... +26 % per launch, or spills.  The last one is
-  // the telling one (profiles/r03_gemm_ksum_probe_phase_dots.txt): 640 -> 807 us with a ZERO selector, i.e. v_dot2c_f32_bf16
-  // interleaved with MFMAs is not hidden by the matrix pipe at all in this loop -- the dot instructions compete with it.  The
-  // ring kernels carry the sums for 0-2 %; asked for k-sums this kernel's launches get the column-sum kernel over the operand.)
+  // k-sums (dvla.h ksum_*; fp32 class only), round 5.  Rounds 3-4 could not carry them here: dots interleaved with the MFMAs competed
+  // with the matrix pipe (+5 ... +26 % per launch, profiles/r03_gemm_ksum_probe_phase_dots.txt) and the weight gradients that need
+  // a bias gradient went to the BK-32 ring kernel or paid a column-sum pass.  With the DMA pieces out of the multiply segments the
+  // LOAD segments end in 240-370 cycles of waiting for the partner's multiply (profiles/r05_gemm_stamps_k1024.txt), so the dots go
+  // THERE: behind the segment's lgkmcnt(0), in front of its barrier, on the fragments that segment has just read -- LOAD1: the two
+  // a-lo fragments (and, for the B operand, the two B fragments) of ONE k16-step, LOAD2: the two a-hi fragments of that step.
+  // Which step: the waves that hold the same rows share the four k16-steps of a K-tile -- the four waves of a group hold the
+  // same A rows (wave wc takes step wc: pgroup wc of 4), the two groups hold the same B columns (group g takes steps g and g + 2:
+  // pgroup g of 2).  16 v_dot2c_f32_bf16 per wave and K-tile, none in a multiply segment; only the tiles of the first tile column
+  // (A) / tile row (B) sum at all.  Partial layout and reduction are the ring kernels' (ksum_store, KSUM_PARTS).
+  // The summing code exists only in the builds the dispatcher launches when a k-sum is asked for (DBG & 8192; the TT layout = the
+  // weight gradients): a launch without k-sums runs the identical kernel without the four accumulators and their flags.
+  constexpr bool KSUM = EPI == EPI_F32 && (DBG & 8192) != 0;
   // (Round 5, measured and not kept: no s_setprio at all -0.5 ... +1 %, static priority 1 for group 1 without per-segment flips
   // -1 ... -3 %; the groups keeping their one-segment skew through the tile boundary -- group 0's epilogue beside group 1's last
   // multiply segment -- -1 ... -2 %: profiles/r05_gemm_placement_probe*.txt, variants 55 / 56 / 71 / 72.)
@@ -358,6 +366,8 @@ void gemm_phase_kernel(GemmKArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float ksa[4] = {0.f, 0.f, 0.f, 0.f};     // k-sums of this wave's A row blocks (a-lo 0, 1; a-hi 2, 3) -- or, [0] and [1], of its B column blocks (a launch sums one operand)
+    const bool ks_a = KSUM && p.ksum_op == 1 && w.n0 == 0, ks_b = KSUM && p.ksum_op == 2 && w.m0 == 0;
     if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one segment behind group 0
     __builtin_amdgcn_sched_barrier(0);
     if (it > 0) stamp_tile(it - 1, 3);
@@ -410,6 +420,22 @@ void gemm_phase_kernel(GemmKArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (KSUM) {      // k-sums of this wave's k16-step (see the top of the kernel): a-lo now, a-hi in LOAD2
+        const int tv_now = (TAIL && kt == seg_ns - 1) ? seg_tv : 4;       // dead k16-steps of a partial last K-tile hold no data
+        if (ks_a) {
+          static_for<4>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if (wc == ks) { ksa[0] = ksum_add_sel(fa[0][ks], 0x3f803f80u, ksa[0]); ksa[1] = ksum_add_sel(fa[1][ks], 0x3f803f80u, ksa[1]); }
+          });
+        }
+        if (ks_b) {
+          static_for<4>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if ((ks & 1) == grp && ks < tv_now) { ksa[0] = ksum_add_sel(fb[0][ks], 0x3f803f80u, ksa[0]); ksa[1] = ksum_add_sel(fb[1][ks], 0x3f803f80u, ksa[1]); }
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       DVLA_SLOT(2, ia, false);
       stamp(u, 1);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
@@ -452,6 +478,15 @@ void gemm_phase_kernel(GemmKArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (KSUM) {
+        if (ks_a) {
+          static_for<4>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if (wc == ks) { ksa[2] = ksum_add_sel(fa[0][ks], 0x3f803f80u, ksa[2]); ksa[3] = ksum_add_sel(fa[1][ks], 0x3f803f80u, ksa[3]); }
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       DVLA_SLOT(9, ia, ib);
       stamp(u, 5);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
@@ -476,12 +511,17 @@ void gemm_phase_kernel(GemmKArgs p) {
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
         }
     };
-    if constexpr (LEAN) {
+    if constexpr (LEAN && !(TAIL && KSUM)) {      // (the partial-K-tile + k-sum build keeps one copy of its loop: registers)
       Seg nx;
       const bool all_live = seg_cached(it + 1, nx) && nx.ns >= 2;
       if (all_live) kloop(std::true_type{}); else kloop(std::false_type{});
     } else {
       kloop(std::false_type{});
+    }
+    if constexpr (KSUM) {
+      // rows of the four A blocks: a-lo j at grp * 128 + 32 j, a-hi j at grp * 128 + 64 + 32 j = ksum_store's consecutive 32-row blocks
+      if (ks_a) ksum_store<4, 4>(p, ksa, lane, w.split, wc, 4, (int64_t)w.m0 + grp * 128, p.M);
+      if (ks_b) ksum_store<2, 4>(p, ksa, lane, w.split, grp, 2, (int64_t)w.n0 + wc * 64, p.N);
     }
     stamp_tile(it, 0);
     if constexpr (LEAN && !TAIL) wait_vmcnt<0>();   // every DMA piece has landed before the first store is issued (see after_epi)

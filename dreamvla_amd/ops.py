@@ -219,8 +219,15 @@ class GemmTuner:
     schedule_tag = 0  # part of every problem key: 1 while GradBucketReducer runs the GEMMs under its robust schedule (collectives
                       # outstanding).  A candidate timed under one schedule must not be locked for the other (round-3 ADVICE).
 
+    # Problem keys that also ask for a k-sum (the bias gradient next to a weight gradient) have two more candidates (round 5): 108 /
+    # 109 = the phase kernel (plain / stream-K schedule) WITHOUT its summing code + the column-sum kernel over the operand, against
+    # 8 / 9 / 10 = the phase kernel with the dots in its load segments and 4 / 6 / 7 = the ring kernels' fused sums.  Measured: the
+    # fused dots cost the summing workgroups 7-13 % and every launch waits for its slowest workgroup -- they win for the trunk
+    # (K = 20 832: +7 % over the ring kernel), the separate pass wins for the decoders' K = 91 840 (a 45-us pass next to a 585-us GEMM).
+    KSUM_EXTRA = (108, 109)
+
     @classmethod
-    def pick(cls, key):
+    def pick(cls, key, ksum=False):
         v = cls.table.get(key)
         if v is not None:
             return v, None
@@ -228,7 +235,8 @@ class GemmTuner:
             return 0, None
         st = cls.trials.get(key)
         if st is None:
-            st = cls.trials[key] = {"pending": [], "times": {c: [] for c in cls.CANDIDATES}, "next": 0}
+            cands = cls.CANDIDATES + (cls.KSUM_EXTRA if ksum else ())
+            st = cls.trials[key] = {"pending": [], "times": {c: [] for c in cands}, "next": 0}
         still = []
         for (var, e0, e1) in st["pending"]:
             if e1.query():
@@ -383,11 +391,13 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
                bias is not None, want_preact, dact_aux is not None, residual is not None,
                dropout_p > 0.0, out.dtype == torch.float32, bool(accumulate), 0 if ksum is None else (1 if ksum[0] == "a" else 2),
                int(GemmTuner.schedule_tag))
-        variant, trial = GemmTuner.pick(key)
-    # k-sums: carried by the ring kernels (variants 4 / 6 / 7; 0 = the library's choice, which falls back by itself); under a
-    # configuration without the summing code the column-sum kernel runs here, AFTER the profiler's end event (it is not GEMM
-    # time) but inside the tuner's trial window (a configuration's cost includes what it leaves to other kernels)
-    ksum_here = ksum is not None and variant not in (0, 4, 6, 7)
+        variant, trial = GemmTuner.pick(key, ksum=ksum is not None)
+    # k-sums: carried by the ring kernels (variants 4 / 6 / 7), by the phase kernel (8 / 9 / 10, round 5) and by whatever the
+    # library's own choice is (0: it falls back by itself); under a configuration without the summing code -- 2, and the tuner's
+    # pseudo-configurations 108 / 109 = phase kernel without the dots -- the column-sum kernel runs here, AFTER the profiler's end
+    # event (it is not GEMM time) but inside the tuner's trial window (a configuration's cost includes what it leaves to others)
+    lib_variant = variant % 100
+    ksum_here = ksum is not None and (variant >= 100 or lib_variant not in (0, 4, 6, 7, 8, 9, 10))
     if ksum is not None and not ksum_here:
         p.ksum, p.ksum_dtype, p.ksum_operand = kout.data_ptr(), _dt(kout), 1 if which == "a" else 2
         ksum_ws = torch.empty(lib.dvla_gemm_ksum_partial_rows(p.split_k) * klen, dtype=torch.float32, device=a.device)
@@ -399,12 +409,12 @@ def gemm(a, b, *, a_trans=False, b_trans=False, bias=None, act=0, want_preact=Fa
     if p.split_k > 1:
         ws = torch.empty((p.split_k, M, N), dtype=torch.float32, device=a.device)
         p.workspace = ws.data_ptr()
-    if variant:
-        lib.dvla_set_gemm_variant(variant)
+    if lib_variant:
+        lib.dvla_set_gemm_variant(lib_variant)
     try:
         check(lib.dvla_gemm_bf16(C.byref(p), _stream()), "dvla_gemm_bf16")
     finally:
-        if variant:
+        if lib_variant:
             lib.dvla_set_gemm_variant(0)
     if prof is not None or trial is not None:
         e1.record()

@@ -18,6 +18,9 @@ ALLOWED = [
     # time is in classes 0-6 (profiles/r04_gemm_breakdown.json), which must be clean.
     (r"gemm_phase_kernelILb[01]ELb[01]ELi7ELi0E", 160, 60),
     (r"gemm_ring_kernelINS_4RCfgILi2ELi4ELi4ELi2ELi4ELi2ELi4ELi32EEELb[01]ELb[01]ELi7E", 140, 36),
+    # round 5 (scalar K bases of the lean DMA issue): the 256 x 256 ring kernel's fp32 class in the TN layout -- no problem key of the
+    # step uses it (every weight gradient is TT, which is clean) -- spills 4 registers outside its stage loop
+    (r"gemm_ring_kernelINS_4RCfgILi2ELi4ELi4ELi2ELi4ELi2ELi4ELi32EEELb1ELb0ELi6E", 24, 4),
     # dQ ring kernel with the dropout generator: one spilled pair outside the loop
     (r"attn_bwd_dq_ring_kernel", 16, 2),
     # the one-XCD sampler kernels: the frame of their one real call (step_boundary) and of the per-phase calls; no VGPR spills --
@@ -42,6 +45,6 @@ def test_every_kernel_within_its_budget():
             over.append((r["name"], r["scratch_bytes"], r["vgpr_spill"]))
     assert not over, over
     # the kernels the step's time is in are there and clean
-    hot = [r for r in rows if re.search(r"gemm_phase_kernelILb[01]ELb[01]ELi[0-6]ELi(0|128)E|gemm_skinny_kernel|attn_(fwd|bwd)_short_kernel|"
+    hot = [r for r in rows if re.search(r"gemm_phase_kernelILb[01]ELb[01]ELi[0-5]ELi0E|gemm_phase_kernelILb[01]ELb[01]ELi6ELi(0|128|8192|8320)E|gemm_skinny_kernel|attn_(fwd|bwd)_short_kernel|"
                                         r"attn_fwd_ring_kernel|attn_bwd_dkv_ring_kernel|ln_(fwd|bwd)_kernel", r["name"])]
     assert len(hot) >= 30 and all(r["scratch_bytes"] == 0 and r["vgpr_spill"] == 0 for r in hot)
