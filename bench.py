@@ -329,10 +329,10 @@ def main():
                     help="replay the GEMM configuration choices saved by --save-plan (no tuner trials: for profiler / counter passes "
                          "of the tuned step); default: $DVLA_GEMM_PLAN")
     ap.add_argument("--save-plan", default=None, metavar="FILE", help="write the tuner's locked choices after the tune steps")
-    ap.add_argument("--tune-steps", type=int, default=25,
+    ap.add_argument("--tune-steps", type=int, default=32,
                     help="untimed steps BEFORE the warm-up in which dreamvla_amd.ops.GemmTuner tries each GEMM kernel "
                          "configuration once per problem shape and locks the fastest (setup, like building the extension); "
-                         "eight candidates x GemmTuner.ROUNDS (3) trials (median): shapes that occur once per step need 24 steps to lock")
+                         "eight candidates (ten for the problems that also produce a k-sum) x GemmTuner.ROUNDS (3) trials (median): shapes that occur once per step need 30 steps to lock")
     ap.add_argument("--torch-profile", default=None, metavar="FILE",
                     help="diagnostics: after the timed region, one more step under torch.profiler; ATen / autograd operators by "
                          "device time (with input shapes) are written to FILE")
