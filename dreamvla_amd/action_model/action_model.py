@@ -109,6 +109,10 @@ class ActionModel(nn.Module):
             if st["ptrs"] != ptrs:          # (re)built outside a capture: the engine's eager warm-up calls come first
                 st["table"] = torch.tensor(ptrs, dtype=torch.int64, device=cond.device).view(len(net.blocks), 8)
                 st["ptrs"], st["keep"] = ptrs, ws
+            capturing = torch.cuda.is_current_stream_capturing()
+            # eager calls compare the workspace's timeout count before and after THEIR launch (a replayed graph may have timed out
+            # on this workspace since the last eager call: that is the engine's business -- RolloutEngine.step -- not this call's)
+            timeouts_before = None if capturing else ops.dit_team_status(st["ws"])[0]
             cond_tab = (z_emb.unsqueeze(0) + t_emb.view(t_emb.shape[0], 1, 1, -1)).contiguous()    # z_emb + t_emb[j], all steps
             sh = lambda w: ops.shadow(w).contiguous()
             out = ops.dit_team_sample(st["table"], len(net.blocks), hidden, net.num_heads, sh(net.x_embedder.linear.weight),
@@ -117,14 +121,14 @@ class ActionModel(nn.Module):
                                       net.blocks[0].norm1.eps, st["ws"])
             self.team_launches = getattr(self, "team_launches", 0) + 1       # (a captured launch counts once: RolloutEngine reads
             #                                                                    "did the decode graph contain the team kernel" off it)
-            if not torch.cuda.is_current_stream_capturing():
+            if not capturing:
                 # eager calls check at once.  Under hipGraph replay no Python runs: RolloutEngine.step checks the ACTION it is about
                 # to hand out and falls back to the launch-by-launch sampler (round-4 ADVICE); the kernel retires its own status,
                 # so the launch after a timeout is clean.
                 timeouts, xcc = ops.dit_team_status(st["ws"])
                 self.team_xcc_mask = xcc
-                if timeouts != st["timeouts"]:
-                    st["timeouts"] = timeouts
+                st["timeouts"] = timeouts
+                if timeouts != timeouts_before:
                     raise ops.DitTeamTimeout(f"dvla_dit_sample: an exchange inside the kernel timed out (the output of this call is NaN; "
                                        f"{timeouts} launches so far, XCC mask {xcc:#x}); set `team_sampler = False` on the action "
                                        f"model for the launch-by-launch sampler")

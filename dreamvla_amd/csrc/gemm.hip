@@ -349,7 +349,8 @@ extern "C" void dvla_get_gemm_schedule(int* oversubscribe, int* stream_k) {
 }
 
 extern "C" int64_t dvla_gemm_ksum_partial_rows(int32_t split_k) {
-  const int64_t fused = (int64_t)(split_k > 1 ? split_k : 1) * dvla_gemm::KSUM_PARTS, fallback = dvla_colsum_partial_rows();
+  // (x 4: the phase kernel spreads a row's sum over up to four tiles, each with its own KSUM_PARTS partial rows)
+  const int64_t fused = (int64_t)(split_k > 1 ? split_k : 1) * dvla_gemm::KSUM_PARTS * 4, fallback = dvla_colsum_partial_rows();
   return fused > fallback ? fused : fallback;
 }
 
@@ -381,6 +382,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   GemmKArgs a;
   a.sk_tiles = 0; a.sk_slabs = nullptr; a.sk_flags = nullptr;
   a.ksum_ws = q->ksum_workspace; a.ksum_op = 0;   // set below, once the configuration is known to carry the summing code
+  a.ksum_parts = KSUM_PARTS;
   a.a_ln = q->a_layernorm != 0; a.a_ln_eps = q->a_ln_eps;
   a.A = reinterpret_cast<const bf16_t*>(q->A); a.lda = q->lda;
   a.B = reinterpret_cast<const bf16_t*>(q->B); a.ldb = q->ldb;
@@ -468,7 +470,13 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     const bool phase_choice = choice == 5 || choice == 6 || choice == 7;
     const bool ksum_fused = q->ksum_operand != 0 && epi_class(a) == EPI_F32 &&
                             (choice == 1 || choice == 3 || choice == 4 || (phase_choice && combo == 3));   // phase: the TT layout (every weight gradient)
-    if (ksum_fused) a.ksum_op = q->ksum_operand;
+    if (ksum_fused) {
+      a.ksum_op = q->ksum_operand;
+      if (phase_choice) {          // tiles of a tile row (A sums) / tile column (B sums) that share the sum: up to four
+        const int64_t other = q->ksum_operand == 1 ? (q->N + PCfg::BN - 1) / PCfg::BN : (q->M + PCfg::BM - 1) / PCfg::BM;
+        a.ksum_parts = KSUM_PARTS * (int)(other < 4 ? other : 4);
+      }
+    }
     switch (choice) {
       case 1: launch_ring<RCfgL>(a, combo, split_k, stream); break;
       case 3: launch_ring<RCfgS>(a, combo, split_k, stream); break;
@@ -504,8 +512,8 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
   if (q->ksum_operand != 0) {
     const int64_t len = q->ksum_operand == 1 ? q->M : q->N;
     if (a.ksum_op != 0) {
-      if (split_k > 1) kj = KsumJob{a.ksum_ws, q->ksum, len, split_k * KSUM_PARTS, q->ksum_dtype == DVLA_DT_BF16, 0u};   // rides on the split-K reduction below
-      else rc = dvla_reduce_partial_rows(a.ksum_ws, split_k * KSUM_PARTS, len, len, q->ksum, q->ksum_dtype == DVLA_DT_BF16, stream);
+      if (split_k > 1) kj = KsumJob{a.ksum_ws, q->ksum, len, split_k * a.ksum_parts, q->ksum_dtype == DVLA_DT_BF16, 0u};   // rides on the split-K reduction below
+      else rc = dvla_reduce_partial_rows(a.ksum_ws, split_k * a.ksum_parts, len, len, q->ksum, q->ksum_dtype == DVLA_DT_BF16, stream);
     } else {
       // this configuration does not sum: the column-sum kernel over the operand as it lies in memory (k-major layouts only)
       const bool kmajor = q->ksum_operand == 1 ? q->a_trans != 0 : q->b_trans != 0;

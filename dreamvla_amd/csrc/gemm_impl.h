@@ -89,6 +89,7 @@ struct GemmKArgs {
   int sk_tiles; float* sk_slabs; unsigned* sk_flags;
   // k-sums of an operand (dvla.h ksum_*): fp32 partials [split][KSUM_PARTS][len], len = M (op 1) or N (op 2); EPI_F32 kernels only
   float* ksum_ws; int ksum_op;
+  int ksum_parts;     // partial rows per K slice: KSUM_PARTS (ring kernels), KSUM_PARTS x (tiles that share a row's sum) (phase kernel)
   // rows of A layer-normalised on the fly (dvla.h a_layernorm): few-rows kernel only
   int a_ln; float a_ln_eps;
 };
@@ -109,18 +110,20 @@ __device__ __forceinline__ float ksum_add_sel(bf16x8 f, uint32_t sel, float acc)
 }
 // a wave's k-sums of 32-row blocks -> the partial buffer.  pgroup < nshare: which of the nshare waves that hold the same operand
 // rows this is; the pgroups nobody owns (nshare .. 3) are zero-filled by pgroup 0.
+// part0 (phase kernel): first of this tile's KSUM_PARTS partial rows inside the K slice's p.ksum_parts.
 template <int NB, int NS>
 __device__ __forceinline__ void ksum_store(const GemmKArgs& p, const float (&sum)[NS], int lane, int split, int pgroup, int nshare,
-                                           int64_t idx0, int64_t len) {
+                                           int64_t idx0, int64_t len, int part0 = 0) {
   static_assert(NB <= NS, "block count");
   const int l31 = lane & 31, g = lane >> 5;
+  const int64_t row0 = (int64_t)split * p.ksum_parts + part0;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int64_t idx = idx0 + b * 32 + l31;
     if (idx < len) {
-      p.ksum_ws[((int64_t)split * KSUM_PARTS + pgroup * 2 + g) * len + idx] = sum[b];
+      p.ksum_ws[(row0 + pgroup * 2 + g) * len + idx] = sum[b];
       if (pgroup == 0)
-        for (int z = nshare; z < KSUM_PARTS / 2; ++z) p.ksum_ws[((int64_t)split * KSUM_PARTS + z * 2 + g) * len + idx] = 0.f;
+        for (int z = nshare; z < KSUM_PARTS / 2; ++z) p.ksum_ws[(row0 + z * 2 + g) * len + idx] = 0.f;
     }
   }
 }

@@ -337,8 +337,10 @@ void gemm_phase_kernel(GemmKArgs p) {
   // a-lo fragments (and, for the B operand, the two B fragments) of ONE k16-step, LOAD2: the two a-hi fragments of that step.
   // Which step: the waves that hold the same rows share the four k16-steps of a K-tile -- the four waves of a group hold the
   // same A rows (wave wc takes step wc: pgroup wc of 4), the two groups hold the same B columns (group g takes steps g and g + 2:
-  // pgroup g of 2).  16 v_dot2c_f32_bf16 per wave and K-tile, none in a multiply segment; only the tiles of the first tile column
-  // (A) / tile row (B) sum at all.  Partial layout and reduction are the ring kernels' (ksum_store, KSUM_PARTS).
+  // pgroup g of 2).  16 v_dot2c_f32_bf16 per wave and K-tile, none in a multiply segment.  A launch waits for its slowest workgroup,
+  // so the sum of a tile row (column) is SPREAD over up to four of its tiles: tile column c < S = min(4, tiles_n) sums the K-tiles
+  // with kt % S == c into its own KSUM_PARTS partial rows (p.ksum_parts = 8 S rows per K slice; the reduction adds them up) -- with
+  // only the first tile column summing, the dots cost a launch 7-13 % (profiles/r05_gemm_ksum_probe.txt).
   // The summing code exists only in the builds the dispatcher launches when a k-sum is asked for (DBG & 8192; the TT layout = the
   // weight gradients): a launch without k-sums runs the identical kernel without the four accumulators and their flags.
   constexpr bool KSUM = EPI == EPI_F32 && (DBG & 8192) != 0;
@@ -367,7 +369,10 @@ void gemm_phase_kernel(GemmKArgs p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ksa[4] = {0.f, 0.f, 0.f, 0.f};     // k-sums of this wave's A row blocks (a-lo 0, 1; a-hi 2, 3) -- or, [0] and [1], of its B column blocks (a launch sums one operand)
-    const bool ks_a = KSUM && p.ksum_op == 1 && w.n0 == 0, ks_b = KSUM && p.ksum_op == 2 && w.m0 == 0;
+    // S = p.ksum_parts / KSUM_PARTS tiles of a row (column) share its sum; this tile's column (row) index c takes the K-tiles with
+    // kt % S == c: ks_cnt counts down to its next K-tile (-1: this tile does not sum).  Two live scalars.
+    const int ks_c = !KSUM ? 0 : p.ksum_op == 1 ? w.n0 / BN : w.m0 / BM;
+    int ks_cnt = (KSUM && ks_c * KSUM_PARTS < p.ksum_parts) ? ks_c : -1;
     if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one segment behind group 0
     __builtin_amdgcn_sched_barrier(0);
     if (it > 0) stamp_tile(it - 1, 3);
@@ -422,13 +427,13 @@ void gemm_phase_kernel(GemmKArgs p) {
       }
       if constexpr (KSUM) {      // k-sums of this wave's k16-step (see the top of the kernel): a-lo now, a-hi in LOAD2
         const int tv_now = (TAIL && kt == seg_ns - 1) ? seg_tv : 4;       // dead k16-steps of a partial last K-tile hold no data
-        if (ks_a) {
+        if (ks_cnt == 0 && p.ksum_op == 1) {
           static_for<4>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             if (wc == ks) { ksa[0] = ksum_add_sel(fa[0][ks], 0x3f803f80u, ksa[0]); ksa[1] = ksum_add_sel(fa[1][ks], 0x3f803f80u, ksa[1]); }
           });
         }
-        if (ks_b) {
+        if (ks_cnt == 0 && p.ksum_op == 2) {
           static_for<4>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             if ((ks & 1) == grp && ks < tv_now) { ksa[0] = ksum_add_sel(fb[0][ks], 0x3f803f80u, ksa[0]); ksa[1] = ksum_add_sel(fb[1][ks], 0x3f803f80u, ksa[1]); }
@@ -479,12 +484,13 @@ void gemm_phase_kernel(GemmKArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (KSUM) {
-        if (ks_a) {
+        if (ks_cnt == 0 && p.ksum_op == 1) {
           static_for<4>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             if (wc == ks) { ksa[2] = ksum_add_sel(fa[0][ks], 0x3f803f80u, ksa[2]); ksa[3] = ksum_add_sel(fa[1][ks], 0x3f803f80u, ksa[3]); }
           });
         }
+        ks_cnt = ks_cnt > 0 ? ks_cnt - 1 : (ks_cnt == 0 ? p.ksum_parts / KSUM_PARTS - 1 : ks_cnt);
         __builtin_amdgcn_sched_barrier(0);
       }
       DVLA_SLOT(9, ia, ib);
@@ -520,8 +526,9 @@ void gemm_phase_kernel(GemmKArgs p) {
     }
     if constexpr (KSUM) {
       // rows of the four A blocks: a-lo j at grp * 128 + 32 j, a-hi j at grp * 128 + 64 + 32 j = ksum_store's consecutive 32-row blocks
-      if (ks_a) ksum_store<4, 4>(p, ksa, lane, w.split, wc, 4, (int64_t)w.m0 + grp * 128, p.M);
-      if (ks_b) ksum_store<2, 4>(p, ksa, lane, w.split, grp, 2, (int64_t)w.n0 + wc * 64, p.N);
+      const int tc = p.ksum_op == 1 ? w.n0 / BN : w.m0 / BM;       // (re-derived: not kept live across the K loop)
+      if (ks_cnt >= 0 && p.ksum_op == 1) ksum_store<4, 4>(p, ksa, lane, w.split, wc, 4, (int64_t)w.m0 + grp * 128, p.M, tc * KSUM_PARTS);
+      if (ks_cnt >= 0 && p.ksum_op == 2) ksum_store<2, 4>(p, ksa, lane, w.split, grp, 2, (int64_t)w.n0 + wc * 64, p.N, tc * KSUM_PARTS);
     }
     stamp_tile(it, 0);
     if constexpr (LEAN && !TAIL) wait_vmcnt<0>();   // every DMA piece has landed before the first store is issued (see after_epi)
