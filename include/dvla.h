@@ -76,8 +76,10 @@ typedef struct dvla_gemm_params {
    *   bf16 operand values, result in ksum_dtype = DVLA_DT_F32 / DVLA_DT_BF16).
    *   ksum_workspace: dvla_gemm_ksum_partial_rows(split_k) x (M or N) floats.
    * The ring kernels sum the fragments they feed to the matrix pipe (one v_dot2c_f32_bf16 per dword, in the MFMA
-   * shadow); a configuration without that code runs the column-sum kernel on the operand instead, which needs the operand
-   * stored k-major (a_trans / b_trans = 1: the weight-gradient layout); otherwise DVLA_ERR_UNSUPPORTED. */
+   * shadow); since ABI 7 the phase kernel sums too (both operands r-contiguous: the weight-gradient layout), in the slack of its
+   * fragment-read segments, the sum of a tile row spread over up to four of its tiles -- dvla_gemm_ksum_partial_rows() accounts
+   * for their partial rows.  A configuration without that code runs the column-sum kernel on the operand instead, which needs
+   * the operand stored k-major (a_trans / b_trans = 1); otherwise DVLA_ERR_UNSUPPORTED. */
   void* ksum; int32_t ksum_dtype; int32_t ksum_operand; float* ksum_workspace;
   /* (ABI 5) a_layernorm != 0: the rows of A are layer-normalised on their way into the product -- A'(m, :) = (A(m, :) - mean_m) *
    * rsqrt(var_m + a_ln_eps), no affine parameters, rounded to bf16 like the output of dvla_layernorm_fwd -- i.e. the GEMM computes
