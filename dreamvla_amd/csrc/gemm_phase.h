@@ -202,7 +202,8 @@ void gemm_phase_kernel(GemmKArgs p) {
   // the hazard nop, the DMA -- instead of ~12 (liveness branch, shift + add for the LDS address, M0 saved / set / restored, the
   // per-lane source advanced by a v_add + v_mov).  The K position lives in the SCALAR base of the instruction (one s_add_u32 +
   // s_addc_u32 per operand and K-tile) and the per-lane offsets stay what openA / openB computed; M0 is not restored (no
-  // instruction of these kernels reads it: tests/test_phase_isa.py); the liveness test is made once per K-tile (two loop bodies).
+  // instruction of these kernels reads it: tests/test_phase_isa.py); the liveness test is made once per TILE (two copies of the K
+  // loop, see kloop below -- two copies of the K-tile BODY inside one loop made the register allocator spill the accumulators).
   constexpr bool LEAN = (DBG & 4096) == 0;        // DBG & 4096: the round-4 issue code (measurement variant 40 of gemm.hip)
   const char* kbA = reinterpret_cast<const char*>(p.A);
   const char* kbB = reinterpret_cast<const char*>(p.B);
