@@ -147,6 +147,44 @@ __device__ __forceinline__ void store_token(bf16_t* dst, const f32x16 (&acc)[2],
 // bit position of accumulator register r inside a visibility word already shifted right by 4*g
 __device__ __forceinline__ bool vis_bit(uint32_t vg, int r) { return (vg >> ((r & 3) + 8 * (r >> 2))) & 1u; }
 __device__ __forceinline__ uint32_t low_mask(int n) { return n >= 32 ? 0xffffffffu : ((1u << n) - 1u); }
+// x where the visibility bit of register r is set, `masked_bits` (a float's bit pattern: 0 or -inf) where it is not.  The bit is
+// sign-extended to a lane mask (v_bfe_i32) and merged with one v_bfi_b32 / v_and_b32: two VALU slots per element, where the
+// compare + conditional move needs an and, a compare, the move and a hazard slot between the last two (round 5; same values)
+template <uint32_t MASKED_BITS>
+__device__ __forceinline__ float vis_select(uint32_t vg, int r, float x) {
+  const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vg, (uint32_t)((r & 3) + 8 * (r >> 2)), 1u);     // 0 / ~0
+  const uint32_t xi = __builtin_bit_cast(uint32_t, x);
+  return __builtin_bit_cast(float, MASKED_BITS ? ((xi & m) | (~m & MASKED_BITS)) : (xi & m));
+}
+constexpr uint32_t NEG_INF_BITS = 0xff800000u;
+
+// The tile flags of a ring kernel's walk, for walks of at most 64 tiles (L <= 2048), as three wave-uniform 64-bit words taken by
+// ballot from the LDS table: `need` -- some wave of the workgroup has work in the tile (the ring's walk), `any` / `mixed` -- this
+// wave's own two flag bits.  Finding the next tile and decoding this wave's flag are then a shift and a find-first-set on SGPRs;
+// the table walk they replace is an LDS byte read with its lgkmcnt(0) round trip per probed tile, twice per tile iteration
+// (once for the DMA cursor three tiles ahead, once for the tile being multiplied).  Longer walks keep the table walk.
+struct TileWords {
+  uint64_t need, any, mixed;
+  int n;            // tiles in the walk; 0: the words are not in use (n > 64)
+  __device__ __forceinline__ int next(int t) const {
+    if (t >= n) return -1;
+    const uint64_t m = need >> t;
+    return m ? t + __builtin_ctzll(m) : -1;
+  }
+  __device__ __forceinline__ int flag(int t) const { return (int)((any >> t) & 1u) + (int)((mixed >> t) & 1u); }   // 0 / 1 / 2
+};
+__device__ __forceinline__ TileWords tile_words(const uint8_t* flags, int n, int wave, int lane) {
+  TileWords w{0, 0, 0, 0};
+  if (n <= 64) {
+    const int f = lane < n ? (int)flags[lane] : 0;
+    const int fw = (f >> (2 * wave)) & 3;
+    w.need = __ballot(f != 0);
+    w.any = __ballot(fw != 0);
+    w.mixed = __ballot(fw == 2);
+    w.n = n;
+  }
+  return w;
+}
 
 __device__ __forceinline__ int tile_flag(const AttnKArgs& p, int qt, int kt) {
   if (qt >= p.nqt || kt >= p.nkt) return 0;
@@ -295,11 +333,13 @@ constexpr int FA_NS = 4, FA_TILE = 4096, FA_STAGE = 2 * FA_TILE, FA_RING = FA_NS
 // lds_dst + 16 lane.  The scalar-base form keeps the per-lane address state at one VGPR per operand (64-bit per-lane pointers
 // cost the dQ kernel 4 spilled VGPRs at 128 -- and a scratch reload inside the loop is a VMEM load: s_waitcnt vmcnt(0),
 // i.e. the ring drained every tile).  The host takes the staged kernels when an operand spans 4 GiB or more.
+// M0 (the LDS base of the transfer) is set and NOT restored: nothing else in these kernels reads M0 (tests/test_phase_isa.py checks
+// the built code object), so the save / restore pair of rounds 2-4 was two scalar instructions per request for nothing.
 __device__ __forceinline__ void fa_glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// four fragments read from LDS are all on their way before the first of them is used (an empty asm that "uses" the four)
+__device__ __forceinline__ void fa_group4(bf16x8 (&f)[4]) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); }
 template <int N>
 __device__ __forceinline__ void fa_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -376,6 +416,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       bits[i] = qq < p.Lq ? p.bits_q[(int64_t)qq * p.nkt + kt] : 0u;
     }
   __syncthreads();
+  const TileWords tw = tile_words(flags, p.nkt, wave, lane);
 
   const int n_items = p.B * p.H;
   for (int bh = blockIdx.y; bh < n_items; bh += gridDim.y) {
@@ -400,6 +441,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
 
   auto next_needed = [&](int kt) -> int {
+    if (tw.n) return tw.next(kt);
     while (kt < p.nkt && __builtin_amdgcn_readfirstlane((int)flags[kt]) == 0) ++kt;
     return kt < p.nkt ? kt : -1;
   };
@@ -444,13 +486,21 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       kti = next_needed(kti + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const int flag = (__builtin_amdgcn_readfirstlane((int)flags[kt]) >> (2 * wave)) & 3;
+    const int flag = tw.n ? tw.flag(kt) : (__builtin_amdgcn_readfirstlane((int)flags[kt]) >> (2 * wave)) & 3;
     if (flag != 0) {
       const char* ks = smem + cslot * FA_STAGE;
       const char* vs = ks + FA_TILE;
       f32x16 sacc = zero16();
+      if (!(DBG & 8)) {
+        // all four K fragments are requested before the first multiply (fa_group4): hipcc otherwise recycles ONE fragment register
+        // quad -- read, lgkmcnt(0), multiply, four times over -- and the wave sits through four LDS round trips per tile
+        bf16x8 kf[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) if (!(DBG & 8)) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_k(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) kf[s] = fa_frag_k(ks, l31, s, g);
+        fa_group4(kf);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sacc, 0, 0, 0);
+      }
       const int k0 = kt * 32;
       uint32_t vis = 0xffffffffu;
       if (flag == 2) vis = bits[(wave * 32 + l31) * p.nkt + kt];
@@ -461,7 +511,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = vis_bit(vg, r) ? sv[r] : -INFINITY;
+        for (int r = 0; r < 16; ++r) sv[r] = vis_select<NEG_INF_BITS>(vg, r, sv[r]);
       }
       if (!(DBG & 2)) {
       float mt = sv[0];
@@ -492,12 +542,22 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
         for (int r = 0; r < 16; ++r) sv[r] = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? sv[r] * p.inv_keep : 0.f;
       }
-      const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
+      if (DBG & 4) {
+        const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
+        asm volatile("" :: "v"(pf0), "v"(pf1));
+      } else {
+        // the four V^T fragments (eight transposing reads) are requested first, P is packed under their latency, and the two
+        // output halves alternate so that consecutive multiplies do not wait on each other's accumulator
+        bf16x8 vf[4];
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        if (DBG & 4) { asm volatile("" :: "v"(pf0), "v"(pf1)); continue; }
-        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_vt(vs, db, 0, lane), pf0, oacc[db], 0, 0, 0);
-        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_vt(vs, db, 1, lane), pf1, oacc[db], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) vf[i] = fa_frag_vt(vs, i >> 1, i & 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
+        fa_group4(vf);
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf0, oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pf0, oacc[1], 0, 0, 0);
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf1, oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[3], pf1, oacc[1], 0, 0, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -621,7 +681,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = vis_bit(vg, r) ? ds[r] : 0.f;
+        for (int r = 0; r < 16; ++r) ds[r] = vis_select<0u>(vg, r, ds[r]);
       }
       uint32_t tk = 0u, dx = 0u;   // one hash per (row, tile), one 24-bit multiply-add per element (common.h)
       if (p.has_drop) { tk = drop_tilekey(rowkey, (uint32_t)kt); dx = drop_rot(tk, (uint32_t)g); }
@@ -744,7 +804,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pr[r] = vis_bit(vg, r) ? pr[r] : 0.f;
+        for (int r = 0; r < 16; ++r) pr[r] = vis_select<0u>(vg, r, pr[r]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -931,8 +991,10 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
   f32x16 dqacc[2] = {zero16(), zero16()};
   __syncthreads();
+  const TileWords tw = tile_words(flags, p.nkt, wave, lane);
 
   auto next_needed = [&](int kt) -> int {
+    if (tw.n) return tw.next(kt);
     while (kt < p.nkt && __builtin_amdgcn_readfirstlane((int)flags[kt]) == 0) ++kt;
     return kt < p.nkt ? kt : -1;
   };
@@ -974,7 +1036,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       kti = next_needed(kti + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const int flag = (__builtin_amdgcn_readfirstlane((int)flags[kt]) >> (2 * wave)) & 3;
+    const int flag = tw.n ? tw.flag(kt) : (__builtin_amdgcn_readfirstlane((int)flags[kt]) >> (2 * wave)) & 3;
     if (flag != 0) {
       const char* ks = smem + cslot * FA_STAGE;
       const char* vs = ks + FA_TILE;
@@ -994,7 +1056,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = vis_bit(vg, r) ? ds[r] : 0.f;
+        for (int r = 0; r < 16; ++r) ds[r] = vis_select<0u>(vg, r, ds[r]);
       }
       uint32_t tk = 0u, dx = 0u;   // one hash per (row, tile), one 24-bit multiply-add per element (common.h)
       if (p.has_drop) { tk = drop_tilekey(rowkey, (uint32_t)kt); dx = drop_rot(tk, (uint32_t)g); }
@@ -1005,11 +1067,14 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         ds[r] = ds[r] * (dp - dlt) * p.scale;
       }
       const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
+      bf16x8 kt4[4];
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(ks, db, 0, lane), f0, dqacc[db], 0, 0, 0);
-        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(ks, db, 1, lane), f1, dqacc[db], 0, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i) kt4[i] = fa_frag_tr(ks, i >> 1, i & 1, lane);
+      fa_group4(kt4);
+      dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt4[0], f0, dqacc[0], 0, 0, 0);
+      dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt4[2], f0, dqacc[1], 0, 0, 0);
+      dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt4[1], f1, dqacc[0], 0, 0, 0);
+      dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt4[3], f1, dqacc[1], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     cslot = (cslot + 1) & (FA_NS - 1);
@@ -1086,8 +1151,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
   const uint32_t* tkw = tks + wave * 32 * p.nqt;
   f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
   __syncthreads();
+  const TileWords tw = tile_words(flags, p.nqt, wave, lane);
 
   auto next_needed = [&](int qt) -> int {
+    if (tw.n) return tw.next(qt);
     while (qt < p.nqt && __builtin_amdgcn_readfirstlane((int)flags[qt]) == 0) ++qt;
     return qt < p.nqt ? qt : -1;
   };
@@ -1127,15 +1194,21 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
       qti = next_needed(qti + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const int flag = (__builtin_amdgcn_readfirstlane((int)flags[qt]) >> (2 * wave)) & 3;
+    const int flag = tw.n ? tw.flag(qt) : (__builtin_amdgcn_readfirstlane((int)flags[qt]) >> (2 * wave)) & 3;
     if (flag != 0) {
       const char* qs = smem + cslot * FA_STAGE;
       const char* dos = qs + FA_TILE;
       f32x16 sacc = zero16(), dpacc = zero16();
+      {   // all eight Q / dO fragments requested before the first multiply (see the forward kernel)
+        bf16x8 fq[4], fd[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(qs, l31, s, g), kf[s], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(dos, l31, s, g), vf[s], dpacc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) { fq[s] = fa_frag_rm(qs, l31, s, g); fd[s] = fa_frag_rm(dos, l31, s, g); }
+        fa_group4(fq); fa_group4(fd);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s], kf[s], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[s], vf[s], dpacc, 0, 0, 0);
+        }
       }
       const int q0 = qt * 32;
       float lse2[16], dlt[16];
@@ -1154,7 +1227,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pr[r] = vis_bit(vg, r) ? pr[r] : 0.f;
+        for (int r = 0; r < 16; ++r) pr[r] = vis_select<0u>(vg, r, pr[r]);
       }
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
@@ -1179,12 +1252,19 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
       }
       const bf16x8 pf0 = pack_frag(pr), pf1 = pack_frag(pr + 8);
       const bf16x8 sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
+      {   // the eight transposed fragments first, then eight multiplies that walk the four accumulators round-robin
+        bf16x8 td[4], tq[4];
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(dos, db, 0, lane), pf0, dvacc[db], 0, 0, 0);
-        dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(dos, db, 1, lane), pf1, dvacc[db], 0, 0, 0);
-        dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(qs, db, 0, lane), sf0, dkacc[db], 0, 0, 0);
-        dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(qs, db, 1, lane), sf1, dkacc[db], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) { td[i] = fa_frag_tr(dos, i >> 1, i & 1, lane); tq[i] = fa_frag_tr(qs, i >> 1, i & 1, lane); }
+        fa_group4(td); fa_group4(tq);
+        dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[0], pf0, dvacc[0], 0, 0, 0);
+        dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[0], sf0, dkacc[0], 0, 0, 0);
+        dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[2], pf0, dvacc[1], 0, 0, 0);
+        dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[2], sf0, dkacc[1], 0, 0, 0);
+        dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[1], pf1, dvacc[0], 0, 0, 0);
+        dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[1], sf1, dkacc[0], 0, 0, 0);
+        dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[3], pf1, dvacc[1], 0, 0, 0);
+        dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[3], sf1, dkacc[1], 0, 0, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1349,28 +1429,38 @@ __global__ __launch_bounds__(SB_THREADS) void attn_bwd_short_kernel(AttnKArgs p)
         const char* ks = regB + (size_t)kt * FA_TILE;
         const char* vs = regB + (size_t)(nt + kt) * FA_TILE;
         f32x16 sacc = zero16(), dpacc = zero16();
+        {   // all eight K / V fragments requested before the first multiply (attn_fwd_ring_kernel: fa_group4)
+          bf16x8 fk[4], fv[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
-          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(vs, l31, s, g), dof[s], dpacc, 0, 0, 0);
+          for (int s = 0; s < 4; ++s) { fk[s] = fa_frag_rm(ks, l31, s, g); fv[s] = fa_frag_rm(vs, l31, s, g); }
+          fa_group4(fk); fa_group4(fv);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[s], qf[s], sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[s], dof[s], dpacc, 0, 0, 0);
+          }
         }
         const int k0 = kt * 32;
         float ds[16];
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) ds[rr] = fast_exp2(fmaf(sacc[rr], scale_log2, -lse2));
         if (k0 + 32 > L) {           // the ragged last key tile (wave-uniform)
+          asm volatile("");          // (keeps this a BRANCH: hipcc if-converted it into sixteen selects on every tile)
           const uint32_t vg = low_mask(L - k0) >> (4 * g);
 #pragma unroll
-          for (int rr = 0; rr < 16; ++rr) ds[rr] = vis_bit(vg, rr) ? ds[rr] : 0.f;
+          for (int rr = 0; rr < 16; ++rr) ds[rr] = vis_select<0u>(vg, rr, ds[rr]);
         }
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) ds[rr] = ds[rr] * (dpacc[rr] - dlt) * p.scale;
         const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
+        bf16x8 kt4[4];
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(ks, db, 0, lane), f0, dqacc[db], 0, 0, 0);
-          dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(ks, db, 1, lane), f1, dqacc[db], 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) kt4[i] = fa_frag_tr(ks, i >> 1, i & 1, lane);
+        fa_group4(kt4);
+        dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt4[0], f0, dqacc[0], 0, 0, 0);
+        dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt4[2], f0, dqacc[1], 0, 0, 0);
+        dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt4[1], f1, dqacc[0], 0, 0, 0);
+        dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt4[3], f1, dqacc[1], 0, 0, 0);
       }
       if (q_ok) store_token(p.dq + (int64_t)b * p.dqsb + (int64_t)q * p.dqst + (int64_t)h * p.dqsh, dqacc, 1.0f, g, (p.st16 & 2) != 0);
     }
@@ -1410,10 +1500,16 @@ __global__ __launch_bounds__(SB_THREADS) void attn_bwd_short_kernel(AttnKArgs p)
         }
         if (!active) continue;
         f32x16 sacc = zero16(), dpacc = zero16();
+        {
+          bf16x8 fq[4], fd[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(qs, l31, s, g), kf[s], sacc, 0, 0, 0);
-          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(dos, l31, s, g), vf[s], dpacc, 0, 0, 0);
+          for (int s = 0; s < 4; ++s) { fq[s] = fa_frag_rm(qs, l31, s, g); fd[s] = fa_frag_rm(dos, l31, s, g); }
+          fa_group4(fq); fa_group4(fd);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s], kf[s], sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[s], vf[s], dpacc, 0, 0, 0);
+          }
         }
         const int q0 = qt * 32;
         float pr[16], ds[16];
@@ -1433,12 +1529,19 @@ __global__ __launch_bounds__(SB_THREADS) void attn_bwd_short_kernel(AttnKArgs p)
         }
         const bf16x8 pf0 = pack_frag(pr), pf1 = pack_frag(pr + 8);
         const bf16x8 sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
+        {
+          bf16x8 td[4], tq[4];
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(dos, db, 0, lane), pf0, dvacc[db], 0, 0, 0);
-          dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(dos, db, 1, lane), pf1, dvacc[db], 0, 0, 0);
-          dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(qs, db, 0, lane), sf0, dkacc[db], 0, 0, 0);
-          dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(qs, db, 1, lane), sf1, dkacc[db], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) { td[i] = fa_frag_tr(dos, i >> 1, i & 1, lane); tq[i] = fa_frag_tr(qs, i >> 1, i & 1, lane); }
+          fa_group4(td); fa_group4(tq);
+          dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[0], pf0, dvacc[0], 0, 0, 0);
+          dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[0], sf0, dkacc[0], 0, 0, 0);
+          dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[2], pf0, dvacc[1], 0, 0, 0);
+          dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[2], sf0, dkacc[1], 0, 0, 0);
+          dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[1], pf1, dvacc[0], 0, 0, 0);
+          dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[1], sf1, dkacc[0], 0, 0, 0);
+          dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[3], pf1, dvacc[1], 0, 0, 0);
+          dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[3], sf1, dkacc[1], 0, 0, 0);
         }
       }
       if (key_ok) {
@@ -1509,16 +1612,23 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         const char* ks = smem + (size_t)kt * FA_TILE;
         const char* vs = smem + (size_t)(nt + kt) * FA_TILE;
         f32x16 sacc = zero16();
+        {
+          bf16x8 fk[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
+          for (int s = 0; s < 4; ++s) fk[s] = fa_frag_rm(ks, l31, s, g);
+          fa_group4(fk);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[s], qf[s], sacc, 0, 0, 0);
+        }
         const int k0 = kt * 32;
         float sv[16];
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) sv[rr] = sacc[rr];
         if (k0 + 32 > L) {
+          asm volatile("");          // (keeps this a BRANCH: hipcc if-converted it into sixteen selects on every tile)
           const uint32_t vg = low_mask(L - k0) >> (4 * g);
 #pragma unroll
-          for (int rr = 0; rr < 16; ++rr) sv[rr] = vis_bit(vg, rr) ? sv[rr] : -INFINITY;
+          for (int rr = 0; rr < 16; ++rr) sv[rr] = vis_select<NEG_INF_BITS>(vg, rr, sv[rr]);
         }
         float mt = sv[0];
 #pragma unroll
@@ -1537,12 +1647,16 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
           for (int rr = 0; rr < 16; ++rr) { oacc[0][rr] *= alpha; oacc[1][rr] *= alpha; }
         }
-        const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
+        bf16x8 vt4[4];
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(vs, db, 0, lane), pf0, oacc[db], 0, 0, 0);
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_tr(vs, db, 1, lane), pf1, oacc[db], 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) vt4[i] = fa_frag_tr(vs, i >> 1, i & 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
+        fa_group4(vt4);
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt4[0], pf0, oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt4[2], pf0, oacc[1], 0, 0, 0);
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt4[1], pf1, oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt4[3], pf1, oacc[1], 0, 0, 0);
       }
       if (q_ok) {
         const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;

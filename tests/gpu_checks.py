@@ -1024,6 +1024,10 @@ def all_checks(quick=False):
         (check_self_attention, dict(B=2, H=16, L=777, mask_kind="dreamvla_E", dropout_p=0.1)),
         (check_self_attention, dict(B=1, H=16, L=1302, mask_kind="dreamvla")),
         (check_self_attention, dict(B=1, H=16, L=1302, mask_kind="dreamvla", dropout_p=0.1)),
+        # walks of more than 64 tiles (L > 2048): the ring kernels keep their tile flags in SGPR words up to 64 tiles (round 5)
+        # and walk the LDS table beyond -- these two run the table walk
+        (check_self_attention, dict(B=1, H=2, L=2085, seed=5)),
+        (check_self_attention, dict(B=1, H=2, L=2085, mask_kind="block", dropout_p=0.1, seed=6)),
         (check_self_attention, dict(B=32, H=16, L=651, mask_kind="dreamvla", dropout_p=0.1, rows=8)),
         (check_self_attention, dict(B=32, H=16, L=651, mask_kind="dreamvla", rows=6, period=5)),
         (check_self_attention, dict(B=448, H=16, L=205, rows=10, period=9)),

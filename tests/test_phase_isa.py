@@ -16,12 +16,12 @@ LIB = os.path.join(K.ROOT, "dreamvla_amd", "libdvla_hip.so")
 OBJDUMP = os.path.join(K.LLVM, "llvm-objdump")
 
 
-def _phase_functions():
-    """{symbol: [instruction text, ...]} of every gemm_phase_kernel in the library's gfx950 code objects"""
+def _functions(*needles):
+    """{symbol: [instruction text, ...]} of every kernel of the library's gfx950 code objects whose name contains one of `needles`"""
     out = {}
     with tempfile.TemporaryDirectory() as d:
         for k, co in enumerate(K.code_objects(LIB)):
-            if b"gemm_phase_kernel" not in co and b"gemm_ring_kernel" not in co:
+            if not any(n.encode() in co for n in needles):
                 continue
             path = os.path.join(d, f"co{k}.elf")
             open(path, "wb").write(co)
@@ -30,7 +30,7 @@ def _phase_functions():
             for line in txt.split("\n"):
                 m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
                 if m:
-                    cur = m.group(1) if ("gemm_phase_kernel" in m.group(1) or "gemm_ring_kernel" in m.group(1)) else None
+                    cur = m.group(1) if any(n in m.group(1) for n in needles) else None
                     if cur:
                         out[cur] = []
                     continue
@@ -43,7 +43,7 @@ def _phase_functions():
 
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="library / llvm-objdump not available")
 def test_no_instruction_of_the_phase_kernels_reads_m0():
-    fns = _phase_functions()
+    fns = _functions("gemm_phase_kernel", "gemm_ring_kernel")
     n_phase = sum("gemm_phase_kernel" in n for n in fns)
     n_ring = sum("gemm_ring_kernel" in n for n in fns)
     assert n_phase >= 33 and n_ring >= 96, (n_phase, n_ring)   # phase: 4 layouts x 8 classes + partial-K-tile build (+ measurement
@@ -66,3 +66,60 @@ def test_no_instruction_of_the_phase_kernels_reads_m0():
             assert ins[i - 1].startswith("s_nop") and (ins[i - 2].startswith("s_add_u32 m0") or ins[i - 2].startswith("s_mov_b32 m0")), \
                 (name, ins[i - 3:i + 1])
     assert lean >= 33 + 96, lean
+
+
+ATTN_DMA = ("attn_fwd_ring_kernel", "attn_bwd_dq_ring_kernel", "attn_bwd_dkv_ring_kernel", "attn_fwd_short_kernel", "attn_bwd_short_kernel")
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="library / llvm-objdump not available")
+def test_no_instruction_of_the_attention_dma_kernels_reads_m0():
+    """csrc/attention.hip fa_glds16 sets M0 and does not restore it (round 5): legal while nothing in these kernels reads M0"""
+    fns = _functions(*ATTN_DMA)
+    assert all(any(k in n for n in fns) for k in ATTN_DMA), sorted(fns)
+    for name, ins in fns.items():
+        dma = [i for i, t in enumerate(ins) if t.startswith("global_load_lds_dwordx4")]
+        assert len(dma) >= 2, (name, len(dma))
+        for t in ins:
+            ops = re.split(r"\s+", t, 1)
+            if len(ops) < 2 or "m0" not in ops[1]:
+                continue
+            assert ops[0] == "s_mov_b32", (name, t)
+            dst, srcs = ops[1].split(",", 1)
+            assert dst.strip() == "m0" and "m0" not in srcs, (name, t)                 # written, never read
+        for i in dma:
+            assert ins[i - 1].startswith("s_nop") and ins[i - 2].startswith("s_mov_b32 m0"), (name, ins[i - 3:i + 1])
+
+
+def _mfma_runs(ins):
+    """for every v_mfma in the instruction list: how many `s_waitcnt lgkmcnt` instructions stand between it and the MFMA before it
+    (with no branch in between) -- a fragment read waited for in front of EACH multiply shows up as a run of ones"""
+    waits, out, seen = 0, [], False
+    for t in ins:
+        if t.startswith("v_mfma"):
+            if seen:
+                out.append(waits)
+            seen, waits = True, 0
+        elif t.startswith("s_waitcnt") and "lgkmcnt" in t:
+            waits += 1
+        elif t.startswith("s_cbranch") or t.startswith("s_branch") or t.startswith("s_barrier"):
+            seen, waits = False, 0
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="library / llvm-objdump not available")
+def test_attention_fragment_reads_are_grouped_in_front_of_the_multiplies():
+    """Round 5: hipcc, left alone, recycles ONE register quad for the LDS fragments of a tile -- ds_read, s_waitcnt lgkmcnt(0),
+    v_mfma, repeated -- so a wave sat through an LDS round trip per multiply (8 per tile in the forward kernels, 12-16 in the
+    backward ones).  attention.hip now requests a tile's fragments as a group (fa_group4) before the first multiply.  The check:
+    inside straight-line code, at most a QUARTER of the multiplies of these kernels have an LDS wait directly in front of them
+    (before the change: all of them).  attn_bwd_dq_ring_kernel's FIRST block (eight multiplies: S and dP) is exempt: the kernel
+    sits at its 128 registers (four waves per SIMD), a group of four fragments there spills 48 registers inside the tile loop and
+    even pairs spill 12 (scratch traffic drains the DMA ring) -- only its dQ block is grouped, so seven waits remain there."""
+    fns = _functions(*ATTN_DMA)
+    for name, ins in fns.items():
+        if "attn_fwd_ring_kernel" in name and "ILi0E" not in name:
+            continue                               # ablation builds of the forward ring kernel (timing only)
+        runs = _mfma_runs(ins)
+        assert len(runs) >= 6, (name, runs)
+        frac = sum(1 for w in runs if w > 0) / len(runs)
+        assert frac <= (0.75 if "dq_ring" in name else 0.3), (name, frac, runs)
