@@ -3,7 +3,6 @@ and writes gpurun_out/perf.json.  Not a test."""
 import json
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,7 +1,6 @@
 """CPU: pins oracle/torch_ref.py::attention_bf16 (the restatement with the kernels' two bf16 rounding points, used by the
 GPU parity tests at 1e-3) to oracle/torch_ref.py::attention (the fp32 restatement of the reference's softmax attention, itself
 pinned to the real reference modules through the golden fixtures): same function up to the roundings of P and dS."""
-import math
 
 import pytest
 import torch

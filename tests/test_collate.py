@@ -7,7 +7,6 @@ maps incl. the traj_cons shift, label cuts, track dictionary).  GPU: the two cam
 csrc/input_pipeline.hip) against the fp32 frames the real collator produced, with the shifts it drew injected."""
 import os
 
-import numpy as np
 import pytest
 import torch
 

@@ -1,5 +1,4 @@
 """Host logic (CPU): attention-mask generator bit-exactness vs the reference + the kernel's mask tables."""
-import itertools
 
 import numpy as np
 import pytest
