@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 5, attention fragment grouping: parity of every attention case, then the same-box A/B against the library built from the
 # tree before the change (build/ab/libdvla_before_attn.so, loaded through DVLA_LIB), then a short training-step run.
+#   (the older build: `cp dreamvla_amd/libdvla_hip.so build/ab/libdvla_before_attn.so` before making the change; build/ is not in git)
 #   gpurun --timeout 540 -- bash tests/probes/attn_ab.sh
 set -u
 OUT=gpurun_out; mkdir -p $OUT
