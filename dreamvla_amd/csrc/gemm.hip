@@ -331,6 +331,10 @@ static bool launch_phase_experiment(int idx, GemmKArgs& a, int split_k, hipStrea
     case 1: launch_phase_one<false, false, 0, 7488>(a, split_k, stream); return true;
     case 2: launch_phase_one<false, false, 0, 3328>(a, split_k, stream); return true;
     case 3: launch_phase_one<false, false, 0, 256>(a, split_k, stream); return true;
+    case 4: launch_phase_one<false, false, 0, 32768>(a, split_k, stream); return true;            // 44: round-5 boundary, buffer-descriptor DMA
+    case 5: launch_phase_one<false, false, 0, 16384 | 65536>(a, split_k, stream); return true;    // 45: deferred epilogue, fragment addresses hoisted
+    case 6: launch_phase_one<false, false, 0, 16384 | 65536 | 131072>(a, split_k, stream); return true;    // 46: 45 + the in-loop epilogue at priority 2
+    case 7: launch_phase_one<false, false, 0, 16384>(a, split_k, stream); return true;                      // 47: deferred epilogue as first measured (fragment addresses re-derived per K-tile)
     default: return false;
   }
 }
@@ -464,7 +468,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
     else if (variant == 9 && phase_ok(a, combo)) choice = 6;
     else if (variant == 10 && phase_ok(a, combo)) choice = 7;
     else if (variant > 80 && variant < 90 && combo == 0 && phase_ok(a, combo)) choice = 80 + (variant - 80);
-    else if (variant >= 40 && variant < 44 && combo == 0 && phase_ok(a, combo) && epi_class(a) == EPI_P0) choice = variant;
+    else if (variant >= 40 && variant < 48 && combo == 0 && phase_ok(a, combo) && epi_class(a) == EPI_P0) choice = variant;
     // k-sums ride on the ring kernels and (round 5) on the phase kernel of the fp32-output class (split-K partial sums or fp32 C:
     // the weight gradients); the other configurations get the column-sum kernel below
     const bool phase_choice = choice == 5 || choice == 6 || choice == 7;
@@ -485,7 +489,7 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
       case 6: launch_phase(a, combo, split_k, stream, 1); break;   // falls back to the plain schedule when stream-K does not apply
       case 7: launch_phase(a, combo, split_k, stream, 2); break;
       case 11: launch_skinny(a, stream); break;
-      case 81: case 83: case 84: case 85: case 86: case 89:   // ablations (plain bf16 epilogue only): 81 no MFMA, 83 no MFMA + no reads, 84 no DMA, 85 no epilogue, 86 raw stores only
+      case 81: case 83: case 84: case 85: case 86: case 88: case 89:   // ablations (plain bf16 epilogue only): 81 no MFMA, 83 no MFMA + no reads, 84 no DMA, 85 no epilogue, 86 raw stores only
         set_tiles<PCfg::BM, PCfg::BN, PCfg::GH>(a);
         if (epi_class(a) != EPI_P0) return DVLA_ERR_UNSUPPORTED;
         if (choice == 81) launch_phase_one<false, false, 0, 1>(a, split_k, stream);
@@ -493,10 +497,11 @@ extern "C" int dvla_gemm_bf16(const dvla_gemm_params* q, void* stream_) {
         else if (choice == 84) launch_phase_one<false, false, 0, 4>(a, split_k, stream);
         else if (choice == 85) launch_phase_one<false, false, 0, 16>(a, split_k, stream);
         else if (choice == 86) launch_phase_one<false, false, 0, 32>(a, split_k, stream);
+        else if (choice == 88) launch_phase_one<false, false, 0, 16448>(a, split_k, stream);   // 88: the stamps build of the deferred epilogue
         else launch_phase_one<false, false, 0, 64>(a, split_k, stream);   // 89: s_memtime stamps into p.workspace
         break;
       default:
-        if (choice >= 40 && choice < 44) {
+        if (choice >= 40 && choice < 48) {
           set_tiles<PCfg::BM, PCfg::BN, PCfg::GH>(a);
           a.sk_tiles = 0;
           if (launch_phase_experiment(choice - 40, a, split_k, stream)) break;

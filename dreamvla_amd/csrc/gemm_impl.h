@@ -708,10 +708,32 @@ __device__ __forceinline__ void glds16s_m0(const void* sbase, uint32_t voff, uin
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
-template <int IMM>
+// PAD (round 6): wait states between the M0 write and the DMA.  0 is the M0 hazard alone.  hipcc may reload a spilled SGPR (the scalar
+// base) with v_readlane_b32 right in front of the statement, and an SGPR written by the VALU needs FIVE wait states before a VMEM
+// instruction reads it -- padding hipcc does for its own instructions, not for these.  tests/test_phase_isa.py audits every built kernel
+// for that pattern; the one instantiation it found (the NN layout's generic epilogue class, whose scalar pressure is the highest) gets PAD = 3.
+template <int IMM, int PAD = 0>
 __device__ __forceinline__ void glds16s_lean(const void* sbase, uint32_t voff, uint32_t lds_base) {
-  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-               : : "v"(voff), "s"(sbase), "s"(lds_base), "n"(IMM) : "memory", "scc");
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop %4\n\tglobal_load_lds_dwordx4 %0, %1"
+               : : "v"(voff), "s"(sbase), "s"(lds_base), "n"(IMM), "n"(PAD) : "memory", "scc");
+}
+
+// Round 6, the deferred-epilogue builds: the same piece through a BUFFER descriptor over the whole operand -- address = base + per-lane
+// offset + scalar offset, rows past the operand's end are refused by the descriptor's bounds check (no per-lane clamp), so a wave's
+// four pieces of an image need two per-lane offsets (even / odd piece: the swizzle alternates) and scalar offsets instead of four
+// per-lane offsets and the hoisted row / column parts they were built from (gemm_phase.h BUFDMA).  soff must have been written well
+// ahead of the statement (an SGPR written by the SALU needs five wait states in front of a VMEM instruction that reads it).
+typedef __attribute__((ext_vector_type(4))) uint32_t rsrc4;
+__device__ __forceinline__ rsrc4 operand_rsrc(const void* base, uint64_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  return rsrc4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes, 0x00020000u};
+}
+template <int IMM>
+__device__ __forceinline__ void glds16b_lean(rsrc4 rs, uint32_t voff, uint32_t soff, uint32_t lds_base) {
+  // (s_nop 3: with the s_add in front, five wait states between a compiler reload of rs / soff -- v_readlane_b32 of a spilled SGPR,
+  //  which hipcc may place right in front of the statement and does not pad for instructions it cannot see -- and the VMEM read)
+  asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_base), "n"(IMM) : "memory", "scc");
 }
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -920,7 +942,9 @@ __device__ __forceinline__ u32x4 window_load(const RowWindow& w, int row) {
 }
 
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };   // timeline builds pass a recorder instead
-template <int TM, int EPI, class ST = NoStamp>
+// NO_BIAS: the bias is already inside the accumulators (the phase kernel's deferred-epilogue builds fold it in with one MFMA per
+// accumulator block, gemm_phase.h)
+template <int TM, int EPI, class ST = NoStamp, bool NO_BIAS = false>
 __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2][TM], int lane, int64_t m_base,
                                              int64_t n_base, int split, ST st = ST()) {
   if (n_base >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
@@ -931,7 +955,7 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
   constexpr bool f32_out = EPI == EPI_F32;
   const bool has_dact = epi_dact(EPI) > 0 || (epi_dact(EPI) < 0 && p.dact_aux != nullptr);
   const bool has_res = epi_res(EPI) > 0 || (epi_res(EPI) < 0 && p.residual != nullptr);
-  const bool has_bias = !split_out && p.bias != nullptr;
+  const bool has_bias = !NO_BIAS && !split_out && p.bias != nullptr;
   const bool two_aux = has_dact && has_res;   // none of the model's GEMMs has both: the act' operand is then read late
 
   // ================= split-K partial sums (the weight gradients): whole 128-byte lines of fp32 =================
@@ -1299,6 +1323,55 @@ __device__ __forceinline__ void reg_epilogue(const GemmKArgs& p, f32x16 (&acc)[2
     });
   });
   });
+}
+
+// ================= pieces of the phase kernel's DEFERRED epilogue (round 6, gemm_phase.h) =================
+// The phase kernel's tile boundary was 16-22 % of a K = 1024 launch with the matrix pipe idle (profiles/r05_gemm_epilogue_decomposition.txt).
+// Its deferred builds run the epilogue of tile t at the head of the next tile's first load segment, one wave group at a time, while
+// the partner wave of the SIMD multiplies (gemm_phase.h DEFER).  The pieces below are what that path needs.
+//
+// Loads the compiler must not count (as the LDS-DMA pieces: its own s_waitcnt in front of the first use would be computed without
+// the DMA pieces issued in between and drain them): issued from inline asm, waited for by wait_vmcnt_dyn + settle.
+// (s_nop 4: an SGPR written by a VALU instruction -- hipcc reloads spilled SGPRs with v_readlane_b32, possibly right in front of the
+// statement -- needs five wait states before a VMEM instruction reads it; hipcc pads that only for instructions it can see.  The
+// first build without the nops read the bias through a stale base register: memory faults in every erf-GELU launch.
+// tests/probes/asm_hazard_audit.py checks the compiler's assembly for this pattern.)
+__device__ __forceinline__ uint32_t aload_b32(const void* sbase, uint32_t voff) {
+  uint32_t r;
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+__device__ __forceinline__ uint32_t aload_u16(const void* sbase, uint32_t voff) {
+  uint32_t r;
+  asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+__device__ __forceinline__ void settle(uint32_t& a, uint32_t& b) { asm volatile("" : "+v"(a), "+v"(b) :: "memory"); }
+// s_waitcnt vmcnt(n) for a wave-uniform n = 0, 4, 8, ... 60 (the immediate is six bits); other values round DOWN (waits for more)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n >> 2) {
+    case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<4>(); break;   case 2: wait_vmcnt<8>(); break;   case 3: wait_vmcnt<12>(); break;
+    case 4: wait_vmcnt<16>(); break;  case 5: wait_vmcnt<20>(); break;  case 6: wait_vmcnt<24>(); break;  case 7: wait_vmcnt<28>(); break;
+    case 8: wait_vmcnt<32>(); break;  case 9: wait_vmcnt<36>(); break;  case 10: wait_vmcnt<40>(); break; case 11: wait_vmcnt<44>(); break;
+    case 12: wait_vmcnt<48>(); break; case 13: wait_vmcnt<52>(); break; case 14: wait_vmcnt<56>(); break; default: wait_vmcnt<60>(); break;
+  }
+}
+// The bias as ONE extra multiply per accumulator block: acc[n][m] += sum_k F[n][k] . O[m][k] with F[n][0..2] = a three-way bf16 split of
+// bias[n] (hi + mid + lo == the fp32 value: 3 x 8 significant bits; a bf16 bias is its own `hi`) and O[m][0..2] = 1 -- k = 0..3 live in
+// the lower half-wave of a v_mfma_f32_32x32x8_bf16_1k operand, the upper half-wave holds zeros.  128 v_add per tile and wave (and the
+// bias registers they read) become 8 short MFMAs.
+typedef __attribute__((ext_vector_type(4))) short bf16x4v;
+__device__ __forceinline__ bf16x4v bias_split(float b, bool lower_half) {
+  const float b0 = lower_half ? b : 0.f;
+  const bf16_t hi = f2bf(b0);
+  const float r1 = b0 - bf2f(hi);
+  const bf16_t mid = f2bf(r1);
+  const bf16_t lo = f2bf(r1 - bf2f(mid));
+  return bf16x4v{(short)hi, (short)mid, (short)lo, 0};
+}
+__device__ __forceinline__ bf16x4v bias_ones(bool lower_half) {
+  const short one = lower_half ? (short)0x3f80 : (short)0;
+  return bf16x4v{one, one, one, 0};
 }
 
 template <class RC, bool A_T, bool B_T, int EPI>

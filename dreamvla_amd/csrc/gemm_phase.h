@@ -94,6 +94,17 @@ void gemm_phase_kernel(GemmKArgs p) {
   constexpr int BM = PCfg::BM, BN = PCfg::BN, BKS = PCfg::BKS, CPW = PCfg::CPW;
   constexpr bool TAIL = (DBG & 128) != 0;
   constexpr int PL = (DBG >> 8) & 15;
+  // DEFER (DBG & 16384, round 6; the P classes): the epilogue of a whole tile (kind 0) that has a successor runs at the head of LOAD1 of
+  // the NEXT tile's first K-tile -- every fragment register is dead there, the accumulators are complete, and the partner group is in a
+  // multiply segment (group 0's epilogue beside group 1's MFMA2 of the old tile, group 1's beside group 0's MFMA1 of the new one: the
+  // VALU and the CU's store path serve ONE group at a time instead of both with the matrix pipe idle) -- and that K-tile's MFMA1 / MFMA2
+  // overwrite the accumulator halves through a zero C operand (no zeroing).  The groups keep their one-segment skew across such a
+  // boundary: no re-align / re-stagger barriers, no drain of the DMA queue.  The bias enters the accumulators as one short MFMA per
+  // block in the first K-tile (no bias registers, no adds in the epilogue).
+  constexpr bool DEFER = (DBG & 16384) != 0;
+  static_assert(!(DBG & 32768) || (!TAIL && (DBG & 4096) == 0), "buffer DMA path: lean issue code, whole K-tiles");
+  static_assert(!DEFER || (!TAIL && (DBG & (4096 | 8192)) == 0 && PL == 0 && (EPI == EPI_P0 || EPI == EPI_P_ERF || EPI == EPI_P_TANH)),
+                "deferred epilogue: production loop, P classes");
   static_assert(!TAIL || (A_T && B_T), "partial K-tiles: k-major operands only");
   static_assert(piece_place(PL).slot[4] >= 7, "B pieces: from LOAD2 on");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -209,11 +220,41 @@ void gemm_phase_kernel(GemmKArgs p) {
   const char* kbB = reinterpret_cast<const char*>(p.B);
   uint32_t m0A = smem_base + (uint32_t)(wave * (CPW * 1024));
   uint32_t m0B = m0A + (uint32_t)PCfg::B_BASE;
+  // BUFDMA (the deferred-epilogue builds): pieces through a buffer descriptor over the whole operand (gemm_impl.h glds16b_lean).
+  // Piece i of this wave = voX[i & 1] (per lane, relative to the segment's origin) + soX / soX2 (scalar: origin + K position, for
+  // pieces 0-1 / 2-3).  k-contiguous operand: piece c = 4 wave + i holds rows 8 c + lane / 8, slot lane % 8 swizzled by
+  // (row >> 1) & 7 = (lane >> 4) + 4 (i & 1); r-contiguous: k rows 2 c + lane / 32, slot lane % 32 swizzled by 4 (k & 3) =
+  // 4 (2 (i & 1) + lane / 32) -- dma_src's maps, with the piece index split into parity (per lane) and pair (scalar).
+  constexpr bool BUFDMA = DEFER || (DBG & 32768) != 0;     // (DBG & 32768 alone: measurement build, the round-5 boundary on the buffer path)
+  uint32_t voA[2] = {0, 0}, voB[2] = {0, 0};
+  uint32_t soA = 0, soA2 = 0, soB = 0, soB2 = 0;
+  const rsrc4 rsA = operand_rsrc(p.A, (uint64_t)(A_T ? p.K : p.M) * (uint64_t)p.lda * 2);
+  const rsrc4 rsB = operand_rsrc(p.B, (uint64_t)(B_T ? p.K : p.N) * (uint64_t)p.ldb * 2);
+  auto buf_offsets = [&](auto trans_c, int64_t ld, int64_t row0, int64_t k0, uint32_t (&vo)[2], uint32_t& so, uint32_t& so2) {
+    constexpr bool TR = decltype(trans_c)::value;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));          // (per segment, not hoisted: these are ~10 VALU)
+    const uint32_t ldb2 = (uint32_t)(ld * 2);
+    if constexpr (!TR) {
+      const uint32_t r = (uint32_t)(wave * 32 + (lane_o >> 3)), sl = (uint32_t)(lane_o & 7), sw = (uint32_t)(lane_o >> 4);
+      vo[0] = r * ldb2 + ((sl ^ sw) << 4);
+      vo[1] = (r + 8) * ldb2 + ((sl ^ (sw + 4)) << 4);
+      so = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((row0 * ld + k0) * 2));
+      so2 = so + 16 * ldb2;
+    } else {
+      const uint32_t k = (uint32_t)(wave * 8 + (lane_o >> 5)), sl = (uint32_t)(lane_o & 31), h = (uint32_t)(lane_o >> 5);
+      vo[0] = k * ldb2 + ((sl ^ (4 * h)) << 4);
+      vo[1] = (k + 2) * ldb2 + ((sl ^ (4 * (2 + h))) << 4);
+      so = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((k0 * ld + row0) * 2));
+      so2 = so + 4 * ldb2;
+    }
+  };
   auto openA = [&](int it) {
     Seg w;
     liveA = seg_cached(it, w);
     if (!liveA) return;
     nkA = w.ns; ktA = 0; tvA = tail_steps(w);
+    if constexpr (BUFDMA) { buf_offsets(std::integral_constant<bool, A_T>{}, p.lda, w.m0, w.k_begin, voA, soA, soA2); return; }
     if constexpr (LEAN) kbA = reinterpret_cast<const char*>(p.A);
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
@@ -225,6 +266,7 @@ void gemm_phase_kernel(GemmKArgs p) {
     liveB = seg_cached(it, w);
     if (!liveB) return;
     nkB = w.ns; ktB = 0; tvB = tail_steps(w);
+    if constexpr (BUFDMA) { buf_offsets(std::integral_constant<bool, B_T>{}, p.ldb, w.n0, w.k_begin, voB, soB, soB2); return; }
     if constexpr (LEAN) kbB = reinterpret_cast<const char*>(p.B);
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
@@ -241,10 +283,11 @@ void gemm_phase_kernel(GemmKArgs p) {
   };
   auto pieceA = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
+    if constexpr (BUFDMA) { glds16b_lean<i * 1024>(rsA, voA[i & 1], (i >> 1) ? soA2 : soA, m0A); return; }
     uint32_t off = srcA[i];
     if constexpr (TAIL) { if (tvA < 4 && ktA == nkA - 1) off -= tail_back(i, tvA, p.lda); }
     if constexpr (LEAN) {
-      glds16s_lean<i * 1024>(kbA, off, m0A);
+      glds16s_lean<i * 1024, EPI == EPI_GEN ? 3 : 0>(kbA, off, m0A);
     } else {
       const uint32_t dst = smem_base + (uint32_t)(nA * PCfg::A_BYTES + wave * (CPW * 1024) + i * 1024);
       glds16s(p.A, off, __builtin_amdgcn_readfirstlane(dst));
@@ -253,15 +296,17 @@ void gemm_phase_kernel(GemmKArgs p) {
   };
   auto doneA = [&]() {
     nA = nA == PCfg::NA - 1 ? 0 : nA + 1;
+    if constexpr (BUFDMA) { soA += stepA; soA2 += stepA; }
     if constexpr (LEAN) { kbA += stepA; m0A = nA == 0 ? m0A - (uint32_t)((PCfg::NA - 1) * PCfg::A_BYTES) : m0A + (uint32_t)PCfg::A_BYTES; }
     if (++ktA == nkA) openA(++itA);
   };
   auto pieceB = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
+    if constexpr (BUFDMA) { glds16b_lean<i * 1024>(rsB, voB[i & 1], (i >> 1) ? soB2 : soB, m0B); return; }
     uint32_t off = srcB[i];
     if constexpr (TAIL) { if (tvB < 4 && ktB == nkB - 1) off -= tail_back(i, tvB, p.ldb); }
     if constexpr (LEAN) {
-      glds16s_lean<i * 1024>(kbB, off, m0B);
+      glds16s_lean<i * 1024, EPI == EPI_GEN ? 3 : 0>(kbB, off, m0B);
     } else {
       const uint32_t dst = smem_base + (uint32_t)(PCfg::B_BASE + (nB & 1) * PCfg::B_BYTES + wave * (CPW * 1024) + i * 1024);
       glds16s(p.B, off, __builtin_amdgcn_readfirstlane(dst));
@@ -270,6 +315,7 @@ void gemm_phase_kernel(GemmKArgs p) {
   };
   auto doneB = [&]() {
     ++nB;
+    if constexpr (BUFDMA) { soB += stepB; soB2 += stepB; }
     if constexpr (LEAN) { kbB += stepB; m0B = (nB & 1) ? m0B + (uint32_t)PCfg::B_BYTES : m0B - (uint32_t)PCfg::B_BYTES; }
     if (++ktB == nkB) openB(++itB);
   };
@@ -349,6 +395,18 @@ void gemm_phase_kernel(GemmKArgs p) {
   // -1 ... -3 %; the groups keeping their one-segment skew through the tile boundary -- group 0's epilogue beside group 1's last
   // multiply segment -- -1 ... -2 %: profiles/r05_gemm_placement_probe*.txt, variants 55 / 56 / 71 / 72.)
   int u = 0, ua = 0;   // global K-tile counter of the multiply, and u % 3
+  f32x16 acc[2][4];
+  if constexpr (DEFER) {     // (defined once: the first K-tile of every segment overwrites them)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  bool pend = false;          // DEFER: slabs 1-3 of the previous tile (origin pm0, pn0) are still in the accumulators
+  int pm0 = 0, pn0 = 0;
+  bool aligned_now = true;    // the two groups are at the same program point (false: group 1 runs one segment behind)
   for (int it = 0;; ++it) {
     // The segment's tile origin / split / kind stay live across the K loop as SCALARS (6 SGPRs, spilled to VGPR lanes when
     // the allocator runs out: one v_readlane each) -- re-deriving them for the epilogue was ~150 dependent scalar instructions
@@ -361,20 +419,35 @@ void gemm_phase_kernel(GemmKArgs p) {
     const int seg_ns = w.ns;
     const int seg_tv = __builtin_amdgcn_readfirstlane(tail_steps(w));
 
-    f32x16 acc[2][4];
+    if constexpr (!DEFER) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    // DEFER: is this tile's epilogue deferred (a whole tile with a successor); the bias of the wave's 64 columns (lane l: column
+    // n0 + 64 wc + l) is requested in LOAD2 of the tile's LAST K-tile and added behind the K loop -- a register that crossed the
+    // in-loop epilogue of the previous tile tipped hipcc's allocator into spilling the DMA offsets (171 spills for ONE register)
+    Seg nx;
+    bool has_next = false, defer_this = false, tile_bias = false;
+    uint32_t braw = 0;
+    int bias_young = 0;       // DMA pieces issued behind the bias load
+    if constexpr (DEFER) {
+      has_next = seg_cached(it + 1, nx);
+      defer_this = w.kind == 0 && has_next;
+      tile_bias = p.bias != nullptr && w.kind != 2;      // (a stream-K tail's partial sums are added to the owner's, which carry it)
+    }
+    const bool fresh = DEFER ? aligned_now : true;      // this tile starts behind an old-style boundary (or is the first)
 
     float ksa[4] = {0.f, 0.f, 0.f, 0.f};     // k-sums of this wave's A row blocks (a-lo 0, 1; a-hi 2, 3) -- or, [0] and [1], of its B column blocks (a launch sums one operand)
     // S = p.ksum_parts / KSUM_PARTS tiles of a row (column) share its sum; this tile's column (row) index c takes the K-tiles with
     // kt % S == c: ks_cnt counts down to its next K-tile (-1: this tile does not sum).  Two live scalars.
     const int ks_c = !KSUM ? 0 : p.ksum_op == 1 ? w.n0 / BN : w.m0 / BM;
     int ks_cnt = (KSUM && ks_c * KSUM_PARTS < p.ksum_parts) ? ks_c : -1;
-    if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one segment behind group 0
+    if (grp == 1 && fresh) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one segment behind group 0
+    aligned_now = false;
     __builtin_amdgcn_sched_barrier(0);
     if (it > 0) stamp_tile(it - 1, 3);
 
@@ -403,17 +476,45 @@ void gemm_phase_kernel(GemmKArgs p) {
       // (vmcnt(0) below: the youngest is half a K-tile old) and K-tile 0 of the next tile skips both of its waits; K-tile 1's
       // wait then meets stores that have had a whole K-tile to drain.
       // (Not in the partial-K-tile build: its K ranges are 80+ K-tiles long, and one more live scalar tips its loop into spilling.)
-      const bool after_epi = LEAN && !TAIL && kt == 0 && it > 0;
+      const bool after_epi = LEAN && !TAIL && kt == 0 && it > 0 && fresh;
+      const bool first = kt == 0;
+      // (DEFER: the lane-dependent parts of the fragment addresses are re-derived per K-tile -- ~10 VALU in a load segment --
+      //  instead of living in four registers across the in-loop epilogue, where hipcc spilled them and reloaded them behind vmcnt(0))
+      int lane_k = lane;
+      if constexpr (DEFER && (DBG & 65536) == 0) asm volatile("" : "+v"(lane_k));
+      int nst = 0;      // DEFER: epilogue stores this wave has issued in this K-tile so far (the counted waits skip them)
       // ---------------- LOAD1 ----------------
       stamp(u, 0);
       const auto ia = live_or(live_c, liveA);
       DVLA_SLOT(0, ia, false);
+      if constexpr (DEFER) {
+        // the previous tile's epilogue: its accumulators are complete, every fragment register is dead, the partner group multiplies
+        if (first && pend && pn0 + wc * 64 < p.N) {
+          int lane_e = lane;
+          asm volatile("" : "+v"(lane_e));
+          if constexpr ((DBG & 131072) != 0) __builtin_amdgcn_s_setprio(2);      // (measurement: the epilogue above the partner's multiply segment)
+          if constexpr ((DBG & 64) != 0) {      // slab stamps of the in-loop epilogue (same slots as the boundary epilogue's)
+            auto st = [&](int idx) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (stamps && it == 2 && lane == 0)
+                (reinterpret_cast<uint64_t*>(p.workspace) + 640 + (wave >> 2) * 16)[idx] = __builtin_amdgcn_s_memtime();
+              __builtin_amdgcn_sched_barrier(0);
+            };
+            reg_epilogue<4, EPI, decltype(st), true>(p, acc, lane_e, (int64_t)pm0 + grp * 128, (int64_t)pn0 + wc * 64, 0, st);
+          } else {
+            reg_epilogue<4, EPI, NoStamp, true>(p, acc, lane_e, (int64_t)pm0 + grp * 128, (int64_t)pn0 + wc * 64, 0);
+          }
+          nst = p.preact ? 32 : 16;
+          if constexpr ((DBG & 131072) != 0) __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) if (!(DBG & 2)) fb[i][ks] = ring_frag<B_T, BN, BKS>(bufB, wc * 64 + i * 32, ks, lane);
+        for (int i = 0; i < 2; ++i) if (!(DBG & 2)) fb[i][ks] = ring_frag<B_T, BN, BKS>(bufB, wc * 64 + i * 32, ks, lane_k);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + j * 32, ks, lane);
+        for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + j * 32, ks, lane_k);
       }
       DVLA_SLOT(1, ia, false);
       wait_lds();
@@ -450,12 +551,27 @@ void gemm_phase_kernel(GemmKArgs p) {
       __builtin_amdgcn_s_setprio(1);
       static_for<4>([&](auto ksc) {
         constexpr int ks = decltype(ksc)::value;
+        if constexpr (DEFER && ks == 0) {
+          if (first) {        // a segment's first K-tile: C = 0 (nothing to zero)
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][0], fa[j][0], zero, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][0], fa[j][0], acc[i][j], 0, 0, 0);
+          }
+        } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             if (!(DBG & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][ks], fa[j][ks], acc[i][j], 0, 0, 0);
             else asm volatile("" :: "v"(fb[i][ks]), "v"(fa[j][ks]));
+        }
         if constexpr (pieces_up_to(PL, 3 + ks) != pieces_up_to(PL, 2 + ks)) DVLA_SLOT(3 + ks, ia, false);
       });
       __builtin_amdgcn_s_setprio(0);
@@ -465,15 +581,28 @@ void gemm_phase_kernel(GemmKArgs p) {
       stamp(u, 4);
       // ---------------- LOAD2 ----------------
       const auto ib = live_or(live_c, liveB);
+      if constexpr (DEFER) {
+        if (kt == seg_ns - 1 && tile_bias) {      // the tile's bias: in flight during its last multiply segment (older than this K-tile's B pieces)
+          const int nb = w.n0 + wc * 64;
+          const uint32_t col = (uint32_t)((nb < p.N ? nb : 0) + lane_k);
+          braw = p.bias_f32 ? aload_b32(p.bias, 4 * col) : aload_u16(p.bias, 2 * col);
+          bias_young = ib ? CPW : 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       DVLA_SLOT(7, ia, ib);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + 64 + j * 32, ks, lane);
+        for (int j = 0; j < 2; ++j) if (!(DBG & 2)) fa[j][ks] = ring_frag<A_T, BM, BKS>(bufA, grp * 128 + 64 + j * 32, ks, lane_k);
       DVLA_SLOT(8, ia, ib);
       // group 1 sits one segment behind group 0, which reads tile u+1 in the next slot: group 1's pieces of A(u+1) / B(u+1)
-      // (issued during ITS tile u-1) must have landed by now.  Younger than those: the pieces of this tile issued so far.
-      if (grp == 1 && !after_epi) { if (ia && ib) wait_vmcnt<pieces_up_to(PL, 8)>(); else wait_vmcnt<0>(); }
+      // (issued during ITS tile u-1) must have landed by now.  Younger than those: the pieces of this tile issued so far
+      // (and, DEFER, the slab stores of this K-tile).
+      if (grp == 1 && !after_epi) {
+        if (DEFER && nst != 0) { if (ia && ib) wait_vmcnt_dyn(pieces_up_to(PL, 8) + nst); else wait_vmcnt<0>(); }
+        else { if (ia && ib) wait_vmcnt<pieces_up_to(PL, 8)>(); else wait_vmcnt<0>(); }
+      }
       wait_lds();
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TAIL) {
@@ -502,26 +631,50 @@ void gemm_phase_kernel(GemmKArgs p) {
       __builtin_amdgcn_s_setprio(1);
       static_for<4>([&](auto ksc) {
         constexpr int ks = decltype(ksc)::value;
+        if constexpr (DEFER && ks == 0) {
+          if (first) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][0], fa[j][0], zero, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][0], fa[j][0], acc[i][2 + j], 0, 0, 0);
+          }
+        } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             if (!(DBG & 1)) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i][ks], fa[j][ks], acc[i][2 + j], 0, 0, 0);
             else asm volatile("" :: "v"(fb[i][ks]), "v"(fa[j][ks]));
+        }
         if constexpr (pieces_up_to(PL, 10 + ks) != pieces_up_to(PL, 9 + ks)) DVLA_SLOT(10 + ks, ia, ib);
       });
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      // everything but this tile's eight pieces (A(u+2), B(u+2)) has landed: A(u+1), B(u+1)
-      if (!after_epi) { if (ia && ib) wait_vmcnt<2 * CPW>(); else wait_vmcnt<0>(); }
+      // everything but this tile's eight pieces (A(u+2), B(u+2)) -- and, DEFER, its slab stores -- has landed: A(u+1), B(u+1)
+      if (!after_epi) {
+        if (DEFER && nst != 0) { if (ia && ib) wait_vmcnt_dyn(2 * CPW + nst); else wait_vmcnt<0>(); }
+        else { if (ia && ib) wait_vmcnt<2 * CPW>(); else wait_vmcnt<0>(); }
+      }
+      if constexpr (DEFER) { if (first) pend = false; }
       stamp(u, 7);
       if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
         }
     };
     if constexpr (LEAN && !(TAIL && KSUM)) {      // (the partial-K-tile + k-sum build keeps one copy of its loop: registers)
-      Seg nx;
-      const bool all_live = seg_cached(it + 1, nx) && nx.ns >= 2;
-      if (all_live) kloop(std::true_type{}); else kloop(std::false_type{});
+      if constexpr (DEFER) {
+        // ONE copy of the loop: the accumulators now live across tile boundaries, and two loops that hold them in different
+        // registers cost a shuffle through scratch at every tile top (hipcc spilled 491 VGPRs)
+        kloop(std::false_type{});
+      } else {
+        const bool all_live = seg_cached(it + 1, nx) && nx.ns >= 2;
+        if (all_live) kloop(std::true_type{}); else kloop(std::false_type{});
+      }
     } else {
       kloop(std::false_type{});
     }
@@ -531,9 +684,31 @@ void gemm_phase_kernel(GemmKArgs p) {
       if (ks_cnt >= 0 && p.ksum_op == 1) ksum_store<4, 4>(p, ksa, lane, w.split, wc, 4, (int64_t)w.m0 + grp * 128, p.M, tc * KSUM_PARTS);
       if (ks_cnt >= 0 && p.ksum_op == 2) ksum_store<2, 4>(p, ksa, lane, w.split, grp, 2, (int64_t)w.n0 + wc * 64, p.N, tc * KSUM_PARTS);
     }
+    if constexpr (DEFER) {
+      if (tile_bias) {
+        // the bias as one short MFMA per accumulator block (gemm_impl.h bias_split): group 0 issues them beside group 1's last
+        // multiply segment, group 1 beside group 0's first of the next tile -- in front of an epilogue that outlasts either anyway
+        wait_vmcnt_dyn(bias_young);
+        uint32_t b_lo = braw, b_hi = braw;
+        settle(b_lo, b_hi);
+        if (!p.bias_f32) { b_lo <<= 16; b_hi <<= 16; }
+        swap_halves(b_lo, b_hi);            // b_hi: lanes 0-31 now hold what lanes 32-63 loaded (columns 32-63)
+        const bool lower = lane < 32;
+        const bf16x4v bfr0 = bias_split(__uint_as_float(b_lo), lower), bfr1 = bias_split(__uint_as_float(b_hi), lower);
+        const bf16x4v ones = bias_ones(lower);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(bfr0, ones, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(bfr1, ones, acc[1][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (defer_this) { pend = true; pm0 = w.m0; pn0 = w.n0; continue; }   // slabs 1-3 ride in the next tile's first K-tile; the groups stay skewed
+    }
     stamp_tile(it, 0);
     if constexpr (LEAN && !TAIL) wait_vmcnt<0>();   // every DMA piece has landed before the first store is issued (see after_epi)
     if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align: both groups run the epilogue together
+    aligned_now = true;
     __builtin_amdgcn_sched_barrier(0);
     stamp_tile(it, 1);
     int lane_e = lane;
@@ -609,9 +784,9 @@ void gemm_phase_kernel(GemmKArgs p) {
             (reinterpret_cast<uint64_t*>(p.workspace) + 640 + (wave >> 2) * 16)[idx] = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
         };
-        reg_epilogue<4, EPI>(p, acc, lane_e, w.m0 + grp * 128, w.n0 + wc * 64, w.split, st);
+        reg_epilogue<4, EPI, decltype(st), DEFER>(p, acc, lane_e, w.m0 + grp * 128, w.n0 + wc * 64, w.split, st);
       } else {
-        reg_epilogue<4, EPI>(p, acc, lane_e, w.m0 + grp * 128, w.n0 + wc * 64, w.split);
+        reg_epilogue<4, EPI, NoStamp, DEFER>(p, acc, lane_e, w.m0 + grp * 128, w.n0 + wc * 64, w.split);
       }
     }
     if constexpr ((DBG & 64) != 0) __builtin_amdgcn_sched_barrier(0);

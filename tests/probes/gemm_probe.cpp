@@ -218,7 +218,7 @@ int main(int argc, char** argv) {
   std::vector<int> variants = {0, 2, 4, 5, 6};
   int iters = 7, rounds = 3; bool check_only = false, no_check = false, full_check = false, stamps = false; int64_t stamps_k = 1024; std::string which = "model";
   std::vector<int> stamp_variants = {89};
-  int hog = 0;
+  int hog = 0, only = -1;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--variants") && i + 1 < argc) variants = parse_list(argv[++i]);
     else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
@@ -230,6 +230,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--stamp-variants") && i + 1 < argc) stamp_variants = parse_list(argv[++i]);
     else if (!strcmp(argv[i], "--hog") && i + 1 < argc) hog = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--cases") && i + 1 < argc) which = argv[++i];
+    else if (!strcmp(argv[i], "--only") && i + 1 < argc) only = atoi(argv[++i]);     // run case number `only` of the group alone
   }
   if (stamps) {   // timeline of the phase kernel (variants 89 / 97 / 98): s_memtime at the 8 segment edges of the first 32 K-tiles, waves 0 and 4
     Case c{"stamps", 20832, 4096, stamps_k, 0, 0, "plain", 1};
@@ -363,6 +364,19 @@ int main(int argc, char** argv) {
       {"K768 NN", 88256, 3072, 768, 0, 0, "plain", 1},
       {"K4096 NN", 20832, 1024, 4096, 0, 0, "plain", 1},
     };
+  } else if (which == "defer") {   // round 6: one case per (layout, P class, bias / pre-activation) of the deferred-epilogue builds
+    cases = {
+      {"NN erf", 20832, 1024, 768, 0, 0, "gelu_erf", 1},
+      {"NN bias", 20832, 1024, 768, 0, 0, "bias", 1},
+      {"NN plain", 20832, 1024, 768, 0, 0, "plain", 1},
+      {"NN tanh+pre", 20832, 1024, 1024, 0, 0, "gelu_tanh_preact", 1},
+      {"NN erf+pre", 20832, 1024, 1024, 0, 0, "gelu_erf_preact", 1},
+      {"NT erf", 20832, 1024, 768, 0, 1, "gelu_erf", 1},
+      {"NT tanh+pre", 20832, 2048, 1024, 0, 1, "gelu_tanh_preact", 1},
+      {"TN bias", 20736, 1024, 1024, 1, 0, "bias", 1},
+      {"TT plain", 20736, 1024, 1024, 1, 1, "plain", 1},
+      {"NN erf ragged N", 20832, 1088, 768, 0, 0, "gelu_erf", 1},
+    };
   } else if (which == "small") {
     cases = {
       {"trunk fc1 fwd", 20832, 4096, 1024, 0, 1, "gelu_tanh_preact", 1},
@@ -375,6 +389,7 @@ int main(int argc, char** argv) {
     };
   }
   if (sk_override > 0) for (auto& c : cases) if (c.split_k > 1) c.split_k = sk_override;
+  if (only >= 0 && only < (int)cases.size()) cases = {cases[only]};
   // ---- correctness: every (case layout / epilogue, variant) at a reduced M (ragged: not a tile multiple) ----
   if (!no_check) {
     for (const Case& c : cases) {

@@ -2,7 +2,12 @@
 of M0 + nop + DMA, no save / restore -- round 5, worth ~9 % of the phase kernel's main loop).  That is only legal while NO other
 instruction of these kernels reads M0: every gemm_phase_kernel / gemm_ring_kernel in the built library is disassembled and
 checked -- M0 appears only as the destination of the scalar instruction in front of a DMA, and every `global_load_lds_dwordx4` is
-preceded by such a write and the hazard nop."""
+preceded by such a write and the hazard nop.
+
+Round 6 adds the VALU -> VMEM scalar hazard audit (test_no_asm_vmem_reads_a_freshly_reloaded_sgpr): hipcc reloads spilled SGPRs with
+v_readlane_b32 and pads the five wait states a VMEM instruction needs before it may read such a register -- but not for the
+instructions INSIDE an asm statement, which it cannot see.  The first deferred-epilogue build read its bias through a stale base
+register that way (memory faults in every erf-GELU launch).  tests/probes/asm_hazard_audit.py is the same check on a -save-temps file."""
 import os
 import re
 import subprocess
@@ -14,6 +19,11 @@ from tests import kernel_resources as K
 
 LIB = os.path.join(K.ROOT, "dreamvla_amd", "libdvla_hip.so")
 OBJDUMP = os.path.join(K.LLVM, "llvm-objdump")
+
+
+def _is_dma(t):
+    """an LDS-DMA instruction: global_load_lds_dwordx4, or (round 6, the measurement builds on the buffer-descriptor path) buffer_load_dwordx4 ... lds"""
+    return t.startswith("global_load_lds_dwordx4") or (t.startswith("buffer_load_dwordx4") and t.split()[-1] == "lds")
 
 
 def _functions(*needles):
@@ -49,7 +59,7 @@ def test_no_instruction_of_the_phase_kernels_reads_m0():
     assert n_phase >= 33 and n_ring >= 96, (n_phase, n_ring)   # phase: 4 layouts x 8 classes + partial-K-tile build (+ measurement
     lean = 0                                                    # variants); ring: 3 configurations x 4 layouts x 8 classes
     for name, ins in fns.items():
-        dma = [i for i, t in enumerate(ins) if t.startswith("global_load_lds_dwordx4")]
+        dma = [i for i, t in enumerate(ins) if _is_dma(t)]
         assert len(dma) >= (16 if "phase" in name else 4), (name, len(dma))  # phase: prologue 16 + 8 per copy of the K loop
         legacy = any(re.match(r"s_mov_b32 s\d+, m0", t) for t in ins)      # the round-4 issue code saves and restores M0 (variants 40 / 41)
         if legacy:
@@ -123,3 +133,54 @@ def test_attention_fragment_reads_are_grouped_in_front_of_the_multiplies():
         assert len(runs) >= 6, (name, runs)
         frac = sum(1 for w in runs if w > 0) / len(runs)
         assert frac <= (0.75 if "dq_ring" in name else 0.3), (name, frac, runs)
+
+
+def _sregs(tok):
+    m = re.match(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"s(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def _valu_sgpr_hazards(ins):
+    """(index, instruction, states, registers) of every VMEM instruction that reads an SGPR written by v_readlane_b32 /
+    v_readfirstlane_b32 fewer than five wait states earlier (straight-line code: a branch empties the window)"""
+    bad, recent = [], []
+    for i, t in enumerate(ins):
+        parts = t.replace(",", " ").split()
+        op, args = parts[0], parts[1:]
+        if op.startswith("s_cbranch") or op.startswith("s_branch") or op.startswith("s_setpc") or op.startswith("s_endpgm"):
+            recent = []
+            continue
+        if op.startswith(("buffer_", "global_", "flat_", "scratch_")):
+            used = set()
+            for a in args:
+                used |= _sregs(a)
+            for age, regs in recent:
+                if age < 5 and (used & regs):
+                    bad.append((i, t, age, sorted(used & regs)))
+        n = int(args[0], 0) + 1 if op == "s_nop" else 1
+        recent = [(age + n, regs) for age, regs in recent if age + n < 8]
+        if op in ("v_readlane_b32", "v_readfirstlane_b32"):
+            recent.append((0, _sregs(args[0])))
+    return bad
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="library / llvm-objdump not available")
+def test_no_asm_vmem_reads_a_freshly_reloaded_sgpr():
+    """every kernel that issues memory instructions from inline asm (the GEMM DMA kernels, the attention DMA kernels): no VMEM
+    instruction reads an SGPR within five wait states of a VALU write of it"""
+    fns = _functions("gemm_phase_kernel", "gemm_ring_kernel", *ATTN_DMA)
+    assert len(fns) > 130, len(fns)
+    found = {name: h for name, ins in fns.items() for h in [_valu_sgpr_hazards(ins)] if h}
+    assert not found, {k: v[:2] for k, v in list(found.items())[:4]}
+
+
+def test_the_hazard_scan_sees_a_planted_hazard():
+    ins = ["v_readlane_b32 s26, v212, 37", "v_readlane_b32 s27, v212, 38", "global_load_ushort v1, v1, s[26:27]"]
+    assert len(_valu_sgpr_hazards(ins)) == 2
+    ins = ["v_readlane_b32 s26, v212, 37", "v_readlane_b32 s27, v212, 38", "s_nop 4", "global_load_ushort v1, v1, s[26:27]"]
+    assert not _valu_sgpr_hazards(ins)
+    ins = ["v_readfirstlane_b32 s4, v0", "s_add_u32 m0, s17, 0", "s_nop 0", "buffer_load_dwordx4 v199, s[4:7], s46 offen lds"]
+    assert len(_valu_sgpr_hazards(ins)) == 1
