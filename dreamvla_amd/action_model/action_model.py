@@ -110,9 +110,10 @@ class ActionModel(nn.Module):
                 st["table"] = torch.tensor(ptrs, dtype=torch.int64, device=cond.device).view(len(net.blocks), 8)
                 st["ptrs"], st["keep"] = ptrs, ws
             capturing = torch.cuda.is_current_stream_capturing()
-            # eager calls compare the workspace's timeout count before and after THEIR launch (a replayed graph may have timed out
-            # on this workspace since the last eager call: that is the engine's business -- RolloutEngine.step -- not this call's)
-            timeouts_before = None if capturing else ops.dit_team_status(st["ws"])[0]
+            # eager calls compare the workspace's timeout count after THEIR launch with the last count seen on this workspace
+            # (st["timeouts"]: kept current by the previous eager call and by RolloutEngine, which reads the count after every
+            # replay of a graph that contains the kernel) -- one host read per eager call, not two (round-5 ADVICE)
+            timeouts_before = None if capturing else st["timeouts"]
             cond_tab = (z_emb.unsqueeze(0) + t_emb.view(t_emb.shape[0], 1, 1, -1)).contiguous()    # z_emb + t_emb[j], all steps
             sh = lambda w: ops.shadow(w).contiguous()
             out = ops.dit_team_sample(st["table"], len(net.blocks), hidden, net.num_heads, sh(net.x_embedder.linear.weight),

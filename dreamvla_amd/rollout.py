@@ -100,6 +100,13 @@ class RolloutEngine:
         self._decode_g = _Graphed(self._decode_eager, warmup_decodes) if self.use_graph else None
         self._encode_g = _Graphed(self._encode_eager, warmup_decodes) if self.use_graph else None
         self.team_fallbacks = 0                 # times the one-XCD sampler kernel timed out and the engine fell back (see step)
+        # The persistent sampler kernel (dvla_dit_sample) is a property of THIS engine's decode path (round-5 ADVICE): whether the
+        # engine allows it (`_team_allowed`: False after a timeout), whether its decode -- eager, or the captured graph -- launched
+        # it (`_team_in_decode`, recorded when the decode last ran in Python, i.e. at every eager call and at capture time); the
+        # kernel's own timeout count (workspace word 33) is read behind every decode that contains it (`_team_timed_out`).
+        self._team_allowed = True
+        self._team_in_decode = False
+        self._team_seen = None
 
     # ------------------------------------------------------------------------------------------------------------
     def reset(self, mask=None):
@@ -165,9 +172,20 @@ class RolloutEngine:
 
     # ------------------------------------------------------------------------------------------------------------
     def _decode_eager(self, tokens, noise, sel):
-        with ops.forward_split_k():       # the trunk at one episode: 930 rows, K = 4096 in the MLP down-projection
-            out = self.model.decode_tokens(tokens, mode="test", test_noise=noise if self.needs_noise else None,
-                                           test_select=None if self.sample_all else sel)
+        am = getattr(self.model, "action_model", None)
+        shared = getattr(am, "team_sampler", True) if am is not None else True
+        before = getattr(am, "team_launches", 0) if am is not None else 0
+        if am is not None:
+            am.team_sampler = bool(shared) and self._team_allowed      # this engine's choice for the duration of ITS decode only
+        try:
+            with ops.forward_split_k():       # the trunk at one episode: 930 rows, K = 4096 in the MLP down-projection
+                out = self.model.decode_tokens(tokens, mode="test", test_noise=noise if self.needs_noise else None,
+                                               test_select=None if self.sample_all else sel)
+        finally:
+            if am is not None:
+                am.team_sampler = shared
+                # (an eager call, or the capture of this engine's graph: what it launched is what its replays launch)
+                self._team_in_decode = getattr(am, "team_launches", 0) > before
         return out[0], out[1]
 
     @torch.no_grad()
@@ -233,13 +251,15 @@ class RolloutEngine:
             if not self.sample_all and noise.shape[0] == B * S and S > 1:
                 noise = noise.view(B, S, *noise.shape[1:])[bi, sel]
         action, arm, grip = self._actions(*self._decode(self.tokens, noise, sel), sel, bi)
-        if self._team_sampler_in_use() and not bool(torch.isfinite(action).all()):
+        if self._team_sampler_in_use() and self._team_timed_out():
             # The one-XCD sampler kernel (dvla_dit_sample) bounds every wait; on a GPU that other work keeps busy its 32 workgroups
             # may not be co-resident, a wait times out and the kernel returns NaN by design.  Under hipGraph replay no Python runs
-            # inside the sampler, so the check is HERE, on the action about to be handed to the environment (round-4 ADVICE: a NaN
-            # arm command with gripper -1 went straight out).  It costs one host read of 7 values per step, on the single-episode
-            # path only -- whose caller reads the action next anyway.  Recovery: the launch-by-launch sampler (same arithmetic),
-            # decode graph re-captured, this step's action recomputed from the same tokens and noise.
+            # inside the sampler, so the check is HERE, before the action is handed to the environment (round-4 ADVICE: a NaN arm
+            # command with gripper -1 went straight out): the kernel's own timeout count (workspace word 33, one 4-byte host read
+            # per step on the single-episode path, whose caller reads the action next anyway) against the count this engine last
+            # saw -- not "the action is not finite" (round-5 ADVICE: a NaN from a bad observation or bad weights is not a sampler
+            # timeout and must not switch the sampler).  Recovery: the launch-by-launch sampler (same arithmetic) for THIS engine,
+            # its decode graph re-captured, this step's action recomputed from the same tokens and noise.
             self._team_fallback()
             action, arm, grip = self._actions(*self._decode(self.tokens, noise, sel), sel, bi)
         return action, arm, grip
@@ -257,17 +277,99 @@ class RolloutEngine:
         return torch.cat((a, (g - 0.5) * 2), dim=-1), arm, grip
 
     def _team_sampler_in_use(self):
-        """did the decode path (eager, or the captured graph) launch the persistent sampler kernel?  (`ActionModel.sample_ddim_cfg`
-        counts its team launches; the shapes that take it are decided there: one episode, DiT-B)"""
+        """did THIS engine's decode path (eager, or its captured graph) launch the persistent sampler kernel?  Recorded by
+        `_decode_eager` whenever the decode runs in Python (`ActionModel.sample_ddim_cfg` counts its team launches; the shapes
+        that take the kernel are decided there: one episode, DiT-B)"""
+        return bool(self.needs_noise and self._team_in_decode)
+
+    def _team_status(self):
+        """the sampler workspace's cache entry of the action model (None before the first team launch)"""
         am = getattr(self.model, "action_model", None)
-        return bool(self.needs_noise and am is not None and getattr(am, "team_sampler", True) and getattr(am, "team_launches", 0) > 0)
+        for k, v in (getattr(am, "_fast_tables", None) or {}).items():
+            if isinstance(k, tuple) and k and k[0] == "team" and k[1] == str(self.device):
+                return v
+        return None
+
+    def _team_timed_out(self):
+        """has the kernel's timeout count (word 33 of its workspace: include/dvla.h) moved since this engine last looked?"""
+        st = self._team_status()
+        if st is None:
+            return False
+        # st["timeouts"] = the count last seen on this workspace by ANYONE (this engine, another engine on the same model, an eager
+        # sampler call): the host drives one launch / replay at a time and looks right behind it, so whatever the count moved by
+        # since the last look belongs to the replay that has just run
+        now = ops.dit_team_status(st["ws"])[0]
+        seen = st["timeouts"]
+        self._team_seen = st["timeouts"] = now
+        return now != seen
 
     def _team_fallback(self):
-        am = self.model.action_model
-        am.team_sampler = False
-        am.team_launches = 0
+        self._team_allowed = False
+        self._team_in_decode = False
         self.team_fallbacks += 1
         if self.use_graph:                       # the captured decode contains the team kernel: warm up and capture again
             self._decode_g = _Graphed(self._decode_eager, self.warmup_decodes)
         warnings.warn("RolloutEngine: dvla_dit_sample timed out (the GPU is shared or busy: its 32 workgroups were not co-resident); "
                       "this engine now runs the launch-by-launch sampler", RuntimeWarning)
+
+
+class TemporalEnsembler:
+    """The LIBERO wrapper's temporal ensembling of the action chunk (utils/eval_utils_libero.py:160-176, `use_ensembling`), batched
+    over the engine's episodes and kept on the device.
+
+    The reference keeps `all_time_actions` (max_steps, max_steps + action_pred_steps, 7), writes the chunk predicted at control step
+    t for the selected window position -- (action_pred_steps, 7): arm (6) and the RAW gripper output -- into row t, columns
+    t .. t + action_pred_steps - 1, takes column t of every row whose 7 values are all non-zero (the predictions made for time t at
+    steps t - action_pred_steps + 1 .. t, oldest first), averages them with weights exp(-k i) / sum (i = 0 for the OLDEST, k =
+    `ensembling_temp`), thresholds the averaged gripper value at 0.5 and maps it to {-1, +1}.  Only the last action_pred_steps rows can
+    be populated at column t, so a ring of that many chunks per episode holds the same information as the (max_steps, ...) table.
+
+    `ens = TemporalEnsembler(B, action_pred_steps, temp, device)`; per control step, with sample="newest" outputs of
+    `RolloutEngine.step`: `action = ens(arm[:, 0], grip[:, 0])` -> (B, 7) float32; `ens.reset(mask)` with the engine's reset."""
+
+    def __init__(self, episodes, action_pred_steps, temp, device):
+        self.B, self.P, self.k = int(episodes), int(action_pred_steps), float(temp)
+        self.device = device
+        # ring[b, j] = the chunk predicted j control steps ago (j = 0: this step); age[b] = chunks stored so far (capped at P)
+        self.ring = torch.zeros(self.B, self.P, self.P, 7, dtype=torch.float32, device=device)
+        self.age = torch.zeros(self.B, dtype=torch.long, device=device)
+        # weights[n, i]: the reference's float64 numpy weights for n populated rows (:170-172), i = 0 the oldest; row 0 unused
+        import numpy as np
+        tab = np.zeros((self.P + 1, self.P), dtype=np.float64)
+        for n in range(1, self.P + 1):
+            e = np.exp(-self.k * np.arange(n))
+            tab[n, :n] = e / e.sum()
+        self.weights = torch.from_numpy(tab).to(device)
+
+    def reset(self, mask=None):
+        if mask is None:
+            self.ring.zero_()
+            self.age.zero_()
+        else:
+            m = torch.as_tensor(mask, dtype=torch.bool, device=self.device)
+            self.ring[m] = 0
+            self.age[m] = 0
+
+    @torch.no_grad()
+    def __call__(self, arm, grip):
+        """arm (B, action_pred_steps, 6), grip (B, action_pred_steps, 1) of the executed window position -> (B, 7)"""
+        B, P = self.B, self.P
+        chunk = torch.cat((arm.float(), grip.float()), dim=-1).to(self.device)                  # eval_utils_libero.py:165
+        self.ring = torch.roll(self.ring, 1, dims=1)
+        self.ring[:, 0] = chunk
+        self.age = torch.clamp(self.age + 1, max=P)
+        # the prediction for NOW made j steps ago is element j of that chunk; rows older than the episode are absent, and the reference
+        # also drops a row whose seven values are not all non-zero (`actions_populated`, :168-169)
+        j = torch.arange(P, device=self.device)
+        cand = self.ring[:, j, j]                                                               # (B, P, 7), newest first
+        have = (j.unsqueeze(0) < self.age.unsqueeze(1)) & (cand != 0).all(dim=-1)
+        # weights exp(-k i) with i counted from the OLDEST populated row (:171): rank among the populated ones, oldest = 0
+        have_o = torch.flip(have, dims=[1])                                                     # oldest first
+        order = (have_o.long().cumsum(1) - 1).clamp_min(0)
+        n = have_o.long().sum(1)
+        w = self.weights[n.unsqueeze(1), order] * have_o                                        # float64, zero where no row
+        # (the reference multiplies float32 actions by float64 weights: product and sum in float64, oldest row first; the absent
+        #  rows add exact zeros)
+        avg = (torch.flip(cand, dims=[1]).double() * w.unsqueeze(-1)).sum(dim=1)
+        g = (avg[:, 6:] > 0.5).to(torch.float32)                                                # :174-175
+        return torch.cat((avg[:, :6].to(torch.float32), (g - 0.5) * 2), dim=-1)

@@ -87,3 +87,55 @@ def test_forward_split_needs_an_epilogue_the_reduction_pass_can_run():
     assert not ops._fwd_split_epilogue_ok(torch.empty(930, 1024), bias, res, 1024)   # fp32 output
     assert not ops._fwd_split_epilogue_ok(torch.empty(930, 1020, dtype=BF), None, None, 1020)
     assert not ops._fwd_split_epilogue_ok(out, torch.empty(1032, dtype=BF)[1:1025], res, 1024)   # bias at a 2-byte offset
+
+
+def _libero_ensembling_oracle(chunks, temp, max_steps):
+    """utils/eval_utils_libero.py:66-73 + 160-176, restated for ONE episode: the (max_steps, max_steps + P, 7) table, the chunk of
+    control step t into row t / columns t .. t + P - 1, column t of every row with seven non-zero values, numpy float64 weights
+    exp(-temp i) / sum (oldest row first), float64 weighted sum, gripper > 0.5 -> +-1.  Returns the executed action per step."""
+    import numpy as np
+    P = chunks[0].shape[0]
+    table = torch.zeros(max_steps, max_steps + P, 7)
+    out = []
+    for t, chunk in enumerate(chunks):
+        table[t:t + 1, t:t + P] = chunk.unsqueeze(0)
+        col = table[:, t]
+        col = col[torch.all(col != 0, axis=1)]
+        w = np.exp(-temp * np.arange(len(col)))
+        w = torch.from_numpy(w / w.sum()).unsqueeze(dim=1)
+        a = (col * w).sum(dim=0, keepdim=True)
+        a = torch.concat((a[:, :6], a[:, 6:] > 0.5), dim=-1)
+        a[:, -1] = (a[:, -1] - 0.5) * 2
+        out.append(a[-1].clone())
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize("P,temp", [(3, 0.01), (5, 0.5), (1, 0.01)])
+def test_temporal_ensembler_matches_the_libero_wrapper(P, temp):
+    """dreamvla_amd.rollout.TemporalEnsembler (a ring of the last P chunks per episode, batched) against the restated table of
+    eval_utils_libero.py: three episodes in lock-step, one reset mid-way, a chunk with a zero element (the reference drops that
+    row), 14 control steps -- the float64 averages bit for bit, cast to float32"""
+    from dreamvla_amd.rollout import TemporalEnsembler
+    g = torch.Generator().manual_seed(5)
+    B, T = 3, 14
+    arm = torch.randn(T, B, P, 6, generator=g)
+    grip = torch.rand(T, B, P, 1, generator=g)
+    arm[4, 1, :, 2] = 0.0                     # episode 1, step 4: a zero element in every row of the chunk -> `actions_populated` drops it
+    ens = TemporalEnsembler(B, P, temp, torch.device("cpu"))
+    got = []
+    for t in range(T):
+        if t == 8:
+            ens.reset(torch.tensor([False, False, True]))
+        got.append(ens(arm[t], grip[t]))
+    got = torch.stack(got)                    # (T, B, 7)
+    for b in range(B):
+        chunks = [torch.cat((arm[t, b], grip[t, b]), dim=-1) for t in range(T)]
+        if b == 2:                             # the reset episode: two independent runs of the wrapper
+            want = torch.cat((_libero_ensembling_oracle(chunks[:8], temp, 20), _libero_ensembling_oracle(chunks[8:], temp, 20)))
+        else:
+            want = _libero_ensembling_oracle(chunks, temp, 20)
+        if b == 1 and P > 1:
+            # step 4's chunk is dropped wherever it would be used (columns 4 .. 4 + P - 1); at step 4 itself it is the only candidate
+            # besides older ones -- with P = 1 nothing is left (the reference would divide by an empty sum): not part of this case
+            pass
+        assert torch.equal(got[:, b].to(torch.float32), want.to(torch.float32)), (b, (got[:, b] - want).abs().max())
