@@ -117,6 +117,115 @@ def eager_rocm_baseline(heads, S, B, steps=5):
     return gpu_eager_baseline.run(heads, B, steps, S=S)
 
 
+def reference_loop_loss_block(out, batch, lab, S, use_dit_head):
+    """What the reference's OWN training loop does with the forward's outputs every step (utils/train_utils.py:158-596), for the
+    integration-levels leg: the loss block as plain ATen ops in the model dtype (`dreamvla_amd.losses.calvin_losses(fused=False)`:
+    the formulation tests/test_losses_golden.py pins against the real loop's values and gradients) AND the loop's per-step host work
+    -- the four example images (:198-213: un-patchify the WHOLE prediction / label, take sample 0, `.detach().cpu().float().numpy()`,
+    min-max normalise on the host), the four depth examples when the depth head is on (:382-396), and `loss.item()` (:596)."""
+    import numpy as np
+    from dreamvla_amd import losses
+    total, parts = losses.calvin_losses(out, batch, sequence_length=S, use_dit_head=use_dit_head, label_action=lab, fused=False,
+                                        compute_dtype=out[2].dtype if out[2] is not None else torch.bfloat16)
+    image_pred, depth_pred = out[2], out[6]
+    bs = batch["image_primary"].shape[0]
+    lo, hi = 3, 3 + S
+
+    def example(t):                                             # (B', P, 3, H, W) -> sample 0 / step 0 on the host, min-max normalised
+        e = t[0][0].permute(1, 2, 0).detach().cpu().float().numpy()
+        return (e - e.min()) / (e.max() - e.min())
+    examples = []
+    if image_pred is not None:
+        ip = image_pred.reshape(bs, S, *image_pred.shape[1:]).reshape(-1, *image_pred.shape[1:])
+        for v, key in ((0, "image_primary"), (1, "image_wrist")):
+            examples.append(example(losses.unpatchify(ip[:, v])))
+            lab_img = losses.normalize_patchfied_image(losses.patchify(batch[key][:, lo:hi].flatten(0, 1), 16))
+            examples.append(example(losses.unpatchify(lab_img.unsqueeze(1))))
+    if depth_pred is not None:
+        dp = depth_pred.reshape(bs, S, *depth_pred.shape[1:]).reshape(-1, *depth_pred.shape[1:])
+        for v, key in ((0, "depth_primary"), (1, "depth_wrist")):
+            examples.append(example(losses.unpatchify(dp[:, v])))
+            examples.append(example(batch[key][:, lo:hi].flatten(0, 1).unsqueeze(1)))
+    loss_value = total.item()                                   # :596 mv_avg_loss.append(loss.item())
+    return total, parts, (loss_value, len(examples))
+
+
+def integration_levels(args, cfg, S, B, dev, headline_samples_per_s, steps=5, warmup=2):
+    """Round-5 VERDICT #6: what a maintainer gets at each level of adoption, same box, same batch, N = 1, `steps` timed steps each:
+      level 0 "untouched loop": only the import is swapped -- the HIP module inside the reference's own
+              `DistributedDataParallel(find_unused_parameters=True)` (train.py:173), its own loss block incl. the per-step example-image
+              copies and `.item()` reads (utils/train_utils.py:158-596, 726), `clip_grad_norm_` + `torch.optim.AdamW` as train.py:174
+              builds it (no `fused=`);
+      level 1 "+ HIP loss block": `dreamvla_amd.losses.calvin_losses` instead of the loop's loss block (one edit), no host reads inside
+              the step;
+      level 2 "+ reducer + flat optimizer" = the headline configuration (GradBucketReducer + FlatAdamW): the timed region's number."""
+    import socket
+    import torch.distributed as dist
+    from dreamvla_amd import losses
+    from dreamvla_amd.dreamvla_model import DreamVLA
+    from dreamvla_amd.synthetic import synthetic_batch
+    own_group = not dist.is_initialized()
+    if own_group:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        BF = torch.bfloat16
+        torch.manual_seed(1234)
+        model = DreamVLA(clip_device="cpu", vit_checkpoint_path=None, **cfg).bfloat16()
+        model.clip_model.requires_grad_(False)
+        model.vision_encoder.requires_grad_(False)
+        model = model.to(dev)
+        model._init_model_type()
+        model.train()
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)      # train.py:173
+        opt = torch.optim.AdamW([p for p in ddp.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-4)            # train.py:174
+        b = synthetic_batch(B, S, window=S + 3, seed=1234, heads=label_heads(args.heads))
+        b["actions"][..., 6:] = (b["actions"][..., 6:] > 0.5).float()
+        batch = {k: (v.to(dev, BF) if torch.is_floating_point(v) else v.to(dev)) for k, v in b.items()}
+        lab = losses.label_actions(batch["actions"], S, 3)
+        inputs = (batch["image_primary"][:, :S].contiguous(), batch["image_wrist"][:, :S].contiguous(),
+                  batch["state"][:, :S].contiguous(), batch["text_token"][:, :S].contiguous())
+
+        def step(level):
+            out = ddp(*inputs, action=batch["actions"][:, :S], action_label=lab, mode="train")
+            if level == 0:
+                total, parts, _ = reference_loop_loss_block(out, batch, lab, S, cfg["use_dit_head"])
+            else:
+                total, parts = losses.calvin_losses(out, batch, sequence_length=S, use_dit_head=cfg["use_dit_head"], label_action=lab)
+            total.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)                                                         # :600
+            opt.step()
+            opt.zero_grad()
+            if level == 0:                       # :726 t.set_postfix(...): nine .item() reads per step
+                _ = [float(x) for x in (total, *(parts[k] for k in ("image", "depth", "arm_action", "gripper_action", "trajectory", "dino", "sam")))]
+            return total
+        res = {}
+        for level, name in ((0, "untouched_loop"), (1, "hip_loss_block")):
+            for _ in range(warmup):
+                step(level)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(level)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            res[name] = {"samples_per_s": B / dt, "ms_per_step": dt * 1e3}
+        res["reducer_and_flat_optimizer"] = {"samples_per_s": headline_samples_per_s, "ms_per_step": B / headline_samples_per_s * 1e3,
+                                             "note": "the timed region of this line"}
+        res["what"] = ("level 0: the HIP module in train.py's own DDP(find_unused_parameters=True) + the loop's ATen loss block with its per-step "
+                       "example-image copies and .item() reads (utils/train_utils.py:158-596, 726) + clip_grad_norm_ + torch.optim.AdamW "
+                       "(train.py:174, unfused); level 1: + dreamvla_amd.losses.calvin_losses; level 2: + GradBucketReducer + FlatAdamW")
+        res["steps"] = steps
+        return res
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 def loss_parity(model, cfg, batch, lab, inputs, S, B, dev):
     """Cross-check of the number the timed steps print as `loss` (round-3 VERDICT weak #3: it was compared with nothing).
     After the timed region, with the weights as the optimizer left them: the loss of the HIP module in eval() mode (dropout
@@ -189,7 +298,7 @@ def other_config(name, heads, S, B, accum, extra_cfg, loss_kw, batch_kw, dev, st
     """One of the configurations BASELINE.json names beside the headline one, timed like the headline (same step: forward, loss
     block, backward, reducer, clip + AdamW; `accum` > 1: utils/train_utils.py:588-607's accumulation, all but the last pass under
     reducer.no_sync(), B samples per pass).  The GEMM configurations come from the committed plan of this configuration
-    (profiles/r05_gemm_plan_<name>.json, written by `bench.py --save-other-plans` on the GPU) -- no tuner trials; without the
+    (profiles/r05_gemm_plan_<name>.json, written by `DVLA_SAVE_OTHER_PLANS=1 python bench.py` on the GPU) -- no tuner trials; without the
     file the tuner runs 12 untimed steps first."""
     from dreamvla_amd import losses, ops
     from dreamvla_amd.ddp import GradBucketReducer
@@ -344,6 +453,8 @@ def main():
     ap.add_argument("--no-loss-parity", action="store_true",
                     help="skip the loss cross-check (after the timed region: the loss of the HIP module, dropout off, against the "
                          "oracle restatement run in fp32 and in bf16 on this GPU with the same weights / batch / DiT noise; ~5 s)")
+    ap.add_argument("--no-integration-levels", action="store_true",
+                    help="skip the integration-levels leg (untouched reference loop / + HIP loss block / headline: N = 1 only, 5 steps each)")
     ap.add_argument("--no-rollout", action="store_true",
                     help="skip the closed-loop rollout leg (BASELINE configs[4]: 64 episodes in lock-step through the hipGraph-"
                          "captured engine, S = 10, DDIM-10; rank 0, N = 1 only; ~15 s after the timed region)")
@@ -557,15 +668,26 @@ def main():
     eager = None
     grad_exchange = "torch DDP" if reducer is None else "GradBucketReducer (flat bf16 buckets, async all-reduce)"
     optimizer_name = ("FlatAdamW (HIP: dvla_sumsq_bf16 + dvla_adamw_bf16 on flat buffers)" if flat_opt is not None
-                      else "clip_grad_norm_ + torch.optim.AdamW(fused)")
+                      else "clip_grad_norm_ + torch.optim.AdamW (train.py:174 as written: no fused=)" if args.torch_ddp
+                      else "clip_grad_norm_ + torch.optim.AdamW(fused=True)")
     if rank == 0 and world == 1 and not args.no_eager_baseline:
         try:
-            del model, ddp_model, reducer, flat_opt, opt, params
+            model = ddp_model = reducer = flat_opt = opt = params = None
             torch.cuda.empty_cache()
             eager = eager_rocm_baseline(args.heads, S, B)
             eager["ours_over_eager"] = value / eager["value"]
         except Exception as e:  # noqa: BLE001
             eager = {"value": None, "unit": "samples/s", "sample": f"failed: {e!r}"}
+
+    levels = None
+    if rank == 0 and world == 1 and not args.no_integration_levels and not args.torch_ddp:
+        try:
+            model = ddp_model = reducer = flat_opt = opt = params = None      # (the timed objects: loss_parity above was their last user)
+            torch.cuda.empty_cache()
+            levels = integration_levels(args, cfg, S, B, dev, value)
+        except Exception as e:  # noqa: BLE001
+            levels = {"failed": repr(e)}
+        torch.cuda.empty_cache()
 
     rollout = None
     if rank == 0 and world == 1 and not args.no_rollout and args.heads == "C":
@@ -608,7 +730,7 @@ def main():
                        "trainable_params_M": n_train / 1e6, "loss": loss_val,
                        "grad_exchange": grad_exchange, "optimizer": optimizer_name},
             "roofline": roofline, "loss_parity": parity, "cpu_baseline": cpu, "eager_rocm_baseline": eager, "rollout": rollout,
-            "other_configs": others, "rccl": rccl,
+            "other_configs": others, "rccl": rccl, "integration_levels": levels,
         }
     if world > 1 or args.torch_ddp:
         # RCCL prints its version banner through C stdio when the group goes away: tear the group down and flush C's buffers FIRST,

@@ -122,7 +122,7 @@ __device__ __forceinline__ void team_wait(const Team& tm) {
     while (__hip_atomic_load(tm.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (++spins > SPIN_LIMIT) {
         *dead = 1;
-        __hip_atomic_store(tm.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tm.status, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // (ordered before this member's leave: team_leave)
         break;
       }
     }
@@ -135,13 +135,16 @@ __device__ __forceinline__ void team_wait(const Team& tm) {
 // longer poisons every later launch on this workspace (round-4 ADVICE; the host compares word 33 with the count it saw last).
 __device__ __forceinline__ void team_leave(unsigned* ctr) {
   if (threadIdx.x == 0) {
-    const unsigned left = __hip_atomic_fetch_add(ctr + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // acq_rel on the leave counter: every member's status store (release, or relaxed + this release) happens-before the LAST leaver's
+    // read of word 32, so a timeout raised late by another member is retired by THIS launch and charged to it -- with relaxed
+    // accesses it could stay in word 32, make the next launch return NaN and be counted there (round-5 ADVICE).  The status word
+    // is taken with an exchange: read and cleared in one step.
+    const unsigned left = __hip_atomic_fetch_add(ctr + 16, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (left == TEAM - 1) {
-      const unsigned st = __hip_atomic_load(ctr + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned st = __hip_atomic_exchange(ctr + 32, 0u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       if (st != 0u) {
         __hip_atomic_store(ctr + 34, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(ctr + 33, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ctr + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(ctr + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel(Args a) {
   if (threadIdx.x == 0) {
     *reinterpret_cast<int*>(dit_lds + DEAD_OFF) = 0;
     a.ctr[64 + tm.rank] = xcc_id();                  // diagnostics: where the team runs (all members on one XCC = the fast case)
-    if (a.inject && tm.rank == 1) __hip_atomic_store(tm.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.inject && tm.rank == 1) __hip_atomic_store(tm.status, 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   const int L = 2 * a.T, R = 2 * a.bs * L;
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(64 * NWAVES) void dit_team_kernel_ahead(Args a) {
   if (threadIdx.x == 0) {
     *reinterpret_cast<int*>(dit_lds + DEAD_OFF) = 0;
     a.ctr[64 + tm.rank] = xcc_id();
-    if (a.inject && tm.rank == 1) __hip_atomic_store(tm.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.inject && tm.rank == 1) __hip_atomic_store(tm.status, 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   const int L = 2 * a.T, R = 2 * a.bs * L;

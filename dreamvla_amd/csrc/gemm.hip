@@ -292,6 +292,13 @@ bool ring_ok(const GemmKArgs& a, int combo) {
   if (a.M < RC::BM || a.N < RC::BN) return false;
   if ((combo & 2) && (a.M % RC::BM != 0)) return false;   // r-contiguous A: whole row panels only
   if ((combo & 1) && (a.N % RC::BN != 0)) return false;
+  // the ring kernels address a DMA piece as a 32-bit byte offset from the tile's origin (round 5): the farthest piece of a tile -- row
+  // BM - 1 of a k-contiguous operand, k row BKS - 1 of an r-contiguous one -- must stay below 4 GiB whatever the leading dimension
+  // (a view into a wider buffer may have a row stride of millions of elements); otherwise the register-staged kernel takes it
+  // (round-5 ADVICE)
+  const int64_t a_far = (int64_t)(((combo & 2) ? RC::BKS : RC::BM) - 1) * a.lda * 2 + 2 * (int64_t)((combo & 2) ? RC::BM : RC::BKS);
+  const int64_t b_far = (int64_t)(((combo & 1) ? RC::BKS : RC::BN) - 1) * a.ldb * 2 + 2 * (int64_t)((combo & 1) ? RC::BN : RC::BKS);
+  if (a_far >= (1ll << 32) || b_far >= (1ll << 32)) return false;
   return true;
 }
 

@@ -126,6 +126,29 @@ def check_gemm(M, N, K, a_trans=False, b_trans=False, bias=False, act="none", re
     return out
 
 
+def check_gemm_wide_stride(variant=7, M=300, N=256, K=128, stride=8_500_000):
+    """round-5 ADVICE: the ring kernels address a DMA piece as a 32-bit byte offset from the tile's origin.  A k-contiguous operand
+    that is a VIEW into a wider buffer (row stride `stride` elements: row 255 of a tile lies 4.3 GB behind row 0) cannot be addressed
+    that way: the dispatcher has to hand the problem to the register-staged kernel (64-bit addressing) -- same values as for a
+    contiguous copy of the operand, `dvla_last_gemm_variant() == 2`."""
+    from dreamvla_amd import ops
+    from dreamvla_amd._lib import load
+    g = torch.Generator().manual_seed(77)
+    A = rnd((M, K), g)
+    B = rnd((N, K), g, 1.0 / math.sqrt(K))
+    big = torch.empty((M - 1) * stride + K, device=DEV, dtype=BF)          # 5.1 GB: only the M x K window is ever touched
+    a_view = torch.as_strided(big, (M, K), (stride, 1))
+    a_view.copy_(A.to(DEV, BF))
+    with torch.no_grad():
+        got = ops.gemm(a_view, B.to(DEV, BF), variant=variant)
+    ran = int(load().dvla_last_gemm_variant())
+    out = [metrics(f"gemm v{variant} forced on a k-contiguous operand with a row stride of {stride} elements", got, A @ B.t(), TOL_FWD)]
+    out.append({"name": f"  ... ran the register-staged kernel (last variant {ran})", "rel_l2": 0.0, "tol": 0.0, "ok": ran == 2})
+    del big
+    torch.cuda.empty_cache()
+    return out
+
+
 def check_gemm_skinny(forced=True, **kw):
     """the few-rows kernel (csrc/gemm_skinny.h: M <= 512, k-contiguous operands -- the shapes of a single-episode control step):
     the same oracle as every other configuration, plus the assertion that it is what ran (forced = variant 11; not forced = the
@@ -868,6 +891,8 @@ def all_checks(quick=False):
         (check_gemm, dict(M=100, N=1024, K=6, bias=True)),
         (check_gemm, dict(M=100, N=64, K=7, b_trans=True, bias=True)),
         (check_gemm, dict(M=257, N=129, K=33)),
+        (check_gemm_wide_stride, dict(variant=7)),
+        (check_gemm_wide_stride, dict(variant=4)),
         # the DiT head's GEMMs at one episode (2 x 10 x 6 = 120 rows, models/action_model/models.py:128-160), the timestep MLP,
         # the output layer (N = 7), the CLIP tower at 77 rows, one-row problems, ragged N / M, fp32 output, pre-activation store
         (check_gemm_skinny, dict(M=120, N=2304, K=768, bias=True)),
