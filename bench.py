@@ -201,7 +201,7 @@ def integration_levels(args, cfg, S, B, dev, headline_samples_per_s, steps=5, wa
             opt.step()
             opt.zero_grad()
             if level == 0:                       # :726 t.set_postfix(...): nine .item() reads per step
-                _ = [float(x) for x in (total, *(parts[k] for k in ("image", "depth", "arm_action", "gripper_action", "trajectory", "dino", "sam")))]
+                _ = [float(x.detach()) for x in (total, *(parts[k] for k in ("image", "depth", "arm_action", "gripper_action", "trajectory", "dino", "sam")))]
             return total
         res = {}
         for level, name in ((0, "untouched_loop"), (1, "hip_loss_block")):
@@ -224,6 +224,8 @@ def integration_levels(args, cfg, S, B, dev, headline_samples_per_s, steps=5, wa
     finally:
         if own_group:
             dist.destroy_process_group()
+            import ctypes
+            ctypes.CDLL(None).fflush(None)      # (RCCL's version banner goes through C stdio: out now, not behind the JSON line)
 
 
 def loss_parity(model, cfg, batch, lab, inputs, S, B, dev):

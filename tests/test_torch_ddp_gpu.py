@@ -112,14 +112,16 @@ def _adamw_reference(init, grads, lr, wd, betas=(0.9, 0.999), eps=1e-8, bias_cor
     return p
 
 
-def _check_adamw_trajectory(traj, param_bits, wd, control):
+def _check_adamw_trajectory(traj, param_bits, wd, control, p_roundings=2):
     """The torch path's UPDATE against float64 AdamW fed the SAME clipped gradients, element by element (round-5 VERDICT weak #1a:
     an update distance of 0.45 between two gradient streams cannot tell a wrong decay or bias-correction term from rounding).
 
     Bound per element after STEPS steps, from the arithmetic torch runs (its multi-tensor AdamW works in the parameter dtype, every
-    in-place op rounding once):  STEPS x (2 u |p| + 8 u x 4 lr),  u = 2^-param_bits the unit roundoff of the parameter dtype
-    (2^-9 bf16, 2^-24 fp32) -- two roundings of the stored parameter per step (decay multiply, addcdiv) and eight roundings on the
-    way to an update of at most ~4 lr (lerp, two ops on the second moment, sqrt, divide, add eps, the scaled quotient, its product).
+    in-place op rounding once):  STEPS x (p_roundings u |p| + 8 u x 4 lr),  u = 2^-param_bits the unit roundoff of the parameter dtype
+    (2^-9 bf16, 2^-24 fp32) -- two roundings of the stored parameter per step (decay multiply, addcdiv; THREE for fp32 parameters,
+    where the decay factor 1 - lr wd is itself rounded to fp32 before the multiply: a relative error of up to u with the SAME sign
+    every step, measured as half of the budget) and eight roundings on the way to an update of at most ~4 lr (lerp, two ops on
+    the second moment, sqrt, divide, add eps, the scaled quotient, its product).
     `control`: a deliberately WRONG reference -- must violate the same bound on a large share of the elements."""
     import numpy as np
     u = 2.0 ** -param_bits
@@ -129,7 +131,7 @@ def _check_adamw_trajectory(traj, param_bits, wd, control):
             assert np.array_equal(tr["final"], tr["init"]), name          # never received a gradient: untouched
             continue
         ref = _adamw_reference(tr["init"], tr["grads"], LR, wd)
-        bound = STEPS * (2 * u * np.maximum(np.abs(tr["init"]), np.abs(ref)) + 8 * u * 4 * LR)
+        bound = STEPS * (p_roundings * u * np.maximum(np.abs(tr["init"]), np.abs(ref)) + 8 * u * 4 * LR)
         ratio = np.abs(tr["final"] - ref) / bound
         worst = max(worst, float(ratio.max()))
         n_el += ratio.size
@@ -255,6 +257,6 @@ def test_torch_ddp_wrapper_in_the_shipped_precision():
     # the optimizer half in fp32 (masters, gradients, moments): float64 AdamW on the gradients DDP delivered, weight decay 1e-2 so
     # that the decay term (lr x wd x |p| = 1e-5 |p| per step) stands well above fp32 rounding -- and a reference WITHOUT the decay
     # must fall out of the bound
-    worst, ctl = _check_adamw_trajectory(got["traj"], param_bits=24, wd=1e-2, control=dict(wd=0.0))
+    worst, ctl = _check_adamw_trajectory(got["traj"], param_bits=24, wd=1e-2, control=dict(wd=0.0), p_roundings=3)
     print(f"torch AdamW (fp32 masters) vs float64 AdamW, same gradients: worst element at {worst:.2f} of the rounding bound; "
           f"control without weight decay: {100 * ctl:.0f} % of the elements outside")
