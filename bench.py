@@ -594,6 +594,9 @@ def main():
                          "buckets_launched_during_backward_last_step": getattr(reducer, "last_early_launches", None),
                          "robust_gemm_schedule": bool(reducer.robust_gemm_schedule),
                          "robust_schedule_switches": getattr(reducer, "robust_switches", 0),
+                         "robust_schedule_cost": {"whole_step_forced_ms": 6.55, "whole_step_forced_rel": 0.048,
+                                                  "expected_at_n_gt_1_rel": 0.024, "under_16_cu_contention_rel": "+0 ... +4 % (default schedule: +53 ... +66 %)",
+                                                  "source": "profiles/r06_gemm_cu_contention.txt (round-6 kernels and plan, 1 GPU, hog proxy)"},
                          "predicted_weak_scaling_efficiency_8gpu": "0.97-0.98 (DESIGN.md section 8)"})
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
