@@ -344,6 +344,9 @@ int main(int argc, char** argv) {
       {"two stores + tanh-GELU", 20832, 4096, 1024, 0, 0, "gelu_tanh_preact", 1},
       {"two stores + erf-GELU", 20832, 4096, 1024, 0, 0, "gelu_erf_preact", 1},
       {"one store + erf-GELU", 20832, 4096, 1024, 0, 0, "gelu_erf", 1},
+      {"one store + residual", 20832, 4096, 1024, 0, 0, "res", 1},
+      {"one store + act' (tanh)", 20832, 4096, 1024, 0, 0, "dact_tanh", 1},
+      {"one store + act' (erf)", 20832, 4096, 1024, 0, 0, "dact_erf", 1},
       {"one store K64", 20832, 4096, 64, 0, 0, "bias", 1},
       {"two stores K64", 20832, 4096, 64, 0, 0, "none_preact", 1},
       {"two stores + tanh-GELU K64", 20832, 4096, 64, 0, 0, "gelu_tanh_preact", 1},
