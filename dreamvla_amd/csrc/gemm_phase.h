@@ -102,6 +102,10 @@ void gemm_phase_kernel(GemmKArgs p) {
   // boundary: no re-align / re-stagger barriers, no drain of the DMA queue.  The bias enters the accumulators as one short MFMA per
   // block in the first K-tile (no bias registers, no adds in the epilogue).
   constexpr bool DEFER = (DBG & 16384) != 0;
+  // ZC (the deferred builds): the first k16-step of a segment's first K-tile multiplies into a literal-zero C operand instead of 128
+  // accumulator registers zeroed by the VALU at every tile top.  (On its own -- the product loop with its two copies, per-tile
+  // accumulators left undefined -- hipcc spills 691 registers around the first-K-tile branches: not a separable piece.)
+  constexpr bool ZC = DEFER;
   static_assert(!(DBG & 32768) || (!TAIL && (DBG & 4096) == 0), "buffer DMA path: lean issue code, whole K-tiles");
   static_assert(!DEFER || (!TAIL && (DBG & (4096 | 8192)) == 0 && PL == 0 && (EPI == EPI_P0 || EPI == EPI_P_ERF || EPI == EPI_P_TANH)),
                 "deferred epilogue: production loop, P classes");
@@ -395,14 +399,14 @@ void gemm_phase_kernel(GemmKArgs p) {
   // -1 ... -3 %; the groups keeping their one-segment skew through the tile boundary -- group 0's epilogue beside group 1's last
   // multiply segment -- -1 ... -2 %: profiles/r05_gemm_placement_probe*.txt, variants 55 / 56 / 71 / 72.)
   int u = 0, ua = 0;   // global K-tile counter of the multiply, and u % 3
-  f32x16 acc[2][4];
+  f32x16 acc_carried[DEFER ? 2 : 1][DEFER ? 4 : 1];      // DEFER: the accumulators live across tile boundaries
   if constexpr (DEFER) {     // (defined once: the first K-tile of every segment overwrites them)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc_carried[i][j][r] = 0.f;
   }
   bool pend = false;          // DEFER: slabs 1-3 of the previous tile (origin pm0, pn0) are still in the accumulators
   int pm0 = 0, pn0 = 0;
@@ -419,7 +423,11 @@ void gemm_phase_kernel(GemmKArgs p) {
     const int seg_ns = w.ns;
     const int seg_tv = __builtin_amdgcn_readfirstlane(tail_steps(w));
 
-    if constexpr (!DEFER) {
+    // per tile (dead at the tile top -- with two copies of the K loop anything else costs a register shuffle through scratch); zeroed
+    // here, or (ZC) left undefined: the first K-tile's multiplies take a literal-zero C operand
+    f32x16 acc_tile[DEFER ? 1 : 2][DEFER ? 1 : 4];
+    f32x16 (&acc)[2][4] = *[&]() { if constexpr (DEFER) return &acc_carried; else return &acc_tile; }();
+    if constexpr (!ZC) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -551,7 +559,7 @@ void gemm_phase_kernel(GemmKArgs p) {
       __builtin_amdgcn_s_setprio(1);
       static_for<4>([&](auto ksc) {
         constexpr int ks = decltype(ksc)::value;
-        if constexpr (DEFER && ks == 0) {
+        if constexpr (ZC && ks == 0) {
           if (first) {        // a segment's first K-tile: C = 0 (nothing to zero)
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -631,7 +639,7 @@ void gemm_phase_kernel(GemmKArgs p) {
       __builtin_amdgcn_s_setprio(1);
       static_for<4>([&](auto ksc) {
         constexpr int ks = decltype(ksc)::value;
-        if constexpr (DEFER && ks == 0) {
+        if constexpr (ZC && ks == 0) {
           if (first) {
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
