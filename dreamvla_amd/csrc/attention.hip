@@ -41,6 +41,8 @@ struct AttnKArgs {
   const uint32_t *bits_q, *bits_k;
   const uint8_t* tile_map; int nqt, nkt;
   int has_drop; uint32_t drop_thr; float inv_keep; uint32_t seed_lo, seed_hi;
+  float c1;   // scale * inv_keep, formed on the host: a kernel argument is an SGPR operand, a product formed in the kernel a VGPR
+              // (gfx950 has no scalar float multiply) -- one register the 128-VGPR dQ kernel does not have
   float* lse;
   const bf16_t* dout; int64_t dsb, dst, dsh;
   float* delta;
@@ -150,12 +152,39 @@ __device__ __forceinline__ uint32_t low_mask(int n) { return n >= 32 ? 0xfffffff
 // x where the visibility bit of register r is set, `masked_bits` (a float's bit pattern: 0 or -inf) where it is not.  The bit is
 // sign-extended to a lane mask (v_bfe_i32) and merged with one v_bfi_b32 / v_and_b32: two VALU slots per element, where the
 // compare + conditional move needs an and, a compare, the move and a hazard slot between the last two (round 5; same values)
+// (round 6: the extract is an OPAQUE instruction.  With the builtin, hipcc recognised `x & sext(bit)` in the MASKED_BITS == 0 form -- the
+// three backward kernels -- as a select and put back and + compare + hazard nop + conditional move: 64 issue slots per mixed tile
+// where this function means 32; the forward kernel's -inf form kept the extract + bit-select.)
 template <uint32_t MASKED_BITS>
 __device__ __forceinline__ float vis_select(uint32_t vg, int r, float x) {
   const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vg, (uint32_t)((r & 3) + 8 * (r >> 2)), 1u);     // 0 / ~0
   const uint32_t xi = __builtin_bit_cast(uint32_t, x);
   return __builtin_bit_cast(float, MASKED_BITS ? ((xi & m) | (~m & MASKED_BITS)) : (xi & m));
 }
+// all sixteen registers of a score tile (vg: the lane's visibility word already shifted right by 4 g).
+// The zeroing form (the three backward kernels) is ONE asm statement that updates the sixteen values in place through two scratch
+// registers: hipcc recognised `x & sext(bit)` of the builtin form as a select and put back and + compare + hazard nop + conditional
+// move (64 issue slots per mixed tile where 32 are meant); sixteen separate asm statements cost a guard nop each and, with results
+// apart from their operands, sixteen registers that the 128-register dQ kernel does not have (it spilled Q / dO fragments and
+// reloaded them inside the tile loop, which drains the DMA ring) -- round 6, all three read off the assembly.
+#define DVLA_VIS2(a, b, pa, pb)                                                                           \
+  "v_bfe_i32 %16, %18, " #pa ", 1\n\tv_bfe_i32 %17, %18, " #pb ", 1\n\tv_and_b32 %" #a ", %" #a ", %16\n\tv_and_b32 %" #b ", %" #b ", %17\n\t"
+template <uint32_t MASKED_BITS>
+__device__ __forceinline__ void vis_select16(uint32_t vg, float (&x)[16]) {
+  if (MASKED_BITS == 0u) {
+    uint32_t t0, t1;
+    asm(DVLA_VIS2(0, 1, 0, 1) DVLA_VIS2(2, 3, 2, 3) DVLA_VIS2(4, 5, 8, 9) DVLA_VIS2(6, 7, 10, 11)
+        DVLA_VIS2(8, 9, 16, 17) DVLA_VIS2(10, 11, 18, 19) DVLA_VIS2(12, 13, 24, 25) DVLA_VIS2(14, 15, 26, 27)
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+          "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]),
+          "=&v"(t0), "=&v"(t1)
+        : "v"(vg));
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = vis_select<MASKED_BITS>(vg, r, x[r]);
+  }
+}
+#undef DVLA_VIS2
 constexpr uint32_t NEG_INF_BITS = 0xff800000u;
 
 // The tile flags of a ring kernel's walk, for walks of at most 64 tiles (L <= 2048), as three wave-uniform 64-bit words taken by
@@ -291,7 +320,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
         const uint32_t tk = drop_tilekey(rowkey, (uint32_t)kt);
         const uint32_t dx = drop_rot(tk, (uint32_t)g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? sv[r] * p.inv_keep : 0.f;
+        for (int r = 0; r < 16; ++r) sv[r] = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? sv[r] : 0.f;   // 1 / keep: on the output (inv_l)
       }
       const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
 #pragma unroll
@@ -306,7 +335,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
     kt = ktn;
   }
   if (q_ok) {
-    const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
+    const float inv_l = l_run > 0.f ? p.inv_keep / l_run : 0.f;     // 1 / keep of the dropout rides on 1 / l (1 without dropout)
     store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g, (p.st16 & 1) != 0);
     if (p.lse && g == 0) p.lse[rowid] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
   }
@@ -510,8 +539,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = vis_select<NEG_INF_BITS>(vg, r, sv[r]);
+        vis_select16<NEG_INF_BITS>(vg, sv);
       }
       if (!(DBG & 2)) {
       float mt = sv[0];
@@ -540,7 +568,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         const uint32_t tk = drop_tilekey(rowkey, (uint32_t)kt);
         const uint32_t dx = drop_rot(tk, (uint32_t)g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? sv[r] * p.inv_keep : 0.f;
+        for (int r = 0; r < 16; ++r) sv[r] = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? sv[r] : 0.f;   // 1 / keep: on the output (inv_l)
       }
       if (DBG & 4) {
         const bf16x8 pf0 = pack_frag(sv), pf1 = pack_frag(sv + 8);
@@ -565,7 +593,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     kt = next_needed(kt + 1);
   }
   if (q_ok) {
-    const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
+    const float inv_l = l_run > 0.f ? p.inv_keep / l_run : 0.f;     // 1 / keep of the dropout rides on 1 / l (1 without dropout)
     store_token(p.o + (int64_t)b * p.osb + (int64_t)q * p.ost + (int64_t)h * p.osh, oacc, inv_l, g, (p.st16 & 1) != 0);
     if (p.lse && g == 0) p.lse[rowid] = l_run > 0.f ? (m_run + log2f(l_run)) * LN2 : INFINITY;
   }
@@ -628,7 +656,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
   }
   const int rowid = (b * p.H + h) * p.Lq + q;
   const float lse2 = q_ok ? p.lse[rowid] * LOG2E : INFINITY;
-  const float dlt = q_ok ? p.delta[rowid] : 0.f;
+  const float dlt = q_ok ? p.delta[rowid] * p.scale : 0.f;       // delta and dP enter dS already scaled: dS = P (c1 dP' - scale delta),
+  const float c1 = p.c1;                                          // c1 = scale / keep, dP' = the kept dP
   uint32_t rowkey = 0;
   if (p.has_drop) rowkey = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)rowid);
   f32x16 dqacc[2] = {zero16(), zero16()};
@@ -680,16 +709,20 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(AttnKArgs p) {
       for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(sacc[r], scale_log2, -lse2));
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = vis_select<0u>(vg, r, ds[r]);
+        vis_select16<0u>(vg, ds);
       }
+      // dS = P (c1 dP' - dlt), dlt = scale * delta, c1 = scale / keep, dP' = the kept dP: scale and 1 / keep cost nothing here.
+      // (The dropout test stays INSIDE the element loop in this kernel: hipcc then keeps sixteen small basic blocks -- a scalar test
+      // and a branch per element, ~3 issue slots each -- but hoisted around the loop, as in the dK/dV kernel, the straight-line
+      // schedule needs more than the 128 registers of four waves per SIMD and reloads Q / dO fragments from scratch inside the
+      // tile loop, which drains the DMA ring (round 6, measured in the assembly: 6 reloads per tile).)
       uint32_t tk = 0u, dx = 0u;   // one hash per (row, tile), one 24-bit multiply-add per element (common.h)
       if (p.has_drop) { tk = drop_tilekey(rowkey, (uint32_t)kt); dx = drop_rot(tk, (uint32_t)g); }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float dp = dpacc[r];
-        if (p.has_drop) dp = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? dp * p.inv_keep : 0.f;
-        ds[r] = ds[r] * (dp - dlt) * p.scale;
+        if (p.has_drop) dp = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? dp : 0.f;
+        ds[r] = ds[r] * fmaf(dp, c1, -dlt);
       }
       const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
 #pragma unroll
@@ -724,6 +757,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
   const bool key_ok = key < p.Lk;
   const int key_row = (key_ok && p.key_index) ? p.key_index[key] : key;
   const float scale_log2 = p.scale * LOG2E;
+  const float c1 = p.c1;                          // dS = P (c1 dP' - scale delta): scale and 1 / keep ride on one fma
   const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
   const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
   const bf16_t* vb = p.v + (int64_t)b * p.vsb + (int64_t)h * p.vsh;
@@ -757,7 +791,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
     if (t < 64) {
       const int qq = qt * 32 + (t & 31);
       if (t < 32) stat = qq < p.Lq ? p.lse[bh_row0 + qq] * LOG2E : INFINITY;
-      else stat = qq < p.Lq ? p.delta[bh_row0 + qq] : 0.f;
+      else stat = qq < p.Lq ? p.delta[bh_row0 + qq] * p.scale : 0.f;    // scaled once here: dS = P (c1 dP' - scale delta)
     }
   };
   auto l_store = [&](int buf) {
@@ -803,8 +837,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
       for (int r = 0; r < 16; ++r) pr[r] = fast_exp2(fmaf(sacc[r], scale_log2, -lse2[r]));  // q >= Lq: lse2 = +inf -> 0
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pr[r] = vis_select<0u>(vg, r, pr[r]);
+        vis_select16<0u>(vg, pr);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -814,10 +847,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
           const uint32_t rk = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + q0 + acc_row(r, g)));
           const uint32_t tk = drop_tilekey(rk, (uint32_t)ktw);
           const bool keep = drop_elem(drop_rot(tk, (uint32_t)((l31 >> 2) & 1)), tk, DVLA_DROP_C((l31 & 3) + 4 * (l31 >> 3))) >= p.drop_thr;
-          dp = keep ? dp * p.inv_keep : 0.f;
-          pdrop = keep ? pdrop * p.inv_keep : 0.f;
+          dp = keep ? dp : 0.f;                // 1 / keep: in c1 for dS, on the stored dV for P
+          pdrop = keep ? pdrop : 0.f;
         }
-        ds[r] = pr[r] * (dp - dlt[r]) * p.scale;
+        ds[r] = pr[r] * fmaf(dp, c1, -dlt[r]);     // the staged statistics hold scale * delta; c1 = scale / keep
         pr[r] = pdrop;
       }
       const bf16x8 pf0 = pack_frag(pr), pf1 = pack_frag(pr + 8);
@@ -837,7 +870,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(AttnKArgs p) {
   }
   if (key_ok) {
     store_token(p.dk + (int64_t)b * p.dksb + (int64_t)key_row * p.dkst + (int64_t)h * p.dksh, dkacc, 1.0f, g, (p.st16 & 4) != 0);
-    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, 1.0f, g, (p.st16 & 8) != 0);
+    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, p.inv_keep, g, (p.st16 & 8) != 0);
   }
 }
 
@@ -868,6 +901,7 @@ int fill_args(const dvla_attn_params* q, AttnKArgs& a) {
   a.nqt = (q->Lq + 31) / 32; a.nkt = (q->Lk + 31) / 32;
   a.has_drop = q->dropout_p > 0.f;
   a.inv_keep = a.has_drop ? 1.0f / (1.0f - q->dropout_p) : 1.0f;
+  a.c1 = q->scale * a.inv_keep;
   {
     double thr = (double)q->dropout_p * 4294967296.0;
     a.drop_thr = thr >= 4294967295.0 ? 4294967295u : (uint32_t)thr;
@@ -973,6 +1007,8 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   } else {
     dlt = q_ok ? p.delta[rowid] : 0.f;
   }
+  dlt *= p.scale;                              // delta and dP enter dS already scaled: dS = P (c1 dP' - scale delta),
+  const float c1 = p.c1;                        // c1 = scale / keep, dP' = the kept dP -- one fma per element, no multiply by scale
   for (int kt = t; kt < p.nkt; kt += AT_THREADS) {
     int f = 0;
 #pragma unroll
@@ -1055,16 +1091,20 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(sacc[r], scale_log2, -lse2));
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = vis_select<0u>(vg, r, ds[r]);
+        vis_select16<0u>(vg, ds);
       }
+      // dS = P (c1 dP' - dlt), dlt = scale * delta, c1 = scale / keep, dP' = the kept dP: scale and 1 / keep cost nothing here.
+      // (The dropout test stays INSIDE the element loop in this kernel: hipcc then keeps sixteen small basic blocks -- a scalar test
+      // and a branch per element, ~3 issue slots each -- but hoisted around the loop, as in the dK/dV kernel, the straight-line
+      // schedule needs more than the 128 registers of four waves per SIMD and reloads Q / dO fragments from scratch inside the
+      // tile loop, which drains the DMA ring (round 6, measured in the assembly: 6 reloads per tile).)
       uint32_t tk = 0u, dx = 0u;   // one hash per (row, tile), one 24-bit multiply-add per element (common.h)
       if (p.has_drop) { tk = drop_tilekey(rowkey, (uint32_t)kt); dx = drop_rot(tk, (uint32_t)g); }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float dp = dpacc[r];
-        if (p.has_drop) dp = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? dp * p.inv_keep : 0.f;
-        ds[r] = ds[r] * (dp - dlt) * p.scale;
+        if (p.has_drop) dp = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? dp : 0.f;
+        ds[r] = ds[r] * fmaf(dp, c1, -dlt);
       }
       const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
       bf16x8 kt4[4];
@@ -1102,6 +1142,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
   const bool key_ok = key < p.Lk;
   const int key_row = (key_ok && p.key_index) ? p.key_index[key] : key;
   const float scale_log2 = p.scale * LOG2E;
+  const float c1 = p.c1;                          // dS = P (c1 dP' - scale delta): scale and 1 / keep ride on one fma
   const bool has_bits = p.tile_map != nullptr && p.bits_k != nullptr;
   const bf16_t* qb = p.q + (int64_t)b * p.qsb + (int64_t)h * p.qsh;
   const bf16_t* kb = p.k + (int64_t)b * p.ksb + (int64_t)h * p.ksh;
@@ -1138,7 +1179,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
     }
   for (int i = t; i < 32 * p.nqt; i += AT_THREADS) {
     lse2s[i] = i < p.Lq ? p.lse[bh_row0 + i] * LOG2E : INFINITY;   // q >= Lq: exp2(s - inf) = 0
-    dlts[i] = i < p.Lq ? p.delta[bh_row0 + i] : 0.f;
+    dlts[i] = i < p.Lq ? p.delta[bh_row0 + i] * p.scale : 0.f;    // scaled once here: dS = P (c1 dP' - scale delta)
     if (p.has_drop) {
       const uint32_t rk = drop_rowkey(p.seed_lo, p.seed_hi, (uint32_t)(bh_row0 + i));
 #pragma unroll
@@ -1226,30 +1267,31 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
       for (int r = 0; r < 16; ++r) pr[r] = fast_exp2(fmaf(sacc[r], scale_log2, -lse2[r]));
       if (__any(vis != 0xffffffffu)) {
         const uint32_t vg = vis >> (4 * g);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pr[r] = vis_select<0u>(vg, r, pr[r]);
+        vis_select16<0u>(vg, pr);
       }
+      float dp[16];
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        uint32_t rk[4] = {0u, 0u, 0u, 0u};
-        if (p.has_drop) {      // tile keys of queries q0 + 8 rq + 4 g .. + 3 (= acc_row(4 rq + e, g)) for this wave's key tile
+      for (int r = 0; r < 16; ++r) dp[r] = dpacc[r];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[r] = pr[r];          // the UNDROPPED probabilities form dS; `pr` goes on to dV
+      if (p.has_drop) {        // ONE branch around all sixteen elements (inside the element loop hipcc kept a scalar test and a
+        // branch per element -- sixteen basic blocks, no select scheduled into the hazard slots of the one before it; round 6)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          // tile keys of queries q0 + 8 rq + 4 g .. + 3 (= acc_row(4 rq + e, g)) for this wave's key tile
           const uint4 a = *reinterpret_cast<const uint4*>(tkw + q0 + 8 * rq + 4 * g);
-          rk[0] = a.x; rk[1] = a.y; rk[2] = a.z; rk[3] = a.w;
-        }
+          const uint32_t rk[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * rq + e;
-          float dp = dpacc[r];
-          float pdrop = pr[r];
-          if (p.has_drop) {
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
             const bool keep = drop_elem(drop_rot(rk[e], drop_half), rk[e], drop_cj) >= p.drop_thr;
-            dp = keep ? dp * p.inv_keep : 0.f;
-            pdrop = keep ? pdrop * p.inv_keep : 0.f;
+            dp[r] = keep ? dp[r] : 0.f;            // 1 / keep: in c1 for dS, on the stored dV for P
+            pr[r] = keep ? pr[r] : 0.f;
           }
-          ds[r] = pr[r] * (dp - dlt[r]) * p.scale;
-          pr[r] = pdrop;
         }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[r] = ds[r] * fmaf(dp[r], c1, -dlt[r]);   // the table holds scale * delta; c1 = scale / keep
       const bf16x8 pf0 = pack_frag(pr), pf1 = pack_frag(pr + 8);
       const bf16x8 sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
       {   // the eight transposed fragments first, then eight multiplies that walk the four accumulators round-robin
@@ -1273,7 +1315,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_ring_kernel(AttnKArgs
   }
   if (key_ok) {
     store_token(p.dk + (int64_t)b * p.dksb + (int64_t)key_row * p.dkst + (int64_t)h * p.dksh, dkacc, 1.0f, g, (p.st16 & 4) != 0);
-    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, 1.0f, g, (p.st16 & 8) != 0);
+    store_token(p.dv + (int64_t)b * p.dvsb + (int64_t)key_row * p.dvst + (int64_t)h * p.dvsh, dvacc, p.inv_keep, g, (p.st16 & 8) != 0);
   }
 }
 
@@ -1422,7 +1464,7 @@ __global__ __launch_bounds__(SB_THREADS) void attn_bwd_short_kernel(AttnKArgs p)
       }
       acc += __shfl_xor(acc, 32, 64);
       const float lse2 = q_ok ? lse_in * LOG2E : INFINITY;       // q >= L: exp2(s - inf) = 0
-      const float dlt = q_ok ? acc : 0.f;
+      const float dlt = q_ok ? acc * p.scale : 0.f;              // scale * delta (here and in the table): dS = P fma(dP, scale, -dlt)
       if (g == 0) { lse2s[j * 32 + l31] = lse2; dlts[j * 32 + l31] = dlt; }
       f32x16 dqacc[2] = {zero16(), zero16()};
       for (int kt = 0; kt < nt; ++kt) {
@@ -1447,11 +1489,10 @@ __global__ __launch_bounds__(SB_THREADS) void attn_bwd_short_kernel(AttnKArgs p)
         if (k0 + 32 > L) {           // the ragged last key tile (wave-uniform)
           asm volatile("");          // (keeps this a BRANCH: hipcc if-converted it into sixteen selects on every tile)
           const uint32_t vg = low_mask(L - k0) >> (4 * g);
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) ds[rr] = vis_select<0u>(vg, rr, ds[rr]);
+          vis_select16<0u>(vg, ds);
         }
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) ds[rr] = ds[rr] * (dpacc[rr] - dlt) * p.scale;
+        for (int rr = 0; rr < 16; ++rr) ds[rr] = ds[rr] * fmaf(dpacc[rr], p.scale, -dlt);
         const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
         bf16x8 kt4[4];
 #pragma unroll
@@ -1524,7 +1565,7 @@ __global__ __launch_bounds__(SB_THREADS) void attn_bwd_short_kernel(AttnKArgs p)
             float pv = fast_exp2(fmaf(sacc[rr], scale_log2, -l4[e]));
             pv = key_ok ? pv : 0.f;
             pr[rr] = pv;
-            ds[rr] = pv * (dpacc[rr] - d4[e]) * p.scale;
+            ds[rr] = pv * fmaf(dpacc[rr], p.scale, -d4[e]);
           }
         }
         const bf16x8 pf0 = pack_frag(pr), pf1 = pack_frag(pr + 8);
@@ -1627,8 +1668,7 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         if (k0 + 32 > L) {
           asm volatile("");          // (keeps this a BRANCH: hipcc if-converted it into sixteen selects on every tile)
           const uint32_t vg = low_mask(L - k0) >> (4 * g);
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) sv[rr] = vis_select<NEG_INF_BITS>(vg, rr, sv[rr]);
+          vis_select16<NEG_INF_BITS>(vg, sv);
         }
         float mt = sv[0];
 #pragma unroll

@@ -148,11 +148,14 @@ def attention_bf16(q, k, v, scale=None, mask=None, drop=None, drop_cols=None, do
 
       forward   s2 = (q k^T) * (scale * log2 e) + mask;  M = ceil(rowmax s2)  (an INTEGER: every online-softmax rescale
                 in the kernel is an exact power of two, so rounding P commutes with it and the result does not depend on the
-                tile order);  p = 2^(s2 - M);  l = sum_j p  (fp32, unrounded p);  P~ = bf16(dropout(p));
-                o = bf16((P~ v) / l);  lse = (M + log2 l) ln 2
-      backward  P = 2^(s2 - lse log2 e)  (from the saved lse, unrounded);  dP = dropout'(dout v^T);
-                delta = rowsum(dout * o)  (o as stored: bf16);  dS~ = bf16(P (dP - delta) scale);
-                dq = bf16(dS~ k),  dk = bf16(dS~^T q),  dv = bf16(bf16(dropout(P))^T dout)
+                tile order);  p = 2^(s2 - M);  l = sum_j p  (fp32, unrounded p);  P~ = bf16(keep ? p : 0);
+                o = bf16((P~ v) / (keep_rate l));  lse = (M + log2 l) ln 2
+      backward  P = 2^(s2 - lse log2 e)  (from the saved lse, unrounded);  dP' = keep ? dout v^T : 0;
+                delta = rowsum(dout * o)  (o as stored: bf16);  dS~ = bf16(P (c1 dP' - scale delta)),  c1 = scale / keep_rate;
+                dq = bf16(dS~ k),  dk = bf16(dS~^T q),  dv = bf16((bf16(keep ? P : 0)^T dout) / keep_rate)
+    (round 6: the dropout's 1 / keep_rate is applied to the accumulated output and to the accumulated dV instead of to every
+    probability before its bf16 rounding, and rides on the fma that forms dS -- the same attention-probability dropout
+    (gpt2.py:82), one multiply per output element instead of one per score)
 
     Pinned by tests/test_attention_oracle.py: equals `attention` (and its autograd) up to those two roundings -- 3e-3 /
     4e-3 rel-L2 on random data -- and is exactly invariant to the order in which key tiles are visited.
@@ -179,9 +182,9 @@ def attention_bf16(q, k, v, scale=None, mask=None, drop=None, drop_cols=None, do
         cols = (torch.arange(Lk, dtype=torch.int64) if drop_cols is None else drop_cols.to(torch.int64)).view(1, 1, 1, Lk)
         keep = attn_drop_keep_mask(seed, rows, cols, pd)
         inv_keep = 1.0 / (1.0 - pd)
-    pdrop = p if keep is None else torch.where(keep, p * inv_keep, torch.zeros_like(p))
+    pdrop = p if keep is None else torch.where(keep, p, torch.zeros_like(p))
     some = l > 0                    # a row that sees no key: o = 0, lse = +inf (the kernel's convention; the reference never builds one)
-    o = bf16_round(torch.where(some, torch.matmul(bf16_round(pdrop), v) / torch.where(some, l, torch.ones_like(l)),
+    o = bf16_round(torch.where(some, torch.matmul(bf16_round(pdrop), v) * (inv_keep / torch.where(some, l, torch.ones_like(l))),
                                torch.zeros(1)))
     lse = torch.where(some, (m + torch.log2(torch.where(some, l, torch.ones_like(l)))) * LN2,
                       torch.full_like(l, float("inf"))).squeeze(-1)
@@ -193,13 +196,13 @@ def attention_bf16(q, k, v, scale=None, mask=None, drop=None, drop_cols=None, do
         P = torch.where(vis, P, torch.zeros_like(P))
     dP = torch.matmul(dout, v.transpose(-1, -2))
     if keep is not None:
-        dP = torch.where(keep, dP * inv_keep, torch.zeros_like(dP))
+        dP = torch.where(keep, dP, torch.zeros_like(dP))
     delta = (dout * o).sum(dim=-1, keepdim=True)
-    dS = bf16_round(P * (dP - delta) * scale)
-    Pd = P if keep is None else torch.where(keep, P * inv_keep, torch.zeros_like(P))
+    dS = bf16_round(P * (dP * (scale * inv_keep) - delta * scale))
+    Pd = P if keep is None else torch.where(keep, P, torch.zeros_like(P))
     dq = bf16_round(torch.matmul(dS, k))
     dk = bf16_round(torch.matmul(dS.transpose(-1, -2), q))
-    dv = bf16_round(torch.matmul(bf16_round(Pd).transpose(-1, -2), dout))
+    dv = bf16_round(torch.matmul(bf16_round(Pd).transpose(-1, -2), dout) * inv_keep)
     return o, lse, dq, dk, dv
 
 
