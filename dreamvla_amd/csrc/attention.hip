@@ -952,7 +952,12 @@ __device__ __forceinline__ bf16x8 fa_frag_tr(const char* tile, int db, int mm, i
   return u.v;
 }
 
-__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dq_ring_kernel(AttnKArgs p) {
+// Three waves per SIMD (round 6; rounds 2-5: four).  At 128 registers the kernel could neither request the eight S / dP fragments of a
+// tile as a group (9 of its 12 multiplies waited for their own LDS read) nor take its dropout selects out of sixteen per-element
+// basic blocks (the straight-line schedule spilled Q / dO fragments and reloaded them inside the tile loop, which drains the DMA
+// ring).  At 168 it does both with 154 registers and no spill; trunk backward with dropout 266.6 -> 260.2 us, without 245.0 -> 236.1
+// (same-box A/B, profiles/r06_attn_dq3_ab.txt).
+__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_ring_kernel(AttnKArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, g = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1077,10 +1082,16 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       const char* ks = smem + cslot * FA_STAGE;
       const char* vs = ks + FA_TILE;
       f32x16 sacc = zero16(), dpacc = zero16();
+      {
+        bf16x8 fk[4], fv[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(ks, l31, s, g), qf[s], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_frag_rm(vs, l31, s, g), dof[s], dpacc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) { fk[s] = fa_frag_rm(ks, l31, s, g); fv[s] = fa_frag_rm(vs, l31, s, g); }
+        fa_group4(fk); fa_group4(fv);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[s], qf[s], sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[s], dof[s], dpacc, 0, 0, 0);
+        }
       }
       const int k0 = kt * 32;
       uint32_t vis = 0xffffffffu;
@@ -1094,17 +1105,18 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         vis_select16<0u>(vg, ds);
       }
       // dS = P (c1 dP' - dlt), dlt = scale * delta, c1 = scale / keep, dP' = the kept dP: scale and 1 / keep cost nothing here.
-      // (The dropout test stays INSIDE the element loop in this kernel: hipcc then keeps sixteen small basic blocks -- a scalar test
-      // and a branch per element, ~3 issue slots each -- but hoisted around the loop, as in the dK/dV kernel, the straight-line
-      // schedule needs more than the 128 registers of four waves per SIMD and reloads Q / dO fragments from scratch inside the
-      // tile loop, which drains the DMA ring (round 6, measured in the assembly: 6 reloads per tile).)
-      uint32_t tk = 0u, dx = 0u;   // one hash per (row, tile), one 24-bit multiply-add per element (common.h)
-      if (p.has_drop) { tk = drop_tilekey(rowkey, (uint32_t)kt); dx = drop_rot(tk, (uint32_t)g); }
+      // ONE branch around two complete element loops (no scalar test and branch per element; see the kernel's header).
+      if (p.has_drop) {
+        const uint32_t tk = drop_tilekey(rowkey, (uint32_t)kt);
+        const uint32_t dx = drop_rot(tk, (uint32_t)g);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float dp = dpacc[r];
-        if (p.has_drop) dp = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? dp : 0.f;
-        ds[r] = ds[r] * fmaf(dp, c1, -dlt);
+        for (int r = 0; r < 16; ++r) {
+          const float dp = (drop_elem(dx, tk, DVLA_DROP_C(r)) >= p.drop_thr) ? dpacc[r] : 0.f;
+          ds[r] = ds[r] * fmaf(dp, c1, -dlt);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[r] = ds[r] * fmaf(dpacc[r], c1, -dlt);
       }
       const bf16x8 f0 = pack_frag(ds), f1 = pack_frag(ds + 8);
       bf16x8 kt4[4];
