@@ -124,70 +124,6 @@ __device__ __forceinline__ void fa_swap_halves(uint32_t& lo_grp, uint32_t& hi_gr
   const auto r = __builtin_amdgcn_permlane32_swap(lo_grp, hi_grp, false, false);
   lo_grp = r[0]; hi_grp = r[1];
 }
-// Reductions across the two half-waves (a score row lives in lanes l and l + 32): ONE v_permlane32_swap hands every lane both
-// halves' values -- swap(a = x, b = x) leaves a = the low half's x in all 64 lanes and b = the high half's.  (__shfl_xor(x, 32)
-// compiles to ds_bpermute_b32: six address instructions, an LDS round trip and an lgkmcnt(0) wait in the middle of the softmax,
-// twice per tile -- round 6.)
-__device__ __forceinline__ float half_max(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, x), __builtin_bit_cast(uint32_t, x), false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-__device__ __forceinline__ float half_sum(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, x), __builtin_bit_cast(uint32_t, x), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
-}
-// Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two values per lane and instruction, each component the same IEEE
-// operation as the scalar form).  hipcc does not pair the sixteen independent fmas of a score tile by itself.
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-// p[r] = 2^(x[r] * a - b), r = 0..15; returns the sum of the sixteen (pairwise partial sums: two chains of eight)
-__device__ __forceinline__ float exp2_tile_sum(float (&p)[16], const float (&x)[16], float a, float b) {
-  const f32x2 a2 = {a, a}, nb2 = {-b, -b};
-  f32x2 acc = {0.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const f32x2 t = pk_fma(f32x2{x[r], x[r + 1]}, a2, nb2);
-    const f32x2 e = {fast_exp2(t.x), fast_exp2(t.y)};
-    p[r] = e.x; p[r + 1] = e.y;
-    acc += e;
-  }
-  return acc.x + acc.y;
-}
-// p[r] = 2^(x[r] * a - b[r]) with a per-register subtrahend (the dK/dV kernels: one log-sum-exp per query row)
-__device__ __forceinline__ void exp2_tile_rows(float (&p)[16], const f32x16& x, float a, const float (&b)[16]) {
-  const f32x2 a2 = {a, a};
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const f32x2 t = pk_fma(f32x2{x[r], x[r + 1]}, a2, f32x2{-b[r], -b[r + 1]});
-    p[r] = fast_exp2(t.x); p[r + 1] = fast_exp2(t.y);
-  }
-}
-// p[r] = 2^(x[r] * a - b), one subtrahend for the lane (the dQ kernels: the lane's own query row)
-__device__ __forceinline__ void exp2_tile(float (&p)[16], const f32x16& x, float a, float b) {
-  const f32x2 a2 = {a, a}, nb2 = {-b, -b};
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const f32x2 t = pk_fma(f32x2{x[r], x[r + 1]}, a2, nb2);
-    p[r] = fast_exp2(t.x); p[r + 1] = fast_exp2(t.y);
-  }
-}
-// ds[r] = p[r] * (dp[r] * c1 - d), one d for the lane (dQ kernels)
-__device__ __forceinline__ void ds_tile(float (&ds)[16], const f32x16& dp, float c1, float d) {
-  const f32x2 c2 = {c1, c1}, nd2 = {-d, -d};
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const f32x2 t = pk_fma(f32x2{dp[r], dp[r + 1]}, c2, nd2) * f32x2{ds[r], ds[r + 1]};
-    ds[r] = t.x; ds[r + 1] = t.y;
-  }
-}
-// ds[r] = p[r] * (dp[r] * c1 - d[r]) with a per-register d (dK/dV kernels)
-__device__ __forceinline__ void ds_tile_rows(float (&ds)[16], const float (&p)[16], const float (&dp)[16], float c1, const float (&d)[16]) {
-  const f32x2 c2 = {c1, c1};
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const f32x2 t = pk_fma(f32x2{dp[r], dp[r + 1]}, c2, f32x2{-d[r], -d[r + 1]}) * f32x2{p[r], p[r + 1]};
-    ds[r] = t.x; ds[r + 1] = t.y;
-  }
-}
 __device__ __forceinline__ void store_token(bf16_t* dst, const f32x16 (&acc)[2], float mul, int g, bool vec16) {
   if (vec16) {
 #pragma unroll
@@ -362,7 +298,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
       float mt = sv[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sv[r]);
-      mt = half_max(mt);
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       // the running maximum is kept as an INTEGER in the log2 domain (rounded up): every rescale factor alpha is then an exact
       // power of two, so the bf16 rounding of P commutes with it -- O = sum_j bf16(2^(s_j - M)) v_j / sum_j 2^(s_j - M) whatever
       // the tile order or the intermediate maxima, which is what lets oracle/torch_ref.py::attention_bf16 restate the kernel's
@@ -370,8 +306,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(AttnKArgs p) {
       const float m_new = fmaxf(m_run, ceilf(mt * scale_log2));
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = fast_exp2(m_run - m_safe);
-      float rs = exp2_tile_sum(sv, sv, scale_log2, m_safe);
-      rs = half_sum(rs);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sv[r] = fast_exp2(fmaf(sv[r], scale_log2, -m_safe)); rs += sv[r]; }
+      rs += __shfl_xor(rs, 32, 64);
       l_run = l_run * alpha + rs;
       m_run = m_new;
       if (__any(alpha != 1.0f)) {
@@ -607,7 +545,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       float mt = sv[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sv[r]);
-      mt = half_max(mt);
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       // the running maximum is kept as an INTEGER in the log2 domain (rounded up): every rescale factor alpha is then an exact
       // power of two, so the bf16 rounding of P commutes with it -- O = sum_j bf16(2^(s_j - M)) v_j / sum_j 2^(s_j - M) whatever
       // the tile order or the intermediate maxima, which is what lets oracle/torch_ref.py::attention_bf16 restate the kernel's
@@ -615,8 +553,10 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       const float m_new = fmaxf(m_run, ceilf(mt * scale_log2));
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = fast_exp2(m_run - m_safe);
-      float rs = exp2_tile_sum(sv, sv, scale_log2, m_safe);
-      rs = half_sum(rs);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sv[r] = fast_exp2(fmaf(sv[r], scale_log2, -m_safe)); rs += sv[r]; }
+      rs += __shfl_xor(rs, 32, 64);
       l_run = l_run * alpha + rs;
       m_run = m_new;
       if (__any(alpha != 1.0f)) {
@@ -1066,7 +1006,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         acc += bf2f((bf16_t)(dw[i] >> 16)) * bf2f((bf16_t)(ow[i] >> 16));
       }
     }
-    acc = half_sum(acc);
+    acc += __shfl_xor(acc, 32, 64);
     dlt = q_ok ? acc : 0.f;
     if (q_ok && g == 0) p.delta[rowid] = acc;
   } else {
@@ -1539,7 +1479,7 @@ __global__ __launch_bounds__(SB_THREADS) void attn_bwd_short_kernel(AttnKArgs p)
           acc += bf2f((bf16_t)(dw[i] >> 16)) * bf2f((bf16_t)(ow[i] >> 16));
         }
       }
-      acc = half_sum(acc);
+      acc += __shfl_xor(acc, 32, 64);
       const float lse2 = q_ok ? lse_in * LOG2E : INFINITY;       // q >= L: exp2(s - inf) = 0
       const float dlt = q_ok ? acc * p.scale : 0.f;              // scale * delta (here and in the table): dS = P fma(dP, scale, -dlt)
       if (g == 0) { lse2s[j * 32 + l31] = lse2; dlts[j * 32 + l31] = dlt; }
@@ -1750,12 +1690,14 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         float mt = sv[0];
 #pragma unroll
         for (int rr = 1; rr < 16; ++rr) mt = fmaxf(mt, sv[rr]);
-        mt = half_max(mt);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, ceilf(mt * scale_log2));     // integer running maximum: see attn_fwd_ring_kernel
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = fast_exp2(m_run - m_safe);
-        float rs = exp2_tile_sum(sv, sv, scale_log2, m_safe);
-        rs = half_sum(rs);
+        float rs = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) { sv[rr] = fast_exp2(fmaf(sv[rr], scale_log2, -m_safe)); rs += sv[rr]; }
+        rs += __shfl_xor(rs, 32, 64);
         l_run = l_run * alpha + rs;
         m_run = m_new;
         if (__any(alpha != 1.0f)) {
