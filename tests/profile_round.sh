@@ -11,7 +11,7 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-eager-baseline --no-rollout --no-loss-parity --no-other-configs"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-eager-baseline --no-rollout --no-loss-parity --no-other-configs --no-integration-levels"
 # 1. kernel trace + stats of the bench command (3 timed steps)
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_step -f csv -- $BENCH --steps 3 --warmup 1 --no-roofline > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 python $REPO/tests/prof_summary.py $OUT/${TAG}_prof_step $OUT/${TAG}_step_summary.txt > /dev/null 2>&1
