@@ -185,6 +185,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
         for (int e = 0; e < 8; ++e) { xh[i][e] = 0.f; gy[i][e] = 0.f; }
       }
     }
+    if (dx) {     // (dx == nullptr, round 6: the input needs no gradient -- the resampler's norm_media over the frozen ViT's patch
+      // tokens -- only the parameter gradients are wanted: no row reductions, no 135-MB store)
     s1 = wave_sum(s1) * inv_n;
     s2 = wave_sum(s2) * inv_n;
     uint4* dr = reinterpret_cast<uint4*>(dx + row * cols);
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
         }
         dr[vi] = pack8(o);
       }
+    }
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { rx[i] = nx[i]; rg[i] = ng[i]; rr[i] = nr[i]; }
@@ -313,7 +316,8 @@ extern "C" int dvla_layernorm_bwd_add(const void* dy, const void* x, const void*
   if (grad_dtype != DVLA_DT_F32 && grad_dtype != DVLA_DT_BF16) return DVLA_ERR_ARG;
   const bf16_t* drp = reinterpret_cast<const bf16_t*>(dres);
   if ((reinterpret_cast<uintptr_t>(dres) & 15) != 0) return DVLA_ERR_UNSUPPORTED;
-  if (!dy || !x || !mean || !rstd || !dx || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
+  if (!dy || !x || !mean || !rstd || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
+  if (!dx && (dres || !(dgamma || dbeta))) return DVLA_ERR_ARG;      // dx == NULL: parameter gradients only (nothing to do otherwise)
   if ((dgamma || dbeta) && !partial) return DVLA_ERR_ARG;
   if (rows == 0) return DVLA_OK;
   if (cols % 8 != 0 || cols > 64 * 8 * LN_MAX_VPL) return DVLA_ERR_UNSUPPORTED;

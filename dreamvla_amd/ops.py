@@ -451,12 +451,15 @@ def layernorm_fwd(x2, gamma, beta, eps, want_stats):
 
 
 def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads, dres2=None, grad_dtype=torch.float32, dg_out=None,
-                  db_out=None):
+                  db_out=None, need_dx=True):
     """dres2: gradient of the residual stream that bypassed the LayerNorm; added to dx inside the kernel.
-    dgamma / dbeta come back in grad_dtype (bf16 or fp32) straight from the reduction kernel."""
+    dgamma / dbeta come back in grad_dtype (bf16 or fp32) straight from the reduction kernel.
+    need_dx=False (with need_param_grads): the input needs no gradient; dx is neither computed nor stored (returns None)."""
     lib = _lib.load()
     rows, cols = x2.shape
-    dx = torch.empty_like(x2)
+    if not need_dx and (dres2 is not None or not need_param_grads):
+        raise ValueError("layernorm_bwd(need_dx=False) is for parameter gradients only")
+    dx = torch.empty_like(x2) if need_dx else None
     dg = db = part = None
     if need_param_grads:
         dg = dg_out if dg_out is not None else torch.empty(cols, dtype=grad_dtype, device=x2.device)
@@ -465,7 +468,7 @@ def layernorm_bwd(dy2, x2, gamma, mean, rstd, need_param_grads, dres2=None, grad
     pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
     gdt = DT_F32 if grad_dtype == torch.float32 else DT_BF16
     check(lib.dvla_layernorm_bwd_add(dy2.data_ptr(), x2.data_ptr(), _ptr(gamma), pdt, mean.data_ptr(), rstd.data_ptr(),
-                                     _ptr(dres2), dx.data_ptr(), _ptr(dg), _ptr(db), gdt, _ptr(part), rows, cols, _stream()),
+                                     _ptr(dres2), _ptr(dx), _ptr(dg), _ptr(db), gdt, _ptr(part), rows, cols, _stream()),
           "dvla_layernorm_bwd_add")
     return dx, dg, db
 
@@ -1190,10 +1193,11 @@ class _LayerNorm(torch.autograd.Function):
             dy2 = dy2.contiguous()
         need_p = ctx.has_affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         gdt = gamma.dtype if need_p else torch.float32
+        need_dx = ctx.needs_input_grad[0] or not need_p       # (an input without gradient: parameter gradients only)
         dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, need_p, None, gdt,
                                    _grad_dest(gamma, gdt) if need_p else None,
-                                   _grad_dest(beta, gdt) if need_p and ctx.has_beta else None)
-        return dx.view(ctx.x_shape), dg, (db if ctx.has_beta else None), None
+                                   _grad_dest(beta, gdt) if need_p and ctx.has_beta else None, need_dx=need_dx)
+        return (dx.view(ctx.x_shape) if dx is not None else None), dg, (db if ctx.has_beta else None), None
 
 
 def layer_norm(x, weight, bias, eps):

@@ -130,7 +130,8 @@ void dvla_get_gemm_schedule(int* oversubscribe, int* stream_k);
  * Replaces nn.LayerNorm at models/vit_mae.py:77,202-204 (eps 1e-6), models/gpt2.py:312-315,437
  * (eps 1e-5), models/dreamvla_model.py:279,352,374,393,412,433, models/perceiver_resampler.py:14,28-29,101.
  * fwd writes mean/rstd (fp32, one per row) when they are non-NULL (needed by bwd).
- * bwd: dx always; dgamma/dbeta (fp32, cols) when non-NULL, using `partial` = fp32 workspace of
+ * bwd: dx (NULL, round 6: the input needs no gradient -- parameter gradients only); dgamma/dbeta (fp32, cols) when non-NULL, using
+ *      `partial` = fp32 workspace of
  *      2 * dvla_layernorm_bwd_partial_rows() * cols floats.
  */
 int dvla_layernorm_fwd(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,

@@ -569,6 +569,15 @@ def check_layernorm(rows, cols, affine=True, eps=1e-5, param_f32=False, seed=0):
     if affine:
         out.append(metrics(tag + " dgamma", wd.grad, wr.grad, TOL_GRAD, round_ref=not param_f32))
         out.append(metrics(tag + " dbeta", bd.grad, br.grad, TOL_GRAD, round_ref=not param_f32))
+        # an input that needs no gradient (round 6: dx == NULL in dvla_layernorm_bwd_add -- the resampler's norm_media over the frozen
+        # ViT's tokens): the parameter gradients must be the SAME numbers, and no input gradient may appear
+        x0 = x.to(DEV, BF)
+        w0 = wd.detach().clone().requires_grad_(True)
+        b0 = bd.detach().clone().requires_grad_(True)
+        ops.layer_norm(x0, w0, b0, eps).backward(dy.to(DEV, BF))
+        out.append(metrics(tag + " dgamma (input without gradient)", w0.grad, wd.grad.detach().float().cpu(), 0.0, round_ref=not param_f32))
+        out.append(metrics(tag + " dbeta (input without gradient)", b0.grad, bd.grad.detach().float().cpu(), 0.0, round_ref=not param_f32))
+        out.append({"name": tag + " no input gradient", "ok": x0.grad is None, "rel_l2": 0.0, "max_abs": 0.0, "tol": 0.0})
     return out
 
 
