@@ -21,6 +21,7 @@ over independent episodes) and removes the redundant work:
 Episodes of one batch advance in lock-step (one `step` = one control step of every episode); `reset(mask)` restarts
 the episodes selected by a boolean mask (their history is cleared, the others keep theirs).
 """
+import gc
 import warnings
 
 import torch
@@ -48,6 +49,14 @@ class _Graphed:
             torch.cuda.synchronize()
             was = GemmTuner.frozen
             GemmTuner.frozen = True                      # no timing events / trials inside the capture
+            # The cyclic garbage collector must not run inside the capture: a collected object whose destructor calls into HIP
+            # (an event, an older graph, a tensor outside the capture's pool) raises "operation not permitted when stream is
+            # capturing" from a destructor, i.e. aborts the process.  Round 6: the full GPU suite died exactly so -- "Fatal Python
+            # error: Aborted ... Garbage-collecting" under encode_frames inside this capture -- once a few allocations elsewhere
+            # had shifted a generation-2 collection into it.  Collect now, keep the collector off until the capture has ended.
+            gc_was = gc.isenabled()
+            gc.collect()
+            gc.disable()
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -55,6 +64,8 @@ class _Graphed:
                 self.graph = g
             finally:
                 GemmTuner.frozen = was
+                if gc_was:
+                    gc.enable()
         for s, t in zip(self.static_in, tensors):
             s.copy_(t)
         self.graph.replay()
