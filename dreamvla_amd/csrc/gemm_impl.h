@@ -1387,7 +1387,14 @@ void gemm_ring_kernel(GemmKArgs p) {
   const int nitems = p.tiles_m * p.tiles_n * p.split_k;
   const int grid = gridDim.x;
   // workgroup b sits on XCD b % 8: give each XCD a run of consecutive items
-  const int perm = (grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // (round 6: also for grids that are not a multiple of 8 -- XCD x then hosts grid / 8 (+ 1 for x < grid % 8) workgroups.  The
+  // identity map such grids used to get spread consecutive items -- the K slices of one tile, neighbouring tiles of one operand
+  // panel -- over all eight L2s: 252-item weight gradients ran 20-26 % slower than their 216-item siblings,
+  // profiles/r06_small_dw_sweep.txt.)
+  const int perm = [&] {
+    const int q8 = grid >> 3, r8 = grid & 7, xcd = (int)(blockIdx.x & 7), idx = (int)(blockIdx.x >> 3);
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }();
   auto item_of = [&](int it) -> int {   // item of iteration `it`, or -1
     const int id = it * grid + perm;
     return id < nitems ? id : -1;

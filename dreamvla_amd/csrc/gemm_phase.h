@@ -119,7 +119,14 @@ void gemm_phase_kernel(GemmKArgs p) {
 
   const int nitems = p.tiles_m * p.tiles_n * p.split_k;
   const int grid = gridDim.x;
-  const int perm = (grid & 7) == 0 ? (int)(blockIdx.x & 7) * (grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // (round 6: also for grids that are not a multiple of 8 -- XCD x then hosts grid / 8 (+ 1 for x < grid % 8) workgroups.  The
+  // identity map such grids used to get spread consecutive items -- the K slices of one tile, neighbouring tiles of one operand
+  // panel -- over all eight L2s: 252-item weight gradients ran 20-26 % slower than their 216-item siblings,
+  // profiles/r06_small_dw_sweep.txt.)
+  const int perm = [&] {
+    const int q8 = grid >> 3, r8 = grid & 7, xcd = (int)(blockIdx.x & 7), idx = (int)(blockIdx.x >> 3);
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }();
   // ---- work segments.  Plain schedule: segment `it` = item it * grid + perm (a whole tile, or one K slice of it).
   // Stream-K hybrid (p.sk_tiles = R > 0 SUPER-tiles, split_k == 1, one workgroup per CU):
   //   a super-tile = SG = 16 consecutive tile ids (the raster makes that a 4 x 4 block of tiles), worked on by a GROUP of
