@@ -139,3 +139,55 @@ def test_temporal_ensembler_matches_the_libero_wrapper(P, temp):
             # besides older ones -- with P = 1 nothing is left (the reference would divide by an empty sum): not part of this case
             pass
         assert torch.equal(got[:, b].to(torch.float32), want.to(torch.float32)), (b, (got[:, b] - want).abs().max())
+
+
+def test_the_garbage_collector_is_off_during_a_graph_capture(monkeypatch):
+    """Round 6: the full GPU suite aborted in `Garbage-collecting` inside the encode capture -- a collected object whose destructor calls
+    into HIP while the stream is capturing ends the process.  `_Graphed` collects, keeps the collector off for the capture (also when
+    the captured function raises) and leaves it as it found it.  Driven here with stand-ins for the capture API (no GPU)."""
+    import contextlib
+    import gc
+
+    from dreamvla_amd import rollout
+
+    seen = []
+
+    class FakeGraph:
+        def replay(self):
+            seen.append(("replay", gc.isenabled()))
+
+    @contextlib.contextmanager
+    def fake_capture(g):
+        seen.append(("capture begins", gc.isenabled()))
+        yield
+        seen.append(("capture ends", gc.isenabled()))
+
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", FakeGraph)
+    monkeypatch.setattr(torch.cuda, "graph", fake_capture)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda: None)
+
+    def fn(x):
+        seen.append(("fn", gc.isenabled()))
+        return (x + 1,)
+
+    assert gc.isenabled()
+    g = rollout._Graphed(fn, warmup=1)
+    x = torch.zeros(3)
+    g(x)                                              # warm-up call: eager, collector untouched
+    assert seen == [("fn", True)]
+    out = g(x)                                        # capture + first replay
+    assert seen[1:] == [("capture begins", False), ("fn", False), ("capture ends", False), ("replay", True)]
+    assert gc.isenabled() and torch.equal(out[0], x + 1)
+
+    def boom(x):
+        raise RuntimeError("inside the capture")
+    b = rollout._Graphed(boom, warmup=0)
+    with pytest.raises(RuntimeError):
+        b(x)
+    assert gc.isenabled()                             # restored on the way out of an exception
+    gc.disable()
+    try:
+        rollout._Graphed(fn, warmup=0)(x)
+        assert not gc.isenabled()                     # a caller that runs without the collector keeps running without it
+    finally:
+        gc.enable()
