@@ -425,6 +425,15 @@ def launch_selftest(rank, world, args):
         dist.destroy_process_group()
 
 
+def require_finite_loss(loss_val):
+    """A model whose parameters have gone non-finite runs FASTER on this chip (round 6, measured: 139 -> 124 ms per step once every
+    operand is NaN -- the matrix pipe toggles less and the clocks rise), so such a run must never print a throughput line."""
+    if not math.isfinite(loss_val):
+        raise SystemExit(f"bench.py: the loss of the last timed step is {loss_val} -- the timed steps did not train a finite model; "
+                         "no throughput is reported (tests/probes/loss_trace.py prints loss / gradient norm / finiteness per step)")
+    return loss_val
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -601,12 +610,7 @@ def main():
                          "predicted_weak_scaling_efficiency_8gpu": "0.97-0.98 (DESIGN.md section 8)"})
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
-    loss_val = float(last.detach())
-    if not math.isfinite(loss_val):
-        # A model whose parameters have gone non-finite runs FASTER on this chip (round 6, measured: 139 -> 124 ms per step once every
-        # operand is NaN -- the matrix pipe toggles less and the clocks rise), so such a run must never print a throughput line.
-        raise SystemExit(f"bench.py: the loss of the last timed step is {loss_val} -- the timed steps did not train a finite model; "
-                         "no throughput is reported (tests/probes/loss_trace.py prints loss / gradient norm / finiteness per step)")
+    loss_val = require_finite_loss(float(last.detach()))
 
     if args.torch_profile and rank == 0:
         from torch.profiler import ProfilerActivity, profile

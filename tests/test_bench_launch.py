@@ -36,3 +36,17 @@ def test_single_rank_selftest():
     r = run(["--gpus", "1", "--launch-selftest"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_a_non_finite_loss_aborts_the_bench():
+    """Round 6: a NaN model runs 11 % faster on the MI355X -- bench.py must refuse to print a throughput for one."""
+    import math
+
+    import pytest
+
+    import bench
+    assert bench.require_finite_loss(0.75) == 0.75
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        with pytest.raises(SystemExit) as e:
+            bench.require_finite_loss(bad)
+        assert "no throughput is reported" in str(e.value) and not math.isfinite(bad)
