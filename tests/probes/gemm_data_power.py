@@ -44,7 +44,7 @@ def main():
             else:
                 a = torch.full((M, K), float("nan"), device="cuda", dtype=BF); b = torch.full((N, K), float("nan"), device="cuda", dtype=BF)
             out = torch.empty(M, N, device="cuda", dtype=BF)
-            n = max(50, int(1.5e15 / (2.0 * M * N * K)))            # ~1.5 s of launches: long enough for the clocks to settle
+            n = max(50, int(2.4e15 / (2.0 * M * N * K)))            # 1.2-1.8 s of launches: long enough for the clocks to settle
 
             def sustained(fn, tag):
                 for _ in range(20):
@@ -52,10 +52,12 @@ def main():
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(n):
+                s = {}
+                for it in range(n):
                     fn()
+                    if it == (2 * n) // 3:                          # the reading is a moving average: sample two thirds into the run, from
+                        s = smi()                                   # inside the launch loop (a full queue blocks the loop: it runs with the GPU)
                 e1.record()
-                s = smi()                                           # sampled while the queue is still running
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / n
                 print(json.dumps({"M": M, "N": N, "K": K, "kernel": tag, "data": kind, "us": round(us, 1),
