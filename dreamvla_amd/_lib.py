@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVLA_LIB") or os.path.join(_HERE, "libdvla_hip.so")
 
 DT_BF16, DT_F32 = 0, 1
-ABI_VERSION = 7          # DVLA_ABI_VERSION of include/dvla.h
+ABI_VERSION = 8          # DVLA_ABI_VERSION of include/dvla.h
 ACT = {"none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "gelu_new": 2, "relu": 3, "silu": 4,
        "quick_gelu": 5, "tanh": 6, "sigmoid": 7}
 
@@ -103,6 +103,8 @@ SYMBOLS = {
     "dvla_layernorm_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "dvla_layernorm_bwd_add": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
     "dvla_layernorm_bwd_partial_rows": (_I64, []),
+    "dvla_layernorm_fwd_rows": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _I32, _P]),
+    "dvla_layernorm_bwd_rows": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _I32, _I32, _P]),
     "dvla_attn_fwd": (C.c_int, [C.POINTER(AttnParams), _P]),
     "dvla_attn_bwd": (C.c_int, [C.POINTER(AttnParams), _P]),
     "dvla_attn_small_fwd": (C.c_int, [C.POINTER(AttnParams), _I32, _P]),

@@ -42,13 +42,22 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
 }
 
+// Row groups (round 6, dvla_layernorm_*_rows): logical row r of the normalised matrix is row (r / grp) * gstride + goff + r % grp of the
+// buffer -- the last `grp` tokens of every `gstride`-token sequence, contiguous inside a sequence, `goff` rows apart across
+// sequences.  grp == 0: the identity (the plain entry points).  One 32-bit division per row and wave, next to 2-4 KiB of traffic.
+__device__ __forceinline__ int64_t ln_buf_row(int64_t r, int grp, int gstride, int goff) {
+  if (grp == 0) return r;
+  const uint32_t g = (uint32_t)r / (uint32_t)grp;
+  return (int64_t)g * gstride + goff + (int64_t)((uint32_t)r - g * (uint32_t)grp);
+}
+
 // cols % 8 == 0 required (vector path); VPL = ceil(cols / 512)
 template <int VPL>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16_t* __restrict__ x, const void* __restrict__ gamma,
                                                             const void* __restrict__ beta, int pf32,
                                                             bf16_t* __restrict__ y, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, int64_t rows, int cols,
-                                                            float eps) {
+                                                            float eps, int grp, int gstride, int goff) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols >> 3;
   const float inv_n = 1.0f / (float)cols;
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16_t* __rest
   int64_t row = (int64_t)blockIdx.x * 4 + wave;
   uint4 raw[VPL], nxt[VPL];
   auto load_row = [&](int64_t r, uint4 (&dst)[VPL]) {
-    const uint4* xr = reinterpret_cast<const uint4*>(x + r * cols);
+    const uint4* xr = reinterpret_cast<const uint4*>(x + ln_buf_row(r, grp, gstride, goff) * cols);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int vi = lane + 64 * i;
@@ -126,7 +135,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
                                                             const void* __restrict__ gamma, int pf32,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             bf16_t* __restrict__ dx, float* __restrict__ partial,
-                                                            int64_t rows, int cols, const bf16_t* __restrict__ dres) {
+                                                            int64_t rows, int cols, const bf16_t* __restrict__ dres,
+                                                            int grp, int gstride, int goff) {
   __shared__ float red[4][64 * 8];  // one vector-slot at a time: [wave][lane*8+e]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols >> 3;
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
   uint4 rx[VPL], rg[VPL], rr[VPL], nx[VPL], ng[VPL], nr[VPL];
   float mu = 0.f, rs = 0.f, nmu = 0.f, nrs = 0.f;
   auto load_row = [&](int64_t r, uint4 (&dx_)[VPL], uint4 (&dg_)[VPL], uint4 (&dr_)[VPL], float& m_, float& r_) {
-    const uint4* xr = reinterpret_cast<const uint4*>(x + r * cols);
+    const uint4* xr = reinterpret_cast<const uint4*>(x + ln_buf_row(r, grp, gstride, goff) * cols);     // (row groups: x and dx in the buffer's rows)
     const uint4* gr = reinterpret_cast<const uint4*>(dy + r * cols);
     const uint4* sr = dres ? reinterpret_cast<const uint4*>(dres + r * cols) : nullptr;
     m_ = mean[r]; r_ = rstd[r];
@@ -189,7 +199,21 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
       // tokens -- only the parameter gradients are wanted: no row reductions, no 135-MB store)
     s1 = wave_sum(s1) * inv_n;
     s2 = wave_sum(s2) * inv_n;
-    uint4* dr = reinterpret_cast<uint4*>(dx + row * cols);
+    uint4* dr = reinterpret_cast<uint4*>(dx + ln_buf_row(row, grp, gstride, goff) * cols);
+    if (grp != 0 && (uint32_t)row % (uint32_t)grp == 0u) {
+      // row groups: dx is the gradient of the WHOLE buffer -- the rows of this sequence outside the group get zeros, written by
+      // the wave that owns the group's first row
+      const int64_t base = (int64_t)((uint32_t)row / (uint32_t)grp) * gstride;
+      for (int j = 0; j < gstride; ++j) {
+        if (j >= goff && j < goff + grp) continue;
+        uint4* zr = reinterpret_cast<uint4*>(dx + (base + j) * cols);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+          const int vi = lane + 64 * i;
+          if (vi < nvec) zr[vi] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int vi = lane + 64 * i;
@@ -275,10 +299,26 @@ int fwd_blocks(int64_t rows) {
 
 extern "C" int64_t dvla_layernorm_bwd_partial_rows(void) { return LN_BWD_BLOCKS; }
 
+static bool ln_groups_ok(int64_t rows, int32_t grp, int32_t gstride, int32_t goff) {
+  if (grp == 0) return gstride == 0 && goff == 0;
+  return grp > 0 && goff >= 0 && gstride >= goff + grp && rows % grp == 0 && rows < (1ll << 31) && (rows / grp) * (int64_t)gstride < (1ll << 40);
+}
+
+extern "C" int dvla_layernorm_fwd_rows(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
+                                       float* mean, float* rstd, int64_t rows, int64_t cols, float eps,
+                                       int32_t grp, int32_t gstride, int32_t goff, void* stream_);
+
 extern "C" int dvla_layernorm_fwd(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
                                   float* mean, float* rstd, int64_t rows, int64_t cols, float eps, void* stream_) {
+  return dvla_layernorm_fwd_rows(x, gamma, beta, param_dtype, y, mean, rstd, rows, cols, eps, 0, 0, 0, stream_);
+}
+
+extern "C" int dvla_layernorm_fwd_rows(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
+                                       float* mean, float* rstd, int64_t rows, int64_t cols, float eps,
+                                       int32_t grp, int32_t gstride, int32_t goff, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!x || !y || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
+  if (!ln_groups_ok(rows, grp, gstride, goff)) return DVLA_ERR_ARG;
   if (rows == 0) return DVLA_OK;
   if (cols % 8 != 0 || cols > 64 * 8 * LN_MAX_VPL) return DVLA_ERR_UNSUPPORTED;
   if (((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) != 0) return DVLA_ERR_UNSUPPORTED;   // parameters are read as 16-B vectors
@@ -288,10 +328,10 @@ extern "C" int dvla_layernorm_fwd(const void* x, const void* gamma, const void* 
   const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
   bf16_t* yp = reinterpret_cast<bf16_t*>(y);
   switch (vpl) {
-    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps); break;
-    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps); break;
-    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps); break;
-    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps); break;
+    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff); break;
+    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff); break;
+    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff); break;
+    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff); break;
   }
   return dvla_check_launch();
 }
@@ -308,11 +348,31 @@ extern "C" int dvla_layernorm_bwd(const void* dy, const void* x, const void* gam
                                 cols, stream_);
 }
 
+static int ln_bwd_launch(const void* dy, const void* x, const void* gamma, int32_t param_dtype, const float* mean, const float* rstd,
+                         const void* dres, void* dx, void* dgamma, void* dbeta, int32_t grad_dtype, float* partial, int64_t rows,
+                         int64_t cols, int32_t grp, int32_t gstride, int32_t goff, void* stream_);
+
 extern "C" int dvla_layernorm_bwd_add(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
                                       const float* mean, const float* rstd, const void* dres, void* dx, void* dgamma,
                                       void* dbeta, int32_t grad_dtype, float* partial, int64_t rows, int64_t cols,
                                       void* stream_) {
+  return ln_bwd_launch(dy, x, gamma, param_dtype, mean, rstd, dres, dx, dgamma, dbeta, grad_dtype, partial, rows, cols, 0, 0, 0, stream_);
+}
+
+extern "C" int dvla_layernorm_bwd_rows(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
+                                       const float* mean, const float* rstd, void* dx, void* dgamma, void* dbeta,
+                                       int32_t grad_dtype, float* partial, int64_t rows, int64_t cols,
+                                       int32_t grp, int32_t gstride, int32_t goff, void* stream_) {
+  if (grp <= 0 || !dx) return DVLA_ERR_ARG;       // (the plain entry points are the identity case; the buffer gradient is the point here)
+  return ln_bwd_launch(dy, x, gamma, param_dtype, mean, rstd, nullptr, dx, dgamma, dbeta, grad_dtype, partial, rows, cols, grp, gstride, goff,
+                       stream_);
+}
+
+static int ln_bwd_launch(const void* dy, const void* x, const void* gamma, int32_t param_dtype, const float* mean, const float* rstd,
+                         const void* dres, void* dx, void* dgamma, void* dbeta, int32_t grad_dtype, float* partial, int64_t rows,
+                         int64_t cols, int32_t grp, int32_t gstride, int32_t goff, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!ln_groups_ok(rows, grp, gstride, goff)) return DVLA_ERR_ARG;
   if (grad_dtype != DVLA_DT_F32 && grad_dtype != DVLA_DT_BF16) return DVLA_ERR_ARG;
   const bf16_t* drp = reinterpret_cast<const bf16_t*>(dres);
   if ((reinterpret_cast<uintptr_t>(dres) & 15) != 0) return DVLA_ERR_UNSUPPORTED;
@@ -332,10 +392,10 @@ extern "C" int dvla_layernorm_bwd_add(const void* dy, const void* x, const void*
   const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
   bf16_t* dxp = reinterpret_cast<bf16_t*>(dx);
   switch (vpl) {
-    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp); break;
-    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp); break;
-    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp); break;
-    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp); break;
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff); break;
+    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff); break;
   }
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;

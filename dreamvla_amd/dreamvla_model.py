@@ -371,7 +371,12 @@ class DreamVLA(nn.Module):
         x = decoder[0].forward_shared_suffix(emb + pos[:, :n_q], (mask_token.to(emb.dtype) + pos[:, n_q:])[0], n2)
         for blk in list(decoder)[1:]:
             x = blk(x)
-        x = norm(x[:, -n_mask:, :].reshape(-1, Hd))
+        # the prediction layer sees the mask tokens only (dreamvla_model.py:812-816): normalised straight out of the (n2, n_q + n_mask, H)
+        # stream -- the strided slice is never copied, and its backward writes the whole stream's gradient (zeros for the query tokens)
+        if os.environ.get("DVLA_LN_ROWS") == "0":      # (same-box A/B of the row-group LayerNorm: the copy of the strided slice)
+            x = norm(x[:, -n_mask:, :].reshape(-1, Hd))
+        else:
+            x = norm.last_tokens(x, n_mask)
         return pred(x, act=act)
 
     def forward(self, image_primary, image_wrist, state, text_token, action=None, track_infos=None, action_label=None,

@@ -33,6 +33,10 @@ class LayerNorm(nn.LayerNorm):
         LayerNorm-backward kernel (ops._LayerNormFork)."""
         return ops.layer_norm_fork(x, self.weight, self.bias, self.eps)
 
+    def last_tokens(self, x, keep):
+        """LayerNorm(x[:, -keep:, :]) as (n * keep, D) without copying the strided slice (ops._LayerNormRows)."""
+        return ops.layer_norm_last_tokens(x, self.weight, self.bias, self.eps, keep)
+
 
 class Conv1D(nn.Module):
     """HF GPT-2 Conv1D: y = x @ W + b with W of shape (nx, nf)."""

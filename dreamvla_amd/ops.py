@@ -1246,6 +1246,70 @@ class _LayerNormFork(torch.autograd.Function):
         return dx.view(ctx.x_shape), dg, (db if ctx.has_beta else None), None
 
 
+class _LayerNormRows(torch.autograd.Function):
+    """LayerNorm over the last `keep` tokens of every sequence of x (n, L, D) -> (n * keep, D), without materialising the strided
+    slice (dvla_layernorm_fwd_rows / _bwd_rows): the dream-head decoders' `norm(x[:, -n_mask:, :])`.  Backward returns the gradient of
+    the whole (n, L, D) buffer, zeros in the leading L - keep tokens of every sequence (written by the kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, keep):
+        lib = _lib.load()
+        _req(x, "layernorm.input")
+        n, L, D = x.shape
+        if not x.is_contiguous():
+            x = x.contiguous()
+        need_grad = any(ctx.needs_input_grad)
+        rows = n * keep
+        y = torch.empty((rows, D), dtype=x.dtype, device=x.device)
+        mean = rstd = None
+        if need_grad:
+            mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
+        check(lib.dvla_layernorm_fwd_rows(x.data_ptr(), _ptr(gamma), _ptr(beta), pdt, y.data_ptr(), _ptr(mean), _ptr(rstd),
+                                          rows, D, float(eps), keep, L, L - keep, _stream()), "dvla_layernorm_fwd_rows")
+        ctx.keep, ctx.has_affine, ctx.has_beta = keep, gamma is not None, beta is not None
+        if need_grad:
+            ctx.save_for_backward(x, gamma, mean, rstd, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, mean, rstd, beta = ctx.saved_tensors
+        n, L, D = x.shape
+        keep = ctx.keep
+        rows = n * keep
+        dy2 = _req(dy, "layernorm.grad_output").reshape(rows, D)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        need_p = ctx.has_affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        gdt = gamma.dtype if need_p else torch.float32
+        dx = torch.empty_like(x)
+        dg = db = part = None
+        if need_p:
+            dg = _grad_dest(gamma, gdt)
+            db = _grad_dest(beta, gdt) if ctx.has_beta else None
+            dg = dg if dg is not None else torch.empty(D, dtype=gdt, device=x.device)
+            db = db if (db is not None or not ctx.has_beta) else torch.empty(D, dtype=gdt, device=x.device)
+            part = torch.empty(2 * lib.dvla_layernorm_bwd_partial_rows() * D, dtype=torch.float32, device=x.device)
+        pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
+        check(lib.dvla_layernorm_bwd_rows(dy2.data_ptr(), x.data_ptr(), _ptr(gamma), pdt, mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                          _ptr(dg), _ptr(db), DT_F32 if gdt == torch.float32 else DT_BF16, _ptr(part), rows, D,
+                                          keep, L, L - keep, _stream()), "dvla_layernorm_bwd_rows")
+        return dx, dg, (db if ctx.has_beta else None), None, None
+
+
+def layer_norm_last_tokens(x, weight, bias, eps, keep):
+    """LayerNorm(x[:, -keep:, :]) of x (n, L, D) as (n * keep, D); one kernel each way, no copy of the slice."""
+    x = to_compute(x)
+    if x.dim() != 3 or not (0 < keep <= x.shape[1]) or x.shape[-1] % 8 != 0 or x.shape[-1] > 2048:
+        raise ValueError("layer_norm_last_tokens: x (n, L, D) with D % 8 == 0, D <= 2048 and 0 < keep <= L")
+    if weight is not None and bias is not None and bias.dtype != weight.dtype:
+        raise TypeError("layernorm weight/bias dtype mismatch")
+    return _LayerNormRows.apply(x, weight, bias, float(eps), int(keep))
+
+
 def layer_norm_fork(x, weight, bias, eps):
     """-> (x as the residual operand, LayerNorm(x)); see _LayerNormFork.  Without autograd it is layer_norm."""
     x = to_compute(x)

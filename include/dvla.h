@@ -40,7 +40,7 @@ extern "C" {
  * weight-gradient GEMM (ksum_* fields of dvla_gemm_params); 5 = dvla_ddim_cfg_step, dvla_act_bwd_colsum, a_layernorm,
  * GEMM configuration 11; 6 = dvla_dit_sample (the evaluation sampler as one persistent kernel); 7 = round 5: the sampler's
  * status word no longer carries over to the next launch (workspace words 33 / 34), dvla_dit_sample_inject_timeouts. */
-#define DVLA_ABI_VERSION 7
+#define DVLA_ABI_VERSION 8
 int dvla_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -148,6 +148,19 @@ int dvla_layernorm_bwd_add(const void* dy, const void* x, const void* gamma, int
                            const float* mean, const float* rstd, const void* dres, void* dx, void* dgamma,
                            void* dbeta, int32_t grad_dtype, float* partial, int64_t rows, int64_t cols, void* stream);
 int64_t dvla_layernorm_bwd_partial_rows(void);
+/* (ABI 8) LayerNorm over the LAST `grp` rows of every `gstride`-row sequence of a (n_seq * gstride, cols) buffer, `goff` = gstride - grp
+ * rows skipped in front of each group -- the dream-head decoders normalise only their mask-token rows before the prediction layer
+ * (`x = self.image_decoder_norm(x[:, -n_mask:, :])`, models/dreamvla_model.py:812-816 and the depth / dino / sam / trajectory twins):
+ * the slice is strided across sequences, and as an ATen copy (+ a zero-fill and a copy-back in backward) it was six launches and ~0.5 ms
+ * per step.  rows = n_seq * grp logical rows; y, mean, rstd, dy are contiguous over them; x is read, and dx (the gradient of the WHOLE
+ * buffer: zeros outside the groups, written by the kernel) is stored, in the buffer's rows.  General in goff: 0 <= goff, goff + grp <= gstride. */
+int dvla_layernorm_fwd_rows(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
+                            float* mean, float* rstd, int64_t rows, int64_t cols, float eps,
+                            int32_t grp, int32_t gstride, int32_t goff, void* stream);
+int dvla_layernorm_bwd_rows(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
+                            const float* mean, const float* rstd, void* dx, void* dgamma, void* dbeta,
+                            int32_t grad_dtype, float* partial, int64_t rows, int64_t cols,
+                            int32_t grp, int32_t gstride, int32_t goff, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Fused multi-head attention, head_dim = 64 (every attention in DreamVLA: ViT 768/12, trunk 1024/16,

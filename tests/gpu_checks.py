@@ -609,6 +609,45 @@ def check_layernorm_fork(rows, cols, affine=True, eps=1e-5, seed=0):
     return out
 
 
+def check_layernorm_last_tokens(n, L, keep, cols, param_f32=False, eps=1e-5, seed=0):
+    """ops.layer_norm_last_tokens (dvla_layernorm_fwd_rows / _bwd_rows, round 6): LayerNorm(x[:, -keep:, :]) of x (n, L, cols) without the
+    strided copy, against the oracle's LayerNorm on the materialised slice; the input gradient is the gradient of the WHOLE buffer
+    (zeros in the leading L - keep tokens of every sequence: the buffer is pre-filled with NaN-free garbage by the allocator, the
+    kernel must write them)."""
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(299 + seed)
+    x = R.bf16_round(rnd((n, L, cols), g, 2.0) + 0.5)
+    w = R.bf16_round(rnd((cols,), g) + 1.0)
+    b = R.bf16_round(rnd((cols,), g))
+    dy = rnd((n * keep, cols), g)
+    pdt = torch.float32 if param_f32 else BF
+    torch.full((n, L, cols), 7.0, device=DEV, dtype=BF)          # (dirty the allocator's pool: an unwritten gradient row would show)
+    xd = x.to(DEV, BF).requires_grad_(True)
+    wd = w.to(DEV, pdt).requires_grad_(True)
+    bd = b.to(DEV, pdt).requires_grad_(True)
+    y = ops.layer_norm_last_tokens(xd, wd, bd, eps, keep)
+    y.backward(dy.to(DEV, BF))
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = R.layer_norm(xr[:, L - keep:, :].reshape(-1, cols), wr, br, eps)
+    yr.backward(dy)
+    tag = f"layernorm_last_tokens {n}x{L}(keep {keep})x{cols} pf32{int(param_f32)}"
+    lead = xd.grad[:, :L - keep, :]
+    out = [metrics(tag + " y", y, yr, TOL_FWD), metrics(tag + " dx (whole buffer)", xd.grad, xr.grad, TOL_GRAD),
+           {"name": tag + " leading tokens get exact zeros", "ok": bool((lead == 0).all()) if lead.numel() else True, "rel_l2": 0.0,
+            "max_abs": float(lead.float().abs().max()) if lead.numel() else 0.0, "tol": 0.0},
+           metrics(tag + " dgamma", wd.grad, wr.grad, TOL_GRAD, round_ref=not param_f32),
+           metrics(tag + " dbeta", bd.grad, br.grad, TOL_GRAD, round_ref=not param_f32)]
+    # the same numbers as the two-step path (copy the slice, plain LayerNorm): bit for bit
+    xd2 = x.to(DEV, BF).requires_grad_(True)
+    w2, b2 = wd.detach().clone().requires_grad_(True), bd.detach().clone().requires_grad_(True)
+    y2 = ops.layer_norm(xd2[:, L - keep:, :].reshape(-1, cols), w2, b2, eps)
+    y2.backward(dy.to(DEV, BF))
+    out.append(metrics(tag + " y == LayerNorm(copy of the slice)", y, y2.detach().float().cpu(), 0.0))
+    out.append(metrics(tag + " dx == the two-step path", xd.grad, xd2.grad.detach().float().cpu(), 0.0))
+    return out
+
+
 def make_block_mask(L, blk, nA):
     """small analogue of generate_attention_mask (dreamvla_model.py:25-66): block-causal over `blk`-token steps,
     the last blk-nA tokens of every step are never keys."""
@@ -1025,6 +1064,10 @@ def all_checks(quick=False):
         (check_layernorm, dict(rows=9, cols=2048)),
         (check_layernorm_fork, dict(rows=1000, cols=1024)),
         (check_layernorm_fork, dict(rows=77, cols=768, affine=False, eps=1e-6)),
+        (check_layernorm_last_tokens, dict(n=5, L=205, keep=196, cols=1024)),
+        (check_layernorm_last_tokens, dict(n=3, L=265, keep=256, cols=1024, param_f32=True)),
+        (check_layernorm_last_tokens, dict(n=7, L=21, keep=21, cols=768, eps=1e-6)),
+        (check_layernorm_last_tokens, dict(n=4, L=40, keep=1, cols=512)),
     ]
     L += [
         (check_self_attention, dict(B=2, H=2, L=32)),

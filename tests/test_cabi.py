@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/dvla.h but not exported"
     assert set(syms) == set(_lib.SYMBOLS), (set(syms) ^ set(_lib.SYMBOLS))
-    assert lib.dvla_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.dvla_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_structs_match_header_layout():
