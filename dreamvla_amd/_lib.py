@@ -103,8 +103,8 @@ SYMBOLS = {
     "dvla_layernorm_bwd": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "dvla_layernorm_bwd_add": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
     "dvla_layernorm_bwd_partial_rows": (_I64, []),
-    "dvla_layernorm_fwd_rows": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _I32, _P]),
-    "dvla_layernorm_bwd_rows": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _I32, _I32, _P]),
+    "dvla_layernorm_fwd_rows": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _I64, _I64, _F, _I32, _I32, _I32, _I32, _P]),
+    "dvla_layernorm_bwd_rows": (C.c_int, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P]),
     "dvla_attn_fwd": (C.c_int, [C.POINTER(AttnParams), _P]),
     "dvla_attn_bwd": (C.c_int, [C.POINTER(AttnParams), _P]),
     "dvla_attn_small_fwd": (C.c_int, [C.POINTER(AttnParams), _I32, _P]),

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16_t* __rest
                                                             const void* __restrict__ beta, int pf32,
                                                             bf16_t* __restrict__ y, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, int64_t rows, int cols,
-                                                            float eps, int grp, int gstride, int goff) {
+                                                            float eps, int grp, int gstride, int goff, int omap) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols >> 3;
   const float inv_n = 1.0f / (float)cols;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16_t* __rest
   int64_t row = (int64_t)blockIdx.x * 4 + wave;
   uint4 raw[VPL], nxt[VPL];
   auto load_row = [&](int64_t r, uint4 (&dst)[VPL]) {
-    const uint4* xr = reinterpret_cast<const uint4*>(x + ln_buf_row(r, grp, gstride, goff) * cols);
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (omap ? r : ln_buf_row(r, grp, gstride, goff)) * cols);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int vi = lane + 64 * i;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16_t* __rest
       if (mean_out) mean_out[row] = mean;
       if (rstd_out) rstd_out[row] = rstd;
     }
-    uint4* yr = reinterpret_cast<uint4*>(y + row * cols);
+    uint4* yr = reinterpret_cast<uint4*>(y + (omap ? ln_buf_row(row, grp, gstride, goff) : row) * cols);     // omap: the OUTPUT lives in the buffer's rows
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int vi = lane + 64 * i;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             bf16_t* __restrict__ dx, float* __restrict__ partial,
                                                             int64_t rows, int cols, const bf16_t* __restrict__ dres,
-                                                            int grp, int gstride, int goff) {
+                                                            int grp, int gstride, int goff, int omap) {
   __shared__ float red[4][64 * 8];  // one vector-slot at a time: [wave][lane*8+e]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols >> 3;
@@ -156,8 +156,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
   uint4 rx[VPL], rg[VPL], rr[VPL], nx[VPL], ng[VPL], nr[VPL];
   float mu = 0.f, rs = 0.f, nmu = 0.f, nrs = 0.f;
   auto load_row = [&](int64_t r, uint4 (&dx_)[VPL], uint4 (&dg_)[VPL], uint4 (&dr_)[VPL], float& m_, float& r_) {
-    const uint4* xr = reinterpret_cast<const uint4*>(x + ln_buf_row(r, grp, gstride, goff) * cols);     // (row groups: x and dx in the buffer's rows)
-    const uint4* gr = reinterpret_cast<const uint4*>(dy + r * cols);
+    // row groups: x and dx in the buffer's rows (omap == 0), or dy in the buffer's rows and x / dx contiguous (omap != 0)
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (omap ? r : ln_buf_row(r, grp, gstride, goff)) * cols);
+    const uint4* gr = reinterpret_cast<const uint4*>(dy + (omap ? ln_buf_row(r, grp, gstride, goff) : r) * cols);
     const uint4* sr = dres ? reinterpret_cast<const uint4*>(dres + r * cols) : nullptr;
     m_ = mean[r]; r_ = rstd[r];
 #pragma unroll
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
       // tokens -- only the parameter gradients are wanted: no row reductions, no 135-MB store)
     s1 = wave_sum(s1) * inv_n;
     s2 = wave_sum(s2) * inv_n;
-    uint4* dr = reinterpret_cast<uint4*>(dx + ln_buf_row(row, grp, gstride, goff) * cols);
-    if (grp != 0 && (uint32_t)row % (uint32_t)grp == 0u) {
+    uint4* dr = reinterpret_cast<uint4*>(dx + (omap ? row : ln_buf_row(row, grp, gstride, goff)) * cols);
+    if (grp != 0 && !omap && (uint32_t)row % (uint32_t)grp == 0u) {
       // row groups: dx is the gradient of the WHOLE buffer -- the rows of this sequence outside the group get zeros, written by
       // the wave that owns the group's first row
       const int64_t base = (int64_t)((uint32_t)row / (uint32_t)grp) * gstride;
@@ -306,17 +307,18 @@ static bool ln_groups_ok(int64_t rows, int32_t grp, int32_t gstride, int32_t gof
 
 extern "C" int dvla_layernorm_fwd_rows(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
                                        float* mean, float* rstd, int64_t rows, int64_t cols, float eps,
-                                       int32_t grp, int32_t gstride, int32_t goff, void* stream_);
+                                       int32_t grp, int32_t gstride, int32_t goff, int32_t map_output, void* stream_);
 
 extern "C" int dvla_layernorm_fwd(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
                                   float* mean, float* rstd, int64_t rows, int64_t cols, float eps, void* stream_) {
-  return dvla_layernorm_fwd_rows(x, gamma, beta, param_dtype, y, mean, rstd, rows, cols, eps, 0, 0, 0, stream_);
+  return dvla_layernorm_fwd_rows(x, gamma, beta, param_dtype, y, mean, rstd, rows, cols, eps, 0, 0, 0, 0, stream_);
 }
 
 extern "C" int dvla_layernorm_fwd_rows(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
                                        float* mean, float* rstd, int64_t rows, int64_t cols, float eps,
-                                       int32_t grp, int32_t gstride, int32_t goff, void* stream_) {
+                                       int32_t grp, int32_t gstride, int32_t goff, int32_t map_output, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (map_output && grp == 0) return DVLA_ERR_ARG;
   if (!x || !y || rows < 0 || cols <= 0) return DVLA_ERR_ARG;
   if (!ln_groups_ok(rows, grp, gstride, goff)) return DVLA_ERR_ARG;
   if (rows == 0) return DVLA_OK;
@@ -328,10 +330,10 @@ extern "C" int dvla_layernorm_fwd_rows(const void* x, const void* gamma, const v
   const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
   bf16_t* yp = reinterpret_cast<bf16_t*>(y);
   switch (vpl) {
-    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff); break;
-    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff); break;
-    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff); break;
-    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff); break;
+    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff, map_output ? 1 : 0); break;
+    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff, map_output ? 1 : 0); break;
+    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff, map_output ? 1 : 0); break;
+    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, xp, gamma, beta, pf32, yp, mean, rstd, rows, (int)cols, eps, grp, gstride, goff, map_output ? 1 : 0); break;
   }
   return dvla_check_launch();
 }
@@ -350,29 +352,30 @@ extern "C" int dvla_layernorm_bwd(const void* dy, const void* x, const void* gam
 
 static int ln_bwd_launch(const void* dy, const void* x, const void* gamma, int32_t param_dtype, const float* mean, const float* rstd,
                          const void* dres, void* dx, void* dgamma, void* dbeta, int32_t grad_dtype, float* partial, int64_t rows,
-                         int64_t cols, int32_t grp, int32_t gstride, int32_t goff, void* stream_);
+                         int64_t cols, int32_t grp, int32_t gstride, int32_t goff, int32_t map_output, void* stream_);
 
 extern "C" int dvla_layernorm_bwd_add(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
                                       const float* mean, const float* rstd, const void* dres, void* dx, void* dgamma,
                                       void* dbeta, int32_t grad_dtype, float* partial, int64_t rows, int64_t cols,
                                       void* stream_) {
-  return ln_bwd_launch(dy, x, gamma, param_dtype, mean, rstd, dres, dx, dgamma, dbeta, grad_dtype, partial, rows, cols, 0, 0, 0, stream_);
+  return ln_bwd_launch(dy, x, gamma, param_dtype, mean, rstd, dres, dx, dgamma, dbeta, grad_dtype, partial, rows, cols, 0, 0, 0, 0, stream_);
 }
 
 extern "C" int dvla_layernorm_bwd_rows(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
                                        const float* mean, const float* rstd, void* dx, void* dgamma, void* dbeta,
                                        int32_t grad_dtype, float* partial, int64_t rows, int64_t cols,
-                                       int32_t grp, int32_t gstride, int32_t goff, void* stream_) {
-  if (grp <= 0 || !dx) return DVLA_ERR_ARG;       // (the plain entry points are the identity case; the buffer gradient is the point here)
+                                       int32_t grp, int32_t gstride, int32_t goff, int32_t map_output, void* stream_) {
+  if (grp <= 0 || (!dx && !map_output)) return DVLA_ERR_ARG;       // (the plain entry points are the identity case; without map_output the
+                                                                   // buffer's gradient is the point; with it dx == NULL = parameter gradients only)
   return ln_bwd_launch(dy, x, gamma, param_dtype, mean, rstd, nullptr, dx, dgamma, dbeta, grad_dtype, partial, rows, cols, grp, gstride, goff,
-                       stream_);
+                       map_output, stream_);
 }
 
 static int ln_bwd_launch(const void* dy, const void* x, const void* gamma, int32_t param_dtype, const float* mean, const float* rstd,
                          const void* dres, void* dx, void* dgamma, void* dbeta, int32_t grad_dtype, float* partial, int64_t rows,
-                         int64_t cols, int32_t grp, int32_t gstride, int32_t goff, void* stream_) {
+                         int64_t cols, int32_t grp, int32_t gstride, int32_t goff, int32_t map_output, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (!ln_groups_ok(rows, grp, gstride, goff)) return DVLA_ERR_ARG;
+  if (!ln_groups_ok(rows, grp, gstride, goff) || (map_output && grp == 0)) return DVLA_ERR_ARG;
   if (grad_dtype != DVLA_DT_F32 && grad_dtype != DVLA_DT_BF16) return DVLA_ERR_ARG;
   const bf16_t* drp = reinterpret_cast<const bf16_t*>(dres);
   if ((reinterpret_cast<uintptr_t>(dres) & 15) != 0) return DVLA_ERR_UNSUPPORTED;
@@ -392,10 +395,10 @@ static int ln_bwd_launch(const void* dy, const void* x, const void* gamma, int32
   const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
   bf16_t* dxp = reinterpret_cast<bf16_t*>(dx);
   switch (vpl) {
-    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff); break;
-    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff); break;
-    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff); break;
-    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff); break;
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff, map_output ? 1 : 0); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff, map_output ? 1 : 0); break;
+    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff, map_output ? 1 : 0); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dyp, xp, gamma, pf32, mean, rstd, dxp, part, rows, (int)cols, drp, grp, gstride, goff, map_output ? 1 : 0); break;
   }
   int rc = dvla_check_launch();
   if (rc != DVLA_OK) return rc;

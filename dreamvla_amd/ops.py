@@ -1267,7 +1267,7 @@ class _LayerNormRows(torch.autograd.Function):
             rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
         check(lib.dvla_layernorm_fwd_rows(x.data_ptr(), _ptr(gamma), _ptr(beta), pdt, y.data_ptr(), _ptr(mean), _ptr(rstd),
-                                          rows, D, float(eps), keep, L, L - keep, _stream()), "dvla_layernorm_fwd_rows")
+                                          rows, D, float(eps), keep, L, L - keep, 0, _stream()), "dvla_layernorm_fwd_rows")
         ctx.keep, ctx.has_affine, ctx.has_beta = keep, gamma is not None, beta is not None
         if need_grad:
             ctx.save_for_backward(x, gamma, mean, rstd, beta)
@@ -1296,8 +1296,84 @@ class _LayerNormRows(torch.autograd.Function):
         pdt = _param_dt(gamma, "layernorm.weight") if gamma is not None else DT_BF16
         check(lib.dvla_layernorm_bwd_rows(dy2.data_ptr(), x.data_ptr(), _ptr(gamma), pdt, mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
                                           _ptr(dg), _ptr(db), DT_F32 if gdt == torch.float32 else DT_BF16, _ptr(part), rows, D,
-                                          keep, L, L - keep, _stream()), "dvla_layernorm_bwd_rows")
+                                          keep, L, L - keep, 0, _stream()), "dvla_layernorm_bwd_rows")
         return dx, dg, (db if ctx.has_beta else None), None, None
+
+
+class _LayerNormConcat(torch.autograd.Function):
+    """cat((LayerNorm_a(a), LayerNorm_b(b)), dim=1) of a (n, La, D) and b (n, Lb, D) -> (n, La + Lb, D): each LayerNorm writes its row range
+    of the ONE output buffer (dvla_layernorm_fwd_rows, map_output), and backward reads its rows of the incoming gradient in place
+    (dvla_layernorm_bwd_rows) -- no torch.cat forward, no copies of the cat's strided gradient slices backward.  The PerceiverResampler's
+    `to_kv(torch.cat((norm_media(x), norm_latents(latents)), dim=-2))` (models/perceiver_resampler.py:44-49)."""
+
+    @staticmethod
+    def forward(ctx, a, ga, ba, b, gb, bb, eps_a, eps_b):
+        lib = _lib.load()
+        _req(a, "layernorm.input"); _req(b, "layernorm.input")
+        n, La, D = a.shape
+        Lb = b.shape[1]
+        if b.shape[0] != n or b.shape[2] != D:
+            raise ValueError("layer_norm_concat: (n, La, D) and (n, Lb, D)")
+        a = a if a.is_contiguous() else a.contiguous()
+        b = b if b.is_contiguous() else b.contiguous()
+        L = La + Lb
+        out = torch.empty((n, L, D), dtype=a.dtype, device=a.device)
+        need_grad = any(ctx.needs_input_grad)
+        stats = []
+        for (x, g, be, Lx, off, eps) in ((a, ga, ba, La, 0, eps_a), (b, gb, bb, Lb, La, eps_b)):
+            rows = n * Lx
+            mean = torch.empty(rows, dtype=torch.float32, device=a.device) if need_grad else None
+            rstd = torch.empty(rows, dtype=torch.float32, device=a.device) if need_grad else None
+            pdt = _param_dt(g, "layernorm.weight") if g is not None else DT_BF16
+            check(lib.dvla_layernorm_fwd_rows(x.data_ptr(), _ptr(g), _ptr(be), pdt, out.data_ptr(), _ptr(mean), _ptr(rstd), rows, D, float(eps),
+                                              Lx, L, off, 1, _stream()), "dvla_layernorm_fwd_rows")
+            stats += [mean, rstd]
+        ctx.dims = (n, La, Lb, D)
+        ctx.flags = (ga is not None, ba is not None, gb is not None, bb is not None)
+        if need_grad:
+            ctx.save_for_backward(a, ga, ba, b, gb, bb, *stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        a, ga, ba, b, gb, bb, mean_a, rstd_a, mean_b, rstd_b = ctx.saved_tensors
+        n, La, Lb, D = ctx.dims
+        L = La + Lb
+        dout = _req(dout, "layernorm.grad_output")
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        res = []
+        for k, (x, g, be, mean, rstd, Lx, off) in enumerate(((a, ga, ba, mean_a, rstd_a, La, 0), (b, gb, bb, mean_b, rstd_b, Lb, La))):
+            need_x = ctx.needs_input_grad[3 * k]
+            need_p = g is not None and (ctx.needs_input_grad[3 * k + 1] or ctx.needs_input_grad[3 * k + 2])
+            if not (need_x or need_p):
+                res += [None, None, None]
+                continue
+            rows = n * Lx
+            gdt = g.dtype if need_p else torch.float32
+            dx = torch.empty_like(x) if need_x else None      # (no input gradient wanted: neither reduced nor stored)
+            dg = db = part = None
+            if need_p:
+                dg = _grad_dest(g, gdt)
+                dg = dg if dg is not None else torch.empty(D, dtype=gdt, device=x.device)
+                if be is not None:
+                    db = _grad_dest(be, gdt)
+                    db = db if db is not None else torch.empty(D, dtype=gdt, device=x.device)
+                part = torch.empty(2 * lib.dvla_layernorm_bwd_partial_rows() * D, dtype=torch.float32, device=x.device)
+            pdt = _param_dt(g, "layernorm.weight") if g is not None else DT_BF16
+            check(lib.dvla_layernorm_bwd_rows(dout.data_ptr(), x.data_ptr(), _ptr(g), pdt, mean.data_ptr(), rstd.data_ptr(), _ptr(dx),
+                                              _ptr(dg), _ptr(db), DT_F32 if gdt == torch.float32 else DT_BF16, _ptr(part), rows, D,
+                                              Lx, L, off, 1, _stream()), "dvla_layernorm_bwd_rows")
+            res += [dx, dg, db]
+        return (*res[:3], *res[3:], None, None)
+
+
+def layer_norm_concat(a, wa, ba, eps_a, b, wb, bb, eps_b):
+    """cat((LayerNorm(a; wa, ba), LayerNorm(b; wb, bb)), dim=1) in two launches on one output buffer; see _LayerNormConcat."""
+    a, b = to_compute(a), to_compute(b)
+    if a.dim() != 3 or b.dim() != 3 or a.shape[-1] % 8 != 0 or a.shape[-1] > 2048:
+        raise ValueError("layer_norm_concat: (n, La, D) and (n, Lb, D) with D % 8 == 0, D <= 2048")
+    return _LayerNormConcat.apply(a, wa, ba, b, wb, bb, float(eps_a), float(eps_b))
 
 
 def layer_norm_last_tokens(x, weight, bias, eps, keep):

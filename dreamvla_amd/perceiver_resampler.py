@@ -9,6 +9,8 @@ Per layer (perceiver_resampler.py:35-61,124-128):
 `sim - sim.amax()` before the softmax (line 57) is the usual max subtraction the fused kernel does anyway; the
 `q * scale` pre-scaling (line 53) is folded into the kernel's score scale.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -43,10 +45,19 @@ class PerceiverAttention(nn.Module):
     def forward(self, x, latents):
         """x: (n, n1, D) media tokens, latents: (n, n2, D).  Returns latents + attention (the residual add is fused
         into the to_out GEMM epilogue)."""
-        xn = self.norm_media(x)
-        ln = self.norm_latents(latents)
-        q = self.to_q(ln)
-        kv = self.to_kv(torch.cat((xn, ln), dim=-2))
+        if os.environ.get("DVLA_LN_CONCAT") == "0":      # (same-box A/B of the fused concatenation: the ATen form)
+            xn = self.norm_media(x)
+            ln = self.norm_latents(latents)
+            q = self.to_q(ln)
+            kv = self.to_kv(torch.cat((xn, ln), dim=-2))
+        else:
+            # the two LayerNorms write the two row ranges of ONE (n, n1 + n2, D) buffer: no torch.cat, and in backward no copies of
+            # the cat's strided gradient slices (ops._LayerNormConcat).  The queries take their own LayerNorm of the 16 latents
+            # (a second, tiny launch): slicing them out of the buffer would send a zero-filled (n, n1 + n2, D) gradient back into it.
+            both = ops.layer_norm_concat(x, self.norm_media.weight, self.norm_media.bias, self.norm_media.eps,
+                                         latents, self.norm_latents.weight, self.norm_latents.bias, self.norm_latents.eps)
+            q = self.to_q(self.norm_latents(latents))
+            kv = self.to_kv(both)
         o = ops.cross_attention(q, kv, self.heads, scale=self.scale)
         return self.to_out(o, residual=latents)
 

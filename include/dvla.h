@@ -153,14 +153,18 @@ int64_t dvla_layernorm_bwd_partial_rows(void);
  * (`x = self.image_decoder_norm(x[:, -n_mask:, :])`, models/dreamvla_model.py:812-816 and the depth / dino / sam / trajectory twins):
  * the slice is strided across sequences, and as an ATen copy (+ a zero-fill and a copy-back in backward) it was six launches and ~0.5 ms
  * per step.  rows = n_seq * grp logical rows; y, mean, rstd, dy are contiguous over them; x is read, and dx (the gradient of the WHOLE
- * buffer: zeros outside the groups, written by the kernel) is stored, in the buffer's rows.  General in goff: 0 <= goff, goff + grp <= gstride. */
+ * buffer: zeros outside the groups, written by the kernel) is stored, in the buffer's rows.  General in goff: 0 <= goff, goff + grp <= gstride.
+ * map_output != 0 is the mirror image: x (and dx) contiguous over the logical rows, the OUTPUT y (forward) and the incoming gradient dy
+ * (backward) in the buffer's rows, nothing zero-filled -- two LayerNorms writing the two row ranges of one buffer replace
+ * `torch.cat((norm_media(x), norm_latents(latents)), dim=-2)` of the PerceiverResampler (models/perceiver_resampler.py:44-49) and, in
+ * backward, the copies of the cat's strided gradient slices. */
 int dvla_layernorm_fwd_rows(const void* x, const void* gamma, const void* beta, int32_t param_dtype, void* y,
                             float* mean, float* rstd, int64_t rows, int64_t cols, float eps,
-                            int32_t grp, int32_t gstride, int32_t goff, void* stream);
+                            int32_t grp, int32_t gstride, int32_t goff, int32_t map_output, void* stream);
 int dvla_layernorm_bwd_rows(const void* dy, const void* x, const void* gamma, int32_t param_dtype,
                             const float* mean, const float* rstd, void* dx, void* dgamma, void* dbeta,
                             int32_t grad_dtype, float* partial, int64_t rows, int64_t cols,
-                            int32_t grp, int32_t gstride, int32_t goff, void* stream);
+                            int32_t grp, int32_t gstride, int32_t goff, int32_t map_output, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Fused multi-head attention, head_dim = 64 (every attention in DreamVLA: ViT 768/12, trunk 1024/16,

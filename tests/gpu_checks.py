@@ -648,6 +648,48 @@ def check_layernorm_last_tokens(n, L, keep, cols, param_f32=False, eps=1e-5, see
     return out
 
 
+def check_layernorm_concat(n, La, Lb, cols, a_needs_grad=True, seed=0):
+    """ops.layer_norm_concat (dvla_layernorm_*_rows with map_output, round 6): cat((LN_a(a), LN_b(b)), dim=1) written by two launches into
+    one buffer, against the oracle's two LayerNorms + cat; and bit for bit against ops.layer_norm + torch.cat on the device.
+    a_needs_grad=False: the resampler's media tokens (no input gradient for a, parameter gradients still)."""
+    from dreamvla_amd import ops
+    g = torch.Generator().manual_seed(399 + seed)
+    a = R.bf16_round(rnd((n, La, cols), g, 2.0) + 0.5)
+    b = R.bf16_round(rnd((n, Lb, cols), g, 1.5) - 0.25)
+    wa, ba = R.bf16_round(rnd((cols,), g) + 1.0), R.bf16_round(rnd((cols,), g))
+    wb, bb = R.bf16_round(rnd((cols,), g) + 1.0), R.bf16_round(rnd((cols,), g))
+    dy = rnd((n, La + Lb, cols), g)
+    def dev(t, grad=True):
+        return t.to(DEV, BF).requires_grad_(grad)
+    ad, bd = dev(a, a_needs_grad), dev(b)
+    wad, bad, wbd, bbd = dev(wa), dev(ba), dev(wb), dev(bb)
+    y = ops.layer_norm_concat(ad, wad, bad, 1e-5, bd, wbd, bbd, 1e-5)
+    y.backward(dy.to(DEV, BF))
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    war, bar, wbr, bbr = (t.clone().requires_grad_(True) for t in (wa, ba, wb, bb))
+    yr = torch.cat((R.layer_norm(ar, war, bar, 1e-5), R.layer_norm(br, wbr, bbr, 1e-5)), dim=1)
+    yr.backward(dy)
+    tag = f"layernorm_concat {n}x({La}+{Lb})x{cols} a_grad{int(a_needs_grad)}"
+    out = [metrics(tag + " y", y, yr, TOL_FWD), metrics(tag + " db_in", bd.grad, br.grad, TOL_GRAD),
+           metrics(tag + " dgamma_a", wad.grad, war.grad, TOL_GRAD), metrics(tag + " dbeta_a", bad.grad, bar.grad, TOL_GRAD),
+           metrics(tag + " dgamma_b", wbd.grad, wbr.grad, TOL_GRAD), metrics(tag + " dbeta_b", bbd.grad, bbr.grad, TOL_GRAD)]
+    if a_needs_grad:
+        out.append(metrics(tag + " da_in", ad.grad, ar.grad, TOL_GRAD))
+    else:
+        out.append({"name": tag + " no gradient for a", "ok": ad.grad is None, "rel_l2": 0.0, "max_abs": 0.0, "tol": 0.0})
+    # the ATen form on the device: same numbers
+    a2, b2 = dev(a, a_needs_grad), dev(b)
+    wa2, ba2, wb2, bb2 = dev(wa), dev(ba), dev(wb), dev(bb)
+    y2 = torch.cat((ops.layer_norm(a2, wa2, ba2, 1e-5), ops.layer_norm(b2, wb2, bb2, 1e-5)), dim=1)
+    y2.backward(dy.to(DEV, BF))
+    cpu = lambda t: t.detach().float().cpu()
+    out.append(metrics(tag + " y == cat of two LayerNorms", y, cpu(y2), 0.0))
+    out.append(metrics(tag + " db_in == ATen form", bd.grad, cpu(b2.grad), 0.0))
+    out.append(metrics(tag + " dgamma_a == ATen form", wad.grad, cpu(wa2.grad), 0.0))
+    out.append(metrics(tag + " dgamma_b == ATen form", wbd.grad, cpu(wb2.grad), 0.0))
+    return out
+
+
 def make_block_mask(L, blk, nA):
     """small analogue of generate_attention_mask (dreamvla_model.py:25-66): block-causal over `blk`-token steps,
     the last blk-nA tokens of every step are never keys."""
@@ -1068,6 +1110,8 @@ def all_checks(quick=False):
         (check_layernorm_last_tokens, dict(n=3, L=265, keep=256, cols=1024, param_f32=True)),
         (check_layernorm_last_tokens, dict(n=7, L=21, keep=21, cols=768, eps=1e-6)),
         (check_layernorm_last_tokens, dict(n=4, L=40, keep=1, cols=512)),
+        (check_layernorm_concat, dict(n=6, La=196, Lb=16, cols=768, a_needs_grad=False)),
+        (check_layernorm_concat, dict(n=5, La=33, Lb=7, cols=1024)),
     ]
     L += [
         (check_self_attention, dict(B=2, H=2, L=32)),
