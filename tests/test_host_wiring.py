@@ -46,3 +46,22 @@ def test_assemble_tokens_gradient_routing(monkeypatch):
     assert torch.equal(img.grad, g[:, :, 1:5])
     assert torch.allclose(tok.grad.float(), gf[:, :, 5:10].sum((0, 1), keepdim=True), atol=0.1)
     assert torch.allclose(pos.grad.float(), gf.sum((0, 2)).reshape(1, S, 1, H), atol=0.1)
+
+
+def test_auto_split_k_picks_the_measured_minima():
+    """ops.auto_split_k against the round-6 sweep on an MI355X (profiles/r06_small_dw_sweep.txt and the large-shape sweep of the same
+    probe): for the step's weight gradients the heuristic's slice count is the measured minimum (or within 3 % of it), and the
+    invariants it is built on hold -- no split for outputs that fill the chip, slices of at least ~1.3 k of K, at most 16."""
+    from dreamvla_amd.ops import auto_split_k
+    measured_min = {(1024, 3072, 20832): 5, (1024, 4096, 20832): 4, (4096, 1024, 20832): 4, (1024, 1024, 20832): 16,
+                    (3072, 1024, 91840): 5, (1024, 4096, 91840): 4, (1024, 1024, 91840): 16, (2304, 768, 10752): 8}
+    for (M, N, K), sk in measured_min.items():
+        assert auto_split_k(M, N, K) == sk, (M, N, K, auto_split_k(M, N, K))
+    # within 3 % of the minimum once the XCD map covers ragged grids (252 workgroups): 61.3 vs 60.6 us, 61.6 vs 60.5 us
+    assert auto_split_k(768, 3072, 10752) == 7 and auto_split_k(3072, 768, 10752) == 7
+    for (M, N, K) in [(20832, 4096, 1024), (88256, 3072, 768), (4096, 4096, 20832)]:
+        assert auto_split_k(M, N, K) == 1                      # the output alone fills (three quarters of) the chip
+    for (M, N, K) in [(768, 768, 10752), (768, 1536, 94976), (1024, 768, 7168), (512, 512, 4096), (256, 256, 1 << 20)]:
+        sk = auto_split_k(M, N, K)
+        assert 1 <= sk <= 16 and K // sk >= 1280
+    assert auto_split_k(1024, 1024, 2048) == 1                 # short contractions are never split
