@@ -65,15 +65,18 @@ def main():
         torch.cuda.synchronize()
         ts = []
         t0 = time.perf_counter()
-        for _ in range(k):
+        mid = None
+        for i in range(k):
             t1 = time.perf_counter()
             step()
             if sync_each:
                 torch.cuda.synchronize()
                 ts.append(round((time.perf_counter() - t1) * 1e3, 1))
+            elif i == (2 * k) // 3:
+                mid = smi()              # free-running: the GPU is busy while this is read (the reading is a lagging average)
         torch.cuda.synchronize()
         print(json.dumps({"tag": tag, "steps": k, "ms_per_step": round((time.perf_counter() - t0) / k * 1e3, 2), "each": ts,
-                          "mem_GB": round(torch.cuda.memory_reserved() / 2**30, 1), "smi": smi()}), flush=True)
+                          "mem_GB": round(torch.cuda.memory_reserved() / 2**30, 1), "smi_during": mid, "smi_after": smi()}), flush=True)
 
     mode = os.environ.get("STEP_TRACE_MODE", "")
     if mode == "idle":       # 4 s of idle GPU after initialisation: is the slow phase a count of steps or time since start?
@@ -89,7 +92,7 @@ def main():
     run("first 10, synced each", 10, True)
     run("next 10, free-running", 10, False)
     run(f"next {n}, synced each", n, True)
-    run("10 free-running", 10, False)
+    run("30 free-running", 30, False)
     torch.cuda.empty_cache()
     run("after empty_cache: 10 synced", 10, True)
     run("10 free-running", 10, False)
