@@ -65,3 +65,24 @@ def test_auto_split_k_picks_the_measured_minima():
         sk = auto_split_k(M, N, K)
         assert 1 <= sk <= 16 and K // sk >= 1280
     assert auto_split_k(1024, 1024, 2048) == 1                 # short contractions are never split
+
+
+def test_layernorm_row_group_map_covers_the_buffer_exactly_once():
+    """The row map of dvla_layernorm_*_rows (csrc/layernorm.hip::ln_buf_row, restated): logical row r -> buffer row
+    (r / grp) * gstride + goff + r % grp.  For every (grp, gstride, goff) the model uses, the mapped rows plus the rows the backward
+    kernel zero-fills (the wave that owns a group's first row writes the sequence's rows outside [goff, goff + grp)) are a partition
+    of the buffer: every row of the whole-stream gradient is written exactly once (tests/gpu_checks.py::check_layernorm_last_tokens
+    checks the values on the GPU)."""
+    def buf_row(r, grp, gstride, goff):
+        return (r // grp) * gstride + goff + r % grp
+    for (n, grp, gstride, goff) in [(5, 196, 205, 9), (3, 256, 265, 9), (7, 21, 21, 0), (4, 1, 40, 39), (6, 196, 212, 0), (6, 16, 212, 196)]:
+        rows = n * grp
+        mapped = [buf_row(r, grp, gstride, goff) for r in range(rows)]
+        assert len(set(mapped)) == rows and all(0 <= m < n * gstride for m in mapped)
+        assert all(goff <= m % gstride < goff + grp for m in mapped)
+        zeroed = [(r // grp) * gstride + j for r in range(0, rows, grp) for j in range(gstride) if not (goff <= j < goff + grp)]
+        assert sorted(mapped + zeroed) == list(range(n * gstride))
+    # the two LayerNorms of the resampler (map_output) tile their buffer: media rows [0, 196) and latent rows [196, 212) of every sequence
+    a = {buf_row(r, 196, 212, 0) for r in range(6 * 196)}
+    b = {buf_row(r, 16, 212, 196) for r in range(6 * 16)}
+    assert not (a & b) and a | b == set(range(6 * 212))
